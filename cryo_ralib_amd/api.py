@@ -1,0 +1,250 @@
+"""ctypes binding of libralign_hip.so (include/ralign.h).
+
+Mirrors the reference's ctypes boundary (test_mref_gpu_align.py:91-149: cu_module,
+AlignConfig, AlignParam, get_c_ptr_array) and adds the handle-based ra_* API that works
+on device pointers (torch CUDA tensors supply the memory and the stream).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the
+engine raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libralign_hip.so")
+
+RA_MODE_MREF = 0
+RA_MODE_REFFREE = 1
+
+
+class AlignConfig(ctypes.Structure):
+    # reference: test_mref_gpu_align.py:112-123 / cuda/gpu_aln_common.h:62-74
+    _fields_ = [("sbj_num", ctypes.c_uint), ("ref_num", ctypes.c_uint), ("img_dim", ctypes.c_uint),
+                ("ring_num", ctypes.c_uint), ("ring_len", ctypes.c_uint),
+                ("shift_step", ctypes.c_float), ("shift_rng_x", ctypes.c_float), ("shift_rng_y", ctypes.c_float)]
+
+
+class AlignParam(ctypes.Structure):
+    # reference: test_mref_gpu_align.py:125-134 / cuda/gpu_aln_common.h:76-83
+    _fields_ = [("sbj_id", ctypes.c_int), ("ref_id", ctypes.c_int), ("shift_x", ctypes.c_float),
+                ("shift_y", ctypes.c_float), ("angle", ctypes.c_float), ("mirror", ctypes.c_bool)]
+
+    def __str__(self):
+        return "s_%d/r_%d::(%d,%d;%.2f)" % (self.sbj_id, self.ref_id, self.shift_x, self.shift_y, self.angle) \
+            + ("[M]" if self.mirror else "")
+
+
+class RaConfig(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int), ("first_ring", ctypes.c_int), ("last_ring", ctypes.c_int),
+                ("ring_skip", ctypes.c_int), ("xrng", ctypes.c_float), ("yrng", ctypes.c_float),
+                ("step", ctypes.c_float), ("nref", ctypes.c_int), ("mode", ctypes.c_int),
+                ("device", ctypes.c_int), ("chunk", ctypes.c_int)]
+
+
+# ra_result as a numpy record (32 bytes)
+RESULT_DTYPE = np.dtype([("alpha", np.float32), ("sx", np.float32), ("sy", np.float32), ("mirror", np.int32),
+                         ("ref_id", np.int32), ("peak", np.float32), ("angle_bin", np.int32),
+                         ("shift_idx", np.int32)])
+
+float_ptr = ctypes.POINTER(ctypes.c_float)
+aln_param_ptr = ctypes.POINTER(AlignParam)
+
+# every symbol include/ralign.h declares
+EXPORTED_SYMBOLS = [
+    "print_gpu_info", "gpu_clear", "pre_align_init", "pre_align_size_check", "pre_align_fetch",
+    "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
+    "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc",
+    "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
+    "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
+]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libralign_hip.so and declare prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise EngineError("HIP alignment library not built: %s (run `python -m cryo_ralib_amd.build`)" % p)
+    L = ctypes.CDLL(p)
+    vp = ctypes.c_void_p
+    L.ra_last_error.restype = ctypes.c_char_p
+    L.ra_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(RaConfig)]
+    L.ra_destroy.argtypes = [vp]
+    L.ra_destroy.restype = None
+    L.ra_set_stream.argtypes = [vp, vp]
+    L.ra_num_shifts.argtypes = [vp]
+    L.ra_maxrin.argtypes = [vp]
+    L.ra_lcirc.argtypes = [vp]
+    L.ra_reset_shifts.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+    L.ra_set_references.argtypes = [vp, vp]
+    L.ra_get_prepared_references.argtypes = [vp, vp]
+    L.ra_align.argtypes = [vp, vp, ctypes.c_int, vp, vp, float_ptr]
+    L.ra_transform_accumulate.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+    L.ra_update_references.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    L.ra_normalize_particles.argtypes = [vp, vp, ctypes.c_int]
+    L.ra_sync.argtypes = [vp]
+    L.ra_kernel_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    # reference surface (test_mref_gpu_align.py:95-97 sets the pointer returns to c_ulonglong)
+    L.pre_align_init.restype = ctypes.c_ulonglong
+    L.pre_align_init.argtypes = [ctypes.c_uint, ctypes.POINTER(AlignConfig), ctypes.c_uint]
+    L.pre_align_size_check.restype = ctypes.c_bool
+    L.pre_align_size_check.argtypes = [ctypes.c_uint, ctypes.POINTER(AlignConfig), ctypes.c_uint, ctypes.c_float,
+                                       ctypes.c_bool]
+    L.pre_align_fetch.argtypes = [ctypes.POINTER(float_ptr), ctypes.c_uint, ctypes.c_char_p]
+    L.pre_align_fetch.restype = None
+    L.pre_align_run.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pre_align_run.restype = None
+    L.pre_align_run_m.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pre_align_run_m.restype = ctypes.c_ulonglong
+    L.mref_align_run.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mref_align_run.restype = ctypes.c_ulonglong
+    L.mref_align_run_m.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mref_align_run_m.restype = float_ptr
+    L.get_num_ref.restype = ctypes.POINTER(ctypes.c_int)
+    L.reset_shifts.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.reset_shifts.restype = None
+    L.print_gpu_info.argtypes = [ctypes.c_uint]
+    L.print_gpu_info.restype = None
+    L.gpu_clear.restype = None
+    if path is None:
+        _lib = L
+    return L
+
+
+def get_c_ptr_array(images):
+    """array of float* over C-contiguous float32 images (test_mref_gpu_align.py:138-146)."""
+    ptrs = []
+    for img in images:
+        assert img.flags["C_CONTIGUOUS"] and img.dtype == np.float32
+        ptrs.append(img.ctypes.data_as(float_ptr))
+    return (float_ptr * len(ptrs))(*ptrs)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EngineError("%s failed (%d): %s" % (what, rc, load_library().ra_last_error().decode()))
+
+
+class Engine:
+    """Handle-based engine.  All tensor arguments are torch CUDA tensors on `device`."""
+
+    def __init__(self, nx, last_ring, xrng, yrng, step, nref, mode=RA_MODE_MREF, first_ring=1, ring_skip=1,
+                 device=0, chunk=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.cfg = RaConfig(int(nx), int(first_ring), int(last_ring), int(ring_skip), float(xrng), float(yrng),
+                            float(step), int(nref), int(mode), int(device), int(chunk))
+        self.handle = ctypes.c_void_p()
+        _check(self.lib.ra_create(ctypes.byref(self.handle), ctypes.byref(self.cfg)), "ra_create")
+        self.nx, self.nref, self.mode, self.device = int(nx), int(nref), int(mode), int(device)
+        self.dev = torch.device("cuda", device)
+
+    def close(self):
+        if self.handle:
+            self.lib.ra_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _ptr(self, t, dtype=None):
+        if t is None:
+            return None
+        assert t.is_cuda and t.is_contiguous(), "device tensor must be a contiguous CUDA tensor"
+        if dtype is not None:
+            assert t.dtype == dtype, (t.dtype, dtype)
+        return ctypes.c_void_p(t.data_ptr())
+
+    def use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.dev)
+        _check(self.lib.ra_set_stream(self.handle, ctypes.c_void_p(s.cuda_stream)), "ra_set_stream")
+
+    @property
+    def num_shifts(self):
+        return self.lib.ra_num_shifts(self.handle)
+
+    @property
+    def maxrin(self):
+        return self.lib.ra_maxrin(self.handle)
+
+    @property
+    def lcirc(self):
+        return self.lib.ra_lcirc(self.handle)
+
+    def new_state(self, n):
+        return self.torch.zeros((n, 2), dtype=self.torch.float32, device=self.dev)
+
+    def new_result(self, n):
+        return self.torch.zeros((n, 8), dtype=self.torch.int32, device=self.dev)
+
+    @staticmethod
+    def result_to_numpy(result):
+        return result.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+
+    # -- API
+    def reset_shifts(self, xrng, yrng, step):
+        _check(self.lib.ra_reset_shifts(self.handle, xrng, yrng, step), "ra_reset_shifts")
+
+    def set_references(self, refs):
+        assert refs.shape == (self.nref, self.nx, self.nx)
+        _check(self.lib.ra_set_references(self.handle, self._ptr(refs, self.torch.float32)), "ra_set_references")
+
+    def prepared_references(self):
+        out = np.zeros((self.nref, self.lcirc), np.float32)
+        _check(self.lib.ra_get_prepared_references(self.handle, out.ctypes.data_as(ctypes.c_void_p)),
+               "ra_get_prepared_references")
+        return out
+
+    def align(self, particles, state, result, cs=None):
+        n = particles.shape[0]
+        assert particles.shape[1:] == (self.nx, self.nx) and state.shape == (n, 2) and result.shape == (n, 8)
+        csp = None
+        if cs is not None:
+            csp = (ctypes.c_float * 2)(float(cs[0]), float(cs[1]))
+        _check(self.lib.ra_align(self.handle, self._ptr(particles, self.torch.float32), n,
+                                 self._ptr(state, self.torch.float32), self._ptr(result, self.torch.int32), csp),
+               "ra_align")
+
+    def transform_accumulate(self, particles, result, index0=0, aligned=None, sums=None, counts=None):
+        n = particles.shape[0]
+        _check(self.lib.ra_transform_accumulate(self.handle, self._ptr(particles, self.torch.float32), n, int(index0),
+                                                self._ptr(result, self.torch.int32),
+                                                self._ptr(aligned, self.torch.float32),
+                                                self._ptr(sums, self.torch.float32),
+                                                self._ptr(counts, self.torch.int32)), "ra_transform_accumulate")
+
+    def update_references(self, sums, counts, refs, min_count=4):
+        _check(self.lib.ra_update_references(self.handle, self._ptr(sums, self.torch.float32),
+                                             self._ptr(counts, self.torch.int32), int(min_count),
+                                             self._ptr(refs, self.torch.float32)), "ra_update_references")
+
+    def normalize_particles(self, particles):
+        _check(self.lib.ra_normalize_particles(self.handle, self._ptr(particles, self.torch.float32),
+                                               particles.shape[0]), "ra_normalize_particles")
+
+    def sync(self):
+        _check(self.lib.ra_sync(self.handle), "ra_sync")
+
+    def kernel_time(self, enable=True):
+        """returns (ms_ccf, launches_ccf, ms_polar, launches_polar) since the last call and
+        (re)arms HIP-event timing of the two hot kernels on the engine's stream."""
+        a = ctypes.c_double(); b = ctypes.c_double(); na = ctypes.c_int(); nb = ctypes.c_int()
+        _check(self.lib.ra_kernel_time(self.handle, int(enable), ctypes.byref(a), ctypes.byref(na), ctypes.byref(b),
+                                       ctypes.byref(nb)), "ra_kernel_time")
+        return a.value, na.value, b.value, nb.value

@@ -1,0 +1,692 @@
+// libralign_hip.so -- host side of the MI355X 2-D alignment engine and its C ABI
+// (include/ralign.h).  Owns geometry tables, workspaces and the kernel schedule; exposes
+// the handle-based ra_* API (device pointers in, asynchronous on one HIP stream) and the
+// reference's ctypes surface (cuda/gpu_aln_noref.h:52-113) on top of it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ralign_geom.h"
+#include "ralign_kernels.h"
+
+using namespace ralign;
+
+static thread_local std::string g_last_error;
+
+#define RA_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t err__ = (call);                                                            \
+        if (err__ != hipSuccess) {                                                            \
+            char buf__[512];                                                                  \
+            snprintf(buf__, sizeof(buf__), "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), \
+                     __FILE__, __LINE__);                                                     \
+            g_last_error = buf__;                                                             \
+            return RA_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct ra_engine {
+    ra_config cfg{};
+    Geometry geo;
+    DevGeom dg{};
+    hipStream_t stream = nullptr;
+    int chunk = 0;
+    int shift_cap = 0, pad_cap = 0;     // search offsets the tables / workspace were sized for
+    int nrtile = 1, refs_per_tile = 1;
+    std::vector<void *> owned;          // device allocations freed at destroy
+    float *d_A = nullptr;               // [chunk * ngroup + 2][a_blk]
+    Cand *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
+    float *d_refspec = nullptr;         // [nref][lring]
+    float *d_B = nullptr;               // [nrtile][LBP][16]
+    float *d_cs = nullptr;              // [2]
+    int *d_ring_off = nullptr, *d_numr = nullptr;
+    float *d_wr = nullptr;
+    size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
+    bool refs_ready = false;
+    // kernel timing
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ccf, ev_polar;
+    size_t ev_used_ccf = 0, ev_used_polar = 0;
+};
+
+template <typename T> static int upload(ra_engine *e, const std::vector<T> &h, const T **dptr)
+{
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    RA_HIP(hipMalloc(&d, bytes));
+    e->owned.push_back(d);
+    if (!h.empty()) RA_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = (const T *)d;
+    return RA_OK;
+}
+
+static bool fft_plan(int h, int &R1, int &R2)
+{
+    switch (h) {
+    case 4: R1 = 4; R2 = 1; return true;
+    case 8: R1 = 8; R2 = 1; return true;
+    case 16: R1 = 16; R2 = 1; return true;
+    case 32: R1 = 8; R2 = 4; return true;
+    case 64: R1 = 8; R2 = 8; return true;
+    case 128: R1 = 16; R2 = 8; return true;
+    case 256: R1 = 16; R2 = 16; return true;
+    default: return false;
+    }
+}
+
+static int build_device_geometry(ra_engine *e)
+{
+    Geometry &g = e->geo;
+    DevGeom &d = e->dg;
+    d.nx = g.nx; d.cnx = g.nx / 2 + 1;
+    d.nring = g.nring; d.maxrin = g.maxrin; d.lcirc = g.lcirc; d.lring = g.lring; d.nbins = g.nbins;
+    d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
+    d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
+    d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
+    d.nn_weight = g.nn_weight; d.mode = e->cfg.mode;
+    int sbuf = (g.lring + 31) / 32 * 32 + 8;    // == 8 (mod 32): the 4 offsets of an entry hit disjoint banks
+    d.sbuf = sbuf;
+    d.a_blk = (g.LB + 4) * 8;
+
+    // FFT work lists
+    std::vector<int4> A, B, C;
+    struct RingPlan { int i, R1, R2; };
+    std::vector<RingPlan> plans;
+    for (int i = 0; i < g.nring; i++) {
+        int n = g.numr[3 * i + 2], R1, R2;
+        if (!fft_plan(n / 2, R1, R2)) { g_last_error = "unsupported ring length"; return RA_ERR_ARG; }
+        plans.push_back({i, R1, R2});
+        for (int b = 0; b < R2; b++) A.push_back(make_int4(g.ring_off[i], R1, R2, b));
+        int h = n / 2;
+        for (int k = 0; k <= h / 2; k++)
+            C.push_back(make_int4(g.ring_off[i] + 2 * k, g.ring_off[i] + 2 * (h - k), k * (g.maxrin / n), k == 0));
+    }
+    std::stable_sort(A.begin(), A.end(), [](const int4 &a, const int4 &b) { return a.y > b.y; });
+    std::stable_sort(plans.begin(), plans.end(), [](const RingPlan &a, const RingPlan &b) { return a.R1 > b.R1; });
+    for (auto &p : plans)
+        if (p.R2 > 1)
+            for (int c = 0; c < p.R1; c++) B.push_back(make_int4(g.ring_off[p.i], p.R1, p.R2, c));
+    while (B.size() % 16) B.push_back(make_int4(0, 0, 0, 0));
+    d.n_itemA = (int)A.size(); d.n_itemB = (int)B.size(); d.n_itemC = (int)C.size();
+
+    std::vector<float2> tw(g.maxrin);
+    for (int k = 0; k < g.maxrin; k++) {
+        double a = -2.0 * M_PI * k / g.maxrin;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    std::vector<float> mask((size_t)g.nx * g.nx);
+    {
+        float radius = (float)g.last_ring;
+        for (int j = 0; j < g.nx; j++)
+            for (int i = 0; i < g.nx; i++) {
+                float x2 = ((float)i - g.nx / 2) * ((float)i - g.nx / 2) / (radius * radius);
+                float y2 = ((float)j - g.nx / 2) * ((float)j - g.nx / 2) / (radius * radius);
+                mask[(size_t)j * g.nx + i] = (x2 + y2 <= 1.0f) ? 1.0f : 0.0f;
+            }
+    }
+    int rc;
+    if ((rc = upload(e, g.samp_dx, &d.samp_dx))) return rc;
+    if ((rc = upload(e, g.samp_dy, &d.samp_dy))) return rc;
+    if ((rc = upload(e, g.samp_w, &d.samp_w))) return rc;
+    if ((rc = upload(e, g.samp_dst, &d.samp_dst))) return rc;
+    if ((rc = upload(e, g.bin_off, &d.bin_off))) return rc;
+    if ((rc = upload(e, g.bin_offp, &d.bin_offp))) return rc;
+    if ((rc = upload(e, g.ent_src, &d.ent_src))) return rc;
+    if ((rc = upload(e, g.ent_wgt, &d.ent_wgt))) return rc;
+    // shift tables are sized for the create-time window; ra_reset_shifts rewrites them
+    std::vector<float> sx(g.shift_x), sy(g.shift_y);
+    if ((rc = upload(e, sx, &d.shift_x))) return rc;
+    if ((rc = upload(e, sy, &d.shift_y))) return rc;
+    if ((rc = upload(e, tw, &d.tw))) return rc;
+    if ((rc = upload(e, A, &d.itemA))) return rc;
+    if ((rc = upload(e, B, &d.itemB))) return rc;
+    if ((rc = upload(e, C, &d.itemC))) return rc;
+    if ((rc = upload(e, mask, &d.mask))) return rc;
+    const int *tmp_i; const float *tmp_f;
+    if ((rc = upload(e, g.ring_off, &tmp_i))) return rc; e->d_ring_off = (int *)tmp_i;
+    if ((rc = upload(e, g.numr, &tmp_i))) return rc; e->d_numr = (int *)tmp_i;
+    if ((rc = upload(e, g.wr, &tmp_f))) return rc; e->d_wr = (float *)tmp_f;
+    return RA_OK;
+}
+
+template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bool zero)
+{
+    void *d = nullptr;
+    RA_HIP(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)));
+    e->owned.push_back(d);
+    if (zero) RA_HIP(hipMemset(d, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    *p = (T *)d;
+    return RA_OK;
+}
+
+extern "C" const char *ra_last_error(void) { return g_last_error.c_str(); }
+
+typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, int, Cand *);
+static ccf_fn select_ccf(int maxrin)
+{
+    switch (maxrin) {
+    case 256: return ccf_kernel<256>;
+    case 128: return ccf_kernel<128>;
+    case 64: return ccf_kernel<64>;
+    case 32: return ccf_kernel<32>;
+    default: return nullptr;
+    }
+}
+
+extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
+{
+    if (!out || !cfg) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->nx < 8 || cfg->nref < 1 || cfg->nref > 65535) { g_last_error = "bad nx/nref"; return RA_ERR_ARG; }
+    // "Shift or radius is too large - particle crosses image boundary" (test_mref_gpu_align.py:314)
+    if (cfg->last_ring + std::max(cfg->xrng, cfg->yrng) > (float)((cfg->nx - 1) / 2)) {
+        g_last_error = "shift or radius too large: particle crosses image boundary";
+        return RA_ERR_ARG;
+    }
+    if (cfg->mode != RA_MODE_MREF && cfg->mode != RA_MODE_REFFREE) { g_last_error = "bad mode"; return RA_ERR_ARG; }
+    int ndev = 0;
+    RA_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) { g_last_error = "no such HIP device"; return RA_ERR_HIP; }
+    RA_HIP(hipSetDevice(cfg->device));
+
+    ra_engine *e = new ra_engine();
+    e->cfg = *cfg;
+    if (!build_rings(e->geo, cfg->nx, cfg->first_ring, cfg->last_ring, cfg->ring_skip > 0 ? cfg->ring_skip : 1) ||
+        !build_shifts(e->geo, cfg->xrng, cfg->yrng, cfg->step)) {
+        g_last_error = "bad ring / shift geometry";
+        delete e;
+        return RA_ERR_ARG;
+    }
+    if (!select_ccf(e->geo.maxrin)) {
+        g_last_error = "maxrin not supported by the CCF kernel (32..256)";
+        delete e;
+        return RA_ERR_ARG;
+    }
+    int rc = build_device_geometry(e);
+    if (rc) { ra_destroy(e); return rc; }
+
+    e->shift_cap = e->geo.nshift; e->pad_cap = e->geo.nshift_pad;
+    e->nrtile = (cfg->nref + 7) / 8;
+    e->refs_per_tile = (cfg->nref + e->nrtile - 1) / e->nrtile;
+    const Geometry &g = e->geo;
+    const int npix_pad = (g.nx * g.nx + 3) & ~3;
+    e->lds_polar = (size_t)(npix_pad + 4 * e->dg.sbuf + 64) * sizeof(float);
+    e->lds_ref = (size_t)(npix_pad + e->dg.sbuf + 8) * sizeof(float);
+    e->lds_ccf = (size_t)64 * (2 * g.maxrin + 32) * sizeof(float);
+    e->lds_xf = (size_t)npix_pad * sizeof(float);
+    const size_t lds_max = 160 * 1024;
+    if (e->lds_polar > lds_max || e->lds_ccf > lds_max) {
+        g_last_error = "image / ring geometry does not fit the 160 KB LDS of one CU";
+        ra_destroy(e);
+        return RA_ERR_ARG;
+    }
+    hipError_t he;
+    he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
+    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
+
+    // workspace: bin-major spectra of `chunk` particles + candidate records
+    int chunk = cfg->chunk > 0 ? cfg->chunk : 8192;
+    chunk = (chunk + 1) & ~1;
+    e->chunk = chunk;
+    const int ngroup = g.nshift_pad / 4;
+    if ((rc = dev_alloc(e, &e->d_A, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
+        (rc = dev_alloc(e, &e->d_cand, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)) ||
+        (rc = dev_alloc(e, &e->d_refspec, (size_t)cfg->nref * g.lring, true)) ||
+        (rc = dev_alloc(e, &e->d_B, (size_t)e->nrtile * g.LBP * 16, true)) ||
+        (rc = dev_alloc(e, &e->d_cs, 2, true))) {
+        ra_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return RA_OK;
+}
+
+extern "C" void ra_destroy(ra_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->owned) (void)hipFree(p);
+    for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete e;
+}
+
+extern "C" int ra_set_stream(ra_engine *e, void *hip_stream)
+{
+    if (!e) return RA_ERR_ARG;
+    e->stream = (hipStream_t)hip_stream;
+    return RA_OK;
+}
+
+extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
+extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
+extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }
+
+extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
+{
+    if (!e) return RA_ERR_ARG;
+    Geometry g2 = e->geo;
+    if (!build_shifts(g2, xrng, yrng, step)) { g_last_error = "bad shift window"; return RA_ERR_ARG; }
+    // the reference asserts the offset count does not change (gpu_aln_noref.cu:135); we only
+    // require that it does not exceed what ra_create sized
+    if (g2.nshift_pad > e->pad_cap || g2.nshift > e->shift_cap) {
+        g_last_error = "reset_shifts: more search offsets than the engine was created with";
+        return RA_ERR_ARG;
+    }
+    if ((float)e->cfg.last_ring + std::max(xrng, yrng) > (float)((e->cfg.nx - 1) / 2)) {
+        g_last_error = "shift or radius too large: particle crosses image boundary";
+        return RA_ERR_ARG;
+    }
+    RA_HIP(hipStreamSynchronize(e->stream));
+    RA_HIP(hipMemcpy((void *)e->dg.shift_x, g2.shift_x.data(), g2.nshift * sizeof(float), hipMemcpyHostToDevice));
+    RA_HIP(hipMemcpy((void *)e->dg.shift_y, g2.shift_y.data(), g2.nshift * sizeof(float), hipMemcpyHostToDevice));
+    e->geo.nkx = g2.nkx; e->geo.nky = g2.nky; e->geo.nshift = g2.nshift; e->geo.step = g2.step;
+    e->geo.shift_x = g2.shift_x; e->geo.shift_y = g2.shift_y;
+    e->geo.nshift_pad = g2.nshift_pad;
+    e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
+    e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad;
+    e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
+    return RA_OK;
+}
+
+extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
+{
+    if (!e || !d_refs) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    const Geometry &g = e->geo;
+    hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(e->cfg.nref), dim3(256), e->lds_ref, e->stream, e->dg, d_refs,
+                       e->cfg.nref, e->d_refspec);
+    RA_HIP(hipGetLastError());
+    int total = e->nrtile * g.LBP * 16;
+    hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
+                       e->cfg.nref, e->refs_per_tile, e->nrtile, e->d_B);
+    RA_HIP(hipGetLastError());
+    e->refs_ready = true;
+    return RA_OK;
+}
+
+extern "C" int ra_get_prepared_references(ra_engine *e, float *h_crefim)
+{
+    if (!e || !h_crefim) return RA_ERR_ARG;
+    if (!e->refs_ready) { g_last_error = "ra_set_references has not been called"; return RA_ERR_STATE; }
+    float *d_out = nullptr;
+    size_t cnt = (size_t)e->cfg.nref * e->geo.lcirc;
+    RA_HIP(hipMalloc((void **)&d_out, cnt * sizeof(float)));
+    hipLaunchKernelGGL(unpack_refs_kernel, dim3(e->cfg.nref), dim3(256), 0, e->stream, e->dg, e->d_refspec,
+                       e->cfg.nref, e->d_ring_off, e->d_numr, e->d_wr, d_out);
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(h_crefim, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    RA_HIP(he);
+    return RA_OK;
+}
+
+static std::pair<hipEvent_t, hipEvent_t> *next_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used)
+{
+    if (used == pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        pool.push_back({a, b});
+    }
+    return &pool[used++];
+}
+
+// average-centre correction of ali2d_single_iter: d += R(-alpha) M cs using the previous
+// parameters (combine_params2(alpha,sx,sy,mirror, 0,-cs0,-cs1,0) then inverse_transform2)
+__global__ void apply_cs_kernel(int n, const float *__restrict__ cs, const ra_result *__restrict__ res,
+                                float *__restrict__ state)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double a = (double)res[p].alpha * M_PI / 180.0, c = cos(a), s = sin(a);
+    double u = res[p].mirror ? -(double)cs[0] : (double)cs[0], v = (double)cs[1];
+    state[2 * p] = (float)((double)state[2 * p] + c * u - s * v);
+    state[2 * p + 1] = (float)((double)state[2 * p + 1] + s * u + c * v);
+}
+
+extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_state, ra_result *d_result,
+                        const float *cs)
+{
+    if (!e || !d_particles || !d_state || !d_result || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e->refs_ready) { g_last_error = "ra_set_references has not been called"; return RA_ERR_STATE; }
+    const Geometry &g = e->geo;
+    const int npix = g.nx * g.nx;
+    const int ngroup = g.nshift_pad / 4;
+    ccf_fn ccf = select_ccf(g.maxrin);
+    if (cs && (cs[0] != 0.f || cs[1] != 0.f)) {
+        RA_HIP(hipMemcpyAsync(e->d_cs, cs, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(apply_cs_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_cs, d_result, d_state);
+        RA_HIP(hipGetLastError());
+    }
+    for (int start = 0; start < n; start += e->chunk) {
+        const int cn = std::min(e->chunk, n - start);
+        const float *part = d_particles + (size_t)start * npix;
+        float *st = d_state + (size_t)start * 2;
+        std::pair<hipEvent_t, hipEvent_t> *evp = nullptr, *evc = nullptr;
+        if (e->timing) {
+            evp = next_events(e->ev_polar, e->ev_used_polar);
+            evc = next_events(e->ev_ccf, e->ev_used_ccf);
+        }
+        if (evp) RA_HIP(hipEventRecord(evp->first, e->stream));
+        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(256), e->lds_polar, e->stream, e->dg, part, st, cn, e->d_A);
+        RA_HIP(hipGetLastError());
+        if (evp) RA_HIP(hipEventRecord(evp->second, e->stream));
+        const int n_mtile = (cn * g.nshift_pad + 7) / 8;
+        const int nblk = ((n_mtile + 7) / 8) * 8 * e->nrtile;
+        if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
+        hipLaunchKernelGGL(ccf, dim3(nblk), dim3(256), e->lds_ccf, e->stream, e->dg, e->d_A, e->d_B, n_mtile, e->nrtile,
+                           e->refs_per_tile, e->cfg.nref, e->d_cand);
+        RA_HIP(hipGetLastError());
+        if (evc) RA_HIP(hipEventRecord(evc->second, e->stream));
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, e->d_cand, e->nrtile,
+                           cn, st, d_result + start, e->d_cs);
+        RA_HIP(hipGetLastError());
+    }
+    (void)ngroup;
+    return RA_OK;
+}
+
+extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, int n, int index0,
+                                       const ra_result *d_result, float *d_aligned, float *d_sums, int *d_counts)
+{
+    if (!e || !d_particles || !d_result || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, e->geo.nx, d_particles, n, index0,
+                       d_result, d_aligned, d_sums, d_counts);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_update_references(ra_engine *e, const float *d_sums, const int *d_counts, int min_count,
+                                    float *d_refs)
+{
+    if (!e || !d_sums || !d_counts || !d_refs) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    hipLaunchKernelGGL(update_refs_kernel, dim3(e->cfg.nref), dim3(256), 0, e->stream, e->geo.nx, d_sums, d_counts,
+                       min_count, e->dg.mask, d_refs);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_normalize_particles(ra_engine *e, float *d_particles, int n)
+{
+    if (!e || !d_particles || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    hipLaunchKernelGGL(normalize_particles_kernel, dim3(n), dim3(256), 0, e->stream, e->geo.nx, e->dg.mask,
+                       d_particles, n);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_sync(ra_engine *e)
+{
+    if (!e) return RA_ERR_ARG;
+    RA_HIP(hipStreamSynchronize(e->stream));
+    return RA_OK;
+}
+
+extern "C" int ra_kernel_time(ra_engine *e, int enable, double *ms_ccf, int *launches_ccf, double *ms_polar,
+                              int *launches_polar)
+{
+    if (!e) return RA_ERR_ARG;
+    RA_HIP(hipStreamSynchronize(e->stream));
+    double a = 0, b = 0;
+    for (size_t i = 0; i < e->ev_used_ccf; i++) {
+        float ms = 0;
+        RA_HIP(hipEventElapsedTime(&ms, e->ev_ccf[i].first, e->ev_ccf[i].second));
+        a += ms;
+    }
+    for (size_t i = 0; i < e->ev_used_polar; i++) {
+        float ms = 0;
+        RA_HIP(hipEventElapsedTime(&ms, e->ev_polar[i].first, e->ev_polar[i].second));
+        b += ms;
+    }
+    if (ms_ccf) *ms_ccf = a;
+    if (launches_ccf) *launches_ccf = (int)e->ev_used_ccf;
+    if (ms_polar) *ms_polar = b;
+    if (launches_polar) *launches_polar = (int)e->ev_used_polar;
+    e->ev_used_ccf = e->ev_used_polar = 0;
+    e->timing = enable != 0;
+    return RA_OK;
+}
+
+// ============================================================================================
+// reference-compatible surface (cuda/gpu_aln_noref.h:52-113): one process-global engine,
+// synchronous calls, print + abort on failure like the reference (gpu_aln_common.cu:89-103).
+
+namespace {
+struct Legacy {
+    ra_engine *eng = nullptr;
+    AlignConfig cfg{};
+    unsigned num_particles = 0;
+    int device = -1;
+    AlignParam *h_param = nullptr;       // pinned, caller reads / writes in place
+    float *d_sbj = nullptr, *d_ref = nullptr, *d_aligned = nullptr, *d_state = nullptr, *d_sums = nullptr;
+    int *d_counts = nullptr;
+    ra_result *d_res = nullptr, *h_res = nullptr;
+    float *h_stage = nullptr, *h_state = nullptr, *h_sums = nullptr;
+    int *h_counts = nullptr;
+    size_t stage_imgs = 0;
+    unsigned sbj_loaded = 0;
+} L;
+
+void die(const char *what)
+{
+    fprintf(stderr, "libralign_hip: %s: %s\n", what, ra_last_error());
+    exit(EXIT_FAILURE);
+}
+void hip_or_die(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) { fprintf(stderr, "libralign_hip: %s: %s\n", what, hipGetErrorString(e)); exit(EXIT_FAILURE); }
+}
+
+ra_config legacy_config(const AlignConfig *c, unsigned device, int mode)
+{
+    ra_config rc{};
+    rc.nx = (int)c->img_dim; rc.first_ring = 1; rc.last_ring = (int)c->ring_num; rc.ring_skip = 1;
+    rc.xrng = c->shift_rng_x; rc.yrng = c->shift_rng_y; rc.step = c->shift_step;
+    rc.nref = (int)c->ref_num; rc.mode = mode; rc.device = (int)device; rc.chunk = 0;
+    return rc;
+}
+
+size_t legacy_bytes(unsigned num_particles, const AlignConfig *c)
+{
+    Geometry g;
+    if (!build_rings(g, (int)c->img_dim, 1, (int)c->ring_num, 1) || !build_shifts(g, c->shift_rng_x, c->shift_rng_y, c->shift_step))
+        return (size_t)-1;
+    size_t npix = (size_t)c->img_dim * c->img_dim;
+    size_t chunk = std::min<size_t>(8192, (c->sbj_num + 1) & ~1u);
+    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * (size_t)(g.LB + 4) * 8 * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * 16;
+    size_t imgs = ((size_t)c->sbj_num * 2 + c->ref_num * 3) * npix * 4;
+    return ws + imgs + (size_t)num_particles * 64;
+}
+
+void run_search(int start, int stop, int mode)
+{
+    if (!L.eng) { fprintf(stderr, "libralign_hip: *_run before pre_align_init\n"); exit(EXIT_FAILURE); }
+    const int n = stop - start;
+    if (n <= 0 || (unsigned)n > L.cfg.sbj_num || (unsigned)stop > L.num_particles) {
+        fprintf(stderr, "libralign_hip: bad index range [%d,%d)\n", start, stop);
+        exit(EXIT_FAILURE);
+    }
+    L.eng->cfg.mode = mode; L.eng->dg.mode = mode;
+    for (int i = 0; i < n; i++) { L.h_state[2 * i] = L.h_param[start + i].shift_x; L.h_state[2 * i + 1] = L.h_param[start + i].shift_y; }
+    hip_or_die(hipMemcpy(L.d_state, L.h_state, sizeof(float) * 2 * n, hipMemcpyHostToDevice), "state upload");
+    if (ra_align(L.eng, L.d_sbj, n, L.d_state, L.d_res, nullptr)) die("ra_align");
+}
+
+void fetch_results(int start, int stop)
+{
+    const int n = stop - start;
+    if (ra_sync(L.eng)) die("sync");
+    hip_or_die(hipMemcpy(L.h_res, L.d_res, sizeof(ra_result) * n, hipMemcpyDeviceToHost), "result download");
+    hip_or_die(hipMemcpy(L.h_state, L.d_state, sizeof(float) * 2 * n, hipMemcpyDeviceToHost), "state download");
+    for (int i = 0; i < n; i++) {
+        AlignParam &a = L.h_param[start + i];
+        a.ref_id = L.h_res[i].ref_id;
+        a.shift_x = L.h_state[2 * i]; a.shift_y = L.h_state[2 * i + 1];
+        a.angle = L.h_res[i].alpha;
+        a.mirror = L.h_res[i].mirror != 0;
+    }
+}
+}  // namespace
+
+extern "C" void print_gpu_info(const unsigned int device_idx)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, (int)device_idx) != hipSuccess) { printf("GPU[%u]: not available\n", device_idx); return; }
+    size_t fr = 0, tot = 0;
+    (void)hipSetDevice((int)device_idx);
+    (void)hipMemGetInfo(&fr, &tot);
+    printf("GPU[%u]: %s (%s), %d CUs, %.1f GiB total, %.1f GiB free, LDS/CU %zu KB, wave %d\n", device_idx, p.name,
+           p.gcnArchName, p.multiProcessorCount, tot / 1073741824.0, fr / 1073741824.0,
+           (size_t)p.maxSharedMemoryPerMultiProcessor / 1024, p.warpSize);
+}
+
+extern "C" void gpu_clear(void)
+{
+    if (L.eng) { ra_destroy(L.eng); L.eng = nullptr; }
+    if (L.h_param) (void)hipHostFree(L.h_param);
+    if (L.h_stage) (void)hipHostFree(L.h_stage);
+    if (L.h_state) (void)hipHostFree(L.h_state);
+    if (L.h_sums) (void)hipHostFree(L.h_sums);
+    if (L.h_counts) (void)hipHostFree(L.h_counts);
+    if (L.h_res) (void)hipHostFree(L.h_res);
+    for (void *p : {(void *)L.d_sbj, (void *)L.d_ref, (void *)L.d_aligned, (void *)L.d_state, (void *)L.d_sums,
+                    (void *)L.d_counts, (void *)L.d_res})
+        if (p) (void)hipFree(p);
+    int dev = L.device;
+    L = Legacy();
+    L.device = dev;   // the reference pins the process to one device id (gpu_aln_noref.cu:105)
+}
+
+extern "C" AlignParam *pre_align_init(const unsigned int num_particles, const AlignConfig *aln_cfg,
+                                      const unsigned int device_id)
+{
+    if (!aln_cfg) { fprintf(stderr, "libralign_hip: pre_align_init: null config\n"); exit(EXIT_FAILURE); }
+    if (L.device != -1 && L.device != (int)device_id) {
+        fprintf(stderr, "libralign_hip: device id may not change within a process\n");
+        exit(EXIT_FAILURE);
+    }
+    if (L.eng) gpu_clear();
+    L.device = (int)device_id;
+    L.cfg = *aln_cfg;
+    L.num_particles = num_particles;
+    ra_config rc = legacy_config(aln_cfg, device_id, RA_MODE_MREF);
+    rc.chunk = (int)std::min<unsigned>(8192, aln_cfg->sbj_num);
+    if (ra_create(&L.eng, &rc)) die("pre_align_init");
+    const size_t npix = (size_t)aln_cfg->img_dim * aln_cfg->img_dim;
+    const size_t B = aln_cfg->sbj_num, R = aln_cfg->ref_num;
+    hip_or_die(hipHostMalloc((void **)&L.h_param, sizeof(AlignParam) * std::max(1u, num_particles)), "param alloc");
+    for (unsigned i = 0; i < num_particles; i++) {
+        L.h_param[i].sbj_id = -1; L.h_param[i].ref_id = 0; L.h_param[i].shift_x = 0; L.h_param[i].shift_y = 0;
+        L.h_param[i].angle = 0; L.h_param[i].mirror = false;
+    }
+    L.stage_imgs = std::max(B, R);
+    hip_or_die(hipHostMalloc((void **)&L.h_stage, L.stage_imgs * npix * sizeof(float)), "stage alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_state, B * 2 * sizeof(float)), "state alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_res, B * sizeof(ra_result)), "res alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_sums, R * 2 * npix * sizeof(float)), "sums alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_counts, R * sizeof(int)), "counts alloc");
+    hip_or_die(hipMalloc((void **)&L.d_sbj, B * npix * sizeof(float)), "sbj alloc");
+    hip_or_die(hipMalloc((void **)&L.d_aligned, B * npix * sizeof(float)), "aligned alloc");
+    hip_or_die(hipMalloc((void **)&L.d_ref, R * npix * sizeof(float)), "ref alloc");
+    hip_or_die(hipMalloc((void **)&L.d_state, B * 2 * sizeof(float)), "state alloc");
+    hip_or_die(hipMalloc((void **)&L.d_res, B * sizeof(ra_result)), "res alloc");
+    hip_or_die(hipMalloc((void **)&L.d_sums, R * 2 * npix * sizeof(float)), "sums alloc");
+    hip_or_die(hipMalloc((void **)&L.d_counts, R * sizeof(int)), "counts alloc");
+    hip_or_die(hipMemset(L.d_res, 0, B * sizeof(ra_result)), "res clear");
+    return L.h_param;
+}
+
+extern "C" bool pre_align_size_check(const unsigned int num_particles, const AlignConfig *cfg,
+                                     const unsigned int device_id, const float request, const bool verbose)
+{
+    if (!cfg) return false;
+    if (hipSetDevice((int)device_id) != hipSuccess) return false;
+    size_t need = legacy_bytes(num_particles, cfg);
+    size_t fr = 0, tot = 0;
+    if (need == (size_t)-1 || hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    if (verbose)
+        printf("GPU[%u] SIZE CHECK: need %zu MB of %zu MB free (request %.2f)\n", device_id, need >> 20, fr >> 20, request);
+    return (double)need <= (double)fr * request;
+}
+
+extern "C" void pre_align_fetch(const float **img_data, const unsigned int img_num, const char *batch_type)
+{
+    if (!L.eng) { fprintf(stderr, "libralign_hip: pre_align_fetch before pre_align_init\n"); exit(EXIT_FAILURE); }
+    const size_t npix = (size_t)L.cfg.img_dim * L.cfg.img_dim;
+    const bool is_sbj = batch_type && strcmp(batch_type, "sbj_batch") == 0;
+    const bool is_ref = batch_type && strcmp(batch_type, "ref_batch") == 0;
+    if (!is_sbj && !is_ref) {
+        // same message and behaviour as gpu_aln_noref.cu:373-376
+        printf("ERROR! fetch_data() :: Unknown batch type '%s' specified.\n", batch_type ? batch_type : "(null)");
+        return;
+    }
+    const unsigned cap = is_sbj ? L.cfg.sbj_num : L.cfg.ref_num;
+    if (img_num > cap || !img_data) { fprintf(stderr, "libralign_hip: pre_align_fetch: %u images exceed the batch (%u)\n", img_num, cap); exit(EXIT_FAILURE); }
+    // gather into one pinned block and ship with a single copy
+    for (unsigned i = 0; i < img_num; i++) memcpy(L.h_stage + (size_t)i * npix, img_data[i], npix * sizeof(float));
+    float *dst = is_sbj ? L.d_sbj : L.d_ref;
+    hip_or_die(hipMemcpy(dst, L.h_stage, (size_t)img_num * npix * sizeof(float), hipMemcpyHostToDevice), "image upload");
+    if (is_sbj) L.sbj_loaded = img_num;
+    else if (ra_set_references(L.eng, L.d_ref)) die("ra_set_references");
+}
+
+extern "C" void pre_align_run(const int start_idx, const int stop_idx)
+{
+    run_search(start_idx, stop_idx, RA_MODE_REFFREE);
+    fetch_results(start_idx, stop_idx);
+}
+
+extern "C" void *pre_align_run_m(const int start_idx, const int stop_idx)
+{
+    run_search(start_idx, stop_idx, RA_MODE_REFFREE);
+    if (ra_transform_accumulate(L.eng, L.d_sbj, stop_idx - start_idx, start_idx, L.d_res, L.d_aligned, nullptr, nullptr)) die("transform");
+    fetch_results(start_idx, stop_idx);
+    return L.d_aligned;
+}
+
+extern "C" void *mref_align_run(const int start_idx, const int stop_idx)
+{
+    run_search(start_idx, stop_idx, RA_MODE_MREF);
+    if (ra_transform_accumulate(L.eng, L.d_sbj, stop_idx - start_idx, start_idx, L.d_res, L.d_aligned, nullptr, nullptr)) die("transform");
+    fetch_results(start_idx, stop_idx);
+    return L.d_aligned;
+}
+
+extern "C" float *mref_align_run_m(const int start_idx, const int stop_idx)
+{
+    const size_t npix = (size_t)L.cfg.img_dim * L.cfg.img_dim, R = L.cfg.ref_num;
+    run_search(start_idx, stop_idx, RA_MODE_MREF);
+    hip_or_die(hipMemsetAsync(L.d_sums, 0, R * 2 * npix * sizeof(float), L.eng->stream), "sums clear");
+    hip_or_die(hipMemsetAsync(L.d_counts, 0, R * sizeof(int), L.eng->stream), "counts clear");
+    if (ra_transform_accumulate(L.eng, L.d_sbj, stop_idx - start_idx, start_idx, L.d_res, L.d_aligned, L.d_sums, L.d_counts)) die("transform");
+    fetch_results(start_idx, stop_idx);
+    // reference layout: all even averages, then all odd ones (test_mref_cheng_yu_bdb_cuda.py:550-551)
+    std::vector<float> tmp(R * 2 * npix);
+    hip_or_die(hipMemcpy(tmp.data(), L.d_sums, tmp.size() * sizeof(float), hipMemcpyDeviceToHost), "sums download");
+    for (size_t r = 0; r < R; r++) {
+        memcpy(L.h_sums + r * npix, tmp.data() + (r * 2) * npix, npix * sizeof(float));
+        memcpy(L.h_sums + (R + r) * npix, tmp.data() + (r * 2 + 1) * npix, npix * sizeof(float));
+    }
+    hip_or_die(hipMemcpy(L.h_counts, L.d_counts, R * sizeof(int), hipMemcpyDeviceToHost), "counts download");
+    return L.h_sums;
+}
+
+extern "C" int *get_num_ref(void) { return L.h_counts; }
+
+extern "C" void reset_shifts(const float shift_range, const float shift_step)
+{
+    if (!L.eng) { fprintf(stderr, "libralign_hip: reset_shifts before pre_align_init\n"); exit(EXIT_FAILURE); }
+    if (ra_reset_shifts(L.eng, shift_range, shift_range, shift_step)) die("reset_shifts");
+}

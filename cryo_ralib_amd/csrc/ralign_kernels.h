@@ -1,0 +1,694 @@
+// Device kernels of the 2-D alignment hot path, written for gfx950 (MI355X, 64-wide waves).
+//
+//   polar_fft_kernel   Polar2Dm (bilinear) + Normalize_ring + Frngs for 4 search offsets of one
+//                      particle at a time; image and ring buffers in LDS; spectra written
+//                      bin-major so the contraction streams them in full 128-B lines.
+//   ccf_kernel         reference x particle cross-correlation (Crosrng_ms) as a dense f32 MFMA
+//                      contraction over rings, per Fourier bin; the CCF spectra of an
+//                      8 (particle-offset) x 8 (reference) tile stay in LDS, are inverse-FFTed
+//                      there (q and t together as one complex transform) and reduced by a
+//                      wavefront argmax; only the peak records leave the CU.
+//   finalize_kernel    per-particle reduction over offsets and references with EMAN2's
+//                      tie rules, prb1d / ang_n, parameter algebra.
+//   transform_kernel   rot_shift2D (quadratic, background) + per-class even/odd accumulation.
+//   refprep / pack / update kernels for the reference side.
+//
+// The arithmetic follows the EMAN2 CPU path; reference call sites are
+// cited at each kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ralign_fft.h"
+#include "../../include/ralign.h"
+
+namespace ralign {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DevGeom {
+    int nx, cnx;                  // cnx = nx/2+1 (1-based SPIDER centre)
+    int nring, maxrin, lcirc, lring, nbins, LB, LBP;
+    int last_ring;
+    int nshift, nshift_pad, nkx, nky;
+    float step, xrng, yrng;
+    float nn_weight;
+    int mode;                     // RA_MODE_*
+    int sbuf;                     // LDS stride of one ring buffer (floats)
+    int a_blk;                    // floats per A block of 4 particle-offsets: (LB+4)*8
+    int n_itemA, n_itemB, n_itemC;
+    const float *samp_dx, *samp_dy, *samp_w;
+    const int *samp_dst;
+    const int *bin_off, *bin_offp;
+    const int *ent_src;
+    const float *ent_wgt;
+    const float *shift_x, *shift_y;
+    const float2 *tw;             // e^{-2 pi i k / maxrin}, k < maxrin
+    const int4 *itemA, *itemB, *itemC;
+    const float *mask;            // model_circle(last_ring) [nx*nx]
+};
+
+// ------------------------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Util::bilinear on a 0-based image pointer with 1-based coordinates (no FMA contraction so
+// that samples match the CPU restatement bit for bit)
+__device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xold, float yold)
+{
+#pragma clang fp contract(off)
+    int ix = (int)xold, iy = (int)yold;
+    float ydif = yold - iy, xdif = xold - ix;
+    // out-of-window offsets (masked later) may leave the image: clamp the taps
+    ix = min(max(ix, 1), nx - 1);
+    iy = min(max(iy, 1), nx - 1);
+    const float *p = img + (iy - 1) * nx + (ix - 1);
+    float f00 = p[0], f10 = p[1], f01 = p[nx], f11 = p[nx + 1];
+    return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+}
+
+// search window of one particle: the reset/clamp rule and search_range
+// (test_mref_gpu_align.py:1030-1038; ali2d_single_iter for RA_MODE_REFFREE)
+struct Window { float sxi, syi; int lkx, rkx, lky, rky; };
+__device__ __forceinline__ Window particle_window(const DevGeom &g, float dx, float dy)
+{
+    Window w;
+    const float mashi = (float)(g.cnx - g.last_ring - 2);
+    if (g.mode == RA_MODE_MREF) {
+        if (fabsf(dx) > mashi || fabsf(dy) > mashi) { dx = 0.f; dy = 0.f; }
+    } else {
+        dx = fminf(fmaxf(dx, -mashi), mashi);
+        dy = fminf(fmaxf(dy, -mashi), mashi);
+    }
+    w.sxi = dx; w.syi = dy;
+    const int cn = g.nx / 2 + 1;
+    float qlx = fmaxf(cn + dx - g.last_ring - 2, 0.f), qex = fmaxf(g.nx - cn - dx - g.last_ring, 0.f);
+    float qly = fmaxf(cn + dy - g.last_ring - 2, 0.f), qey = fmaxf(g.nx - cn - dy - g.last_ring, 0.f);
+    w.lkx = (int)(fminf(qlx, g.xrng) / g.step); w.rkx = (int)(fminf(qex, g.xrng) / g.step);
+    w.lky = (int)(fminf(qly, g.yrng) / g.step); w.rky = (int)(fminf(qey, g.yrng) / g.step);
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// ring FFT passes on LDS ring buffers.  A ring of n reals is the n/2-point complex sequence
+// z_m = x_2m + i x_2m+1 already in place; h = n/2 = R1*R2.
+//   pass A: R2 items/ring, DFT-R1 over stride R2, twiddle, in place
+//   pass B: R1 items/ring, DFT-R2 over contiguous R2, output stride R1 (lock-step in one wave)
+//   pass C: split step X_k <- (Z_k, Z_{h-k}), in place, writes X_0 and X_h (padding slot)
+
+template <int R>
+__device__ __forceinline__ void passA_item(float *buf, const int4 it, const float2 *__restrict__ tw,
+                                           int maxrin, float avg, float rsg)
+{
+    const int off = it.x, R2 = it.z, b = it.w;
+    float2 v[R];
+#pragma unroll
+    for (int a = 0; a < R; a++) {
+        float2 z = *reinterpret_cast<const float2 *>(buf + off + 2 * (R2 * a + b));
+        v[a] = make_float2((z.x - avg) * rsg, (z.y - avg) * rsg);
+    }
+    Dft<-1, R>::run(v);
+    const int tstep = maxrin / (R * R2) * b;   // W_h^{b c} = W_maxrin^{b c maxrin/h}
+#pragma unroll
+    for (int c = 0; c < R; c++) {
+        float2 o = v[c];
+        if (R2 > 1 && c > 0) o = cmul(o, tw[(tstep * c) & (maxrin - 1)]);
+        *reinterpret_cast<float2 *>(buf + off + 2 * (R2 * c + b)) = o;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void passB_item(float *buf, const int4 it)
+{
+    const int off = it.x, R1 = it.y, c = it.w;
+    float2 v[R];
+#pragma unroll
+    for (int b = 0; b < R; b++) v[b] = *reinterpret_cast<const float2 *>(buf + off + 2 * (R * c + b));
+    Dft<-1, R>::run(v);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int e = 0; e < R; e++) *reinterpret_cast<float2 *>(buf + off + 2 * (c + R1 * e)) = v[e];
+}
+
+// item: x = float offset of Z_k, y = float offset of Z_{h-k}, z = twiddle index k*maxrin/n, w = (k==0)
+__device__ __forceinline__ void passC_item(float *buf, const int4 it, const float2 *__restrict__ tw)
+{
+    float2 zk = *reinterpret_cast<const float2 *>(buf + it.x);
+    if (it.w) {   // k = 0: X_0 = Zr + Zi, X_h = Zr - Zi, both real
+        *reinterpret_cast<float2 *>(buf + it.x) = make_float2(zk.x + zk.y, 0.f);
+        *reinterpret_cast<float2 *>(buf + it.y) = make_float2(zk.x - zk.y, 0.f);
+        return;
+    }
+    float2 zm = *reinterpret_cast<const float2 *>(buf + it.y);
+    // E = (Z_k + conj Z_m)/2 ; O = (Z_k - conj Z_m)/(2i) ; X_k = E + W^k O ; X_m = conj(E - W^k O)
+    float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+    float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+    float2 w = tw[it.z];
+    float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+    *reinterpret_cast<float2 *>(buf + it.x) = make_float2(er + tr, ei + ti);
+    if (it.x != it.y) *reinterpret_cast<float2 *>(buf + it.y) = make_float2(er - tr, -(ei - ti));
+}
+
+// run the three passes over `nbuf` ring buffers (stride sbuf) with the whole workgroup
+__device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int nbuf,
+                                             const float *avg, const float *rsg)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int idx = tid; idx < g.n_itemA * nbuf; idx += nt) {
+        int s = idx / g.n_itemA, i = idx - s * g.n_itemA;
+        int4 it = g.itemA[i];
+        float *b = bufs + s * g.sbuf;
+        float av = avg[s], rs = rsg[s];
+        switch (it.y) {
+        case 16: passA_item<16>(b, it, g.tw, g.maxrin, av, rs); break;
+        case 8:  passA_item<8>(b, it, g.tw, g.maxrin, av, rs); break;
+        case 4:  passA_item<4>(b, it, g.tw, g.maxrin, av, rs); break;
+        default: passA_item<2>(b, it, g.tw, g.maxrin, av, rs); break;
+        }
+    }
+    __syncthreads();
+    // pass B: items of one ring are consecutive and radix-aligned, so they sit in one wave;
+    // the trip count is made wave-uniform so the in-wave load/store ordering holds
+    const int nB = g.n_itemB * nbuf;
+    for (int base = 0; base < nB; base += nt) {
+        int idx = base + tid;
+        if (idx < nB) {
+            int s = idx / g.n_itemB, i = idx - s * g.n_itemB;
+            int4 it = g.itemB[i];
+            float *b = bufs + s * g.sbuf;
+            switch (it.z) {
+            case 16: passB_item<16>(b, it); break;
+            case 8:  passB_item<8>(b, it); break;
+            case 4:  passB_item<4>(b, it); break;
+            case 2:  passB_item<2>(b, it); break;
+            default: break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < g.n_itemC * nbuf; idx += nt) {
+        int s = idx / g.n_itemC, i = idx - s * g.n_itemC;
+        passC_item(bufs + s * g.sbuf, g.itemC[i], g.tw);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: polar resampling + Normalize_ring + ring FFT of every search offset of one particle.
+// Restates Polar2Dm / Normalize_ring / Frngs as called inside Util.multiref_polar_ali_2d
+// (reference call site test_mref_gpu_align.py:1043-1044; ormq for RA_MODE_REFFREE).
+//   particles [n][nx*nx], state [n][2] (accumulated centre offset), A blocks out.
+// One workgroup per particle; 4 offsets per pass.  LDS: image + 4 ring buffers.
+__global__ __launch_bounds__(256) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
+                                                        const float *__restrict__ state, int n,
+                                                        float *__restrict__ A)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int npix = g.nx * g.nx;
+    float *img = lds;
+    float *bufs = lds + ((npix + 3) & ~3);
+    float *red = bufs + 4 * g.sbuf;      // [4 waves][8] partials, then [8] avg/rsg
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p >= n) return;
+
+    const float *src = particles + (size_t)p * npix;
+    for (int i = tid; i < npix; i += blockDim.x) img[i] = src[i];
+    // the padding slots of every ring buffer must read as finite numbers
+    for (int i = tid; i < 4 * g.sbuf; i += blockDim.x) bufs[i] = 0.f;
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
+    __syncthreads();
+
+    const int ngroup = g.nshift_pad / 4;
+    for (int grp = 0; grp < ngroup; grp++) {
+        float cx[4], cy[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            int si = min(grp * 4 + s, g.nshift - 1);
+            cx[s] = cxf + g.shift_x[si];
+            cy[s] = cyf + g.shift_y[si];
+        }
+        float av[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < g.lcirc; i += blockDim.x) {
+            const float dx = g.samp_dx[i], dy = g.samp_dy[i], wt = g.samp_w[i];
+            const int dst = g.samp_dst[i];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                float v = bilinear_1b(img, g.nx, dx + cx[s], dy + cy[s]);
+                bufs[s * g.sbuf + dst] = v;
+                av[s] += v * wt;
+                sq[s] += v * v * wt;
+            }
+        }
+        if (g.mode == RA_MODE_MREF) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                float a = wave_sum(av[s]), q = wave_sum(sq[s]);
+                if (lane == 0) { red[wave * 8 + s] = a; red[wave * 8 + 4 + s] = q; }
+            }
+            __syncthreads();
+            if (tid < 4) {
+                float a = 0.f, q = 0.f;
+                for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) { a += red[wv * 8 + tid]; q += red[wv * 8 + 4 + tid]; }
+                const float nn = g.nn_weight;
+                float avg = a / nn;
+                float sgm = sqrtf((q - a * a / nn) / nn);
+                red[32 + tid] = avg;
+                red[36 + tid] = 1.0f / sgm;
+            }
+            __syncthreads();
+        } else {
+            if (tid < 4) { red[32 + tid] = 0.f; red[36 + tid] = 1.f; }
+            __syncthreads();
+        }
+        ring_fft_all(g, bufs, 4, red + 32, red + 36);
+
+        // bin-major write-out: entry e = (bin k, ring i), 4 offsets x (re, im) per entry
+        float *dstA = A + ((size_t)p * ngroup + grp) * g.a_blk;
+        for (int f = tid; f < g.LB * 4; f += blockDim.x) {
+            int e = f >> 2, m4 = f & 3;
+            float2 v = *reinterpret_cast<const float2 *>(bufs + m4 * g.sbuf + g.ent_src[e]);
+            *reinterpret_cast<float2 *>(dstA + 2 * f) = v;
+        }
+        __syncthreads();
+    }
+}
+
+// K0a: references -> Polar2Dm(cnx,cny) + Frngs, natural (padded ring buffer) layout in HBM.
+// (test_mref_gpu_align.py:1015-1016)
+__global__ __launch_bounds__(256) void ref_polar_fft_kernel(DevGeom g, const float *__restrict__ refs,
+                                                            int nref, float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int npix = g.nx * g.nx;
+    float *img = lds;
+    float *bufs = lds + ((npix + 3) & ~3);
+    float *red = bufs + g.sbuf;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= nref) return;
+    for (int i = tid; i < npix; i += blockDim.x) img[i] = refs[(size_t)r * npix + i];
+    for (int i = tid; i < g.sbuf; i += blockDim.x) bufs[i] = 0.f;
+    if (tid == 0) { red[0] = 0.f; red[1] = 1.f; }
+    __syncthreads();
+    const float c = (float)g.cnx;
+    for (int i = tid; i < g.lcirc; i += blockDim.x)
+        bufs[g.samp_dst[i]] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
+    __syncthreads();
+    ring_fft_all(g, bufs, 1, red, red + 1);
+    for (int i = tid; i < g.lring; i += blockDim.x) out[(size_t)r * g.lring + i] = bufs[i];
+}
+
+// K0b: Applyws + 1/maxrin, packed bin-major as the MFMA B operand:
+//   B[rtile][entryP][16 cols], col = 2*(ref in tile) + (0: Re, 1: Im); padded entries zero.
+// (Applyws: test_mref_gpu_align.py:1017)
+__global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, int nref, int refs_per_tile,
+                                 int nrtile, float *__restrict__ B)
+{
+    const int total = nrtile * g.LBP * 16;
+    const float inv = 1.0f / (float)g.maxrin;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int col = idx & 15, ep = (idx >> 4) % g.LBP, rt = idx / (16 * g.LBP);
+        // locate the bin of padded entry ep
+        int lo = 0, hi = g.nbins - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (g.bin_offp[mid] <= ep) lo = mid; else hi = mid - 1; }
+        int k = lo, j = ep - g.bin_offp[k], cnt = g.bin_off[k + 1] - g.bin_off[k];
+        int rr = col >> 1, ref = rt * refs_per_tile + rr;
+        float v = 0.f;
+        if (j < cnt && rr < refs_per_tile && ref < nref) {
+            int e = g.bin_off[k] + j;
+            v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
+        }
+        B[idx] = v;
+    }
+}
+
+// diagnostic: prepared references in EMAN2 packing (after Applyws, without the 1/maxrin)
+__global__ void unpack_refs_kernel(DevGeom g, const float *__restrict__ refspec, int nref,
+                                   const int *__restrict__ ring_off, const int *__restrict__ numr,
+                                   const float *__restrict__ wr, float *__restrict__ out)
+{
+    int r = blockIdx.x;
+    for (int i = 0; i < g.nring; i++) {
+        int n = numr[3 * i + 2], o = numr[3 * i + 1] - 1, ro = ring_off[i];
+        const float *s = refspec + (size_t)r * g.lring + ro;
+        float *d = out + (size_t)r * g.lcirc + o;
+        float w = wr[i];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            float v;
+            if (j == 0) v = s[0] * w;
+            else if (j == 1) v = s[n] * ((n == g.maxrin) ? w : 0.5f * w);
+            else v = s[j] * w;
+            d[j] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: CCF contraction on MFMA + in-LDS inverse FFT + wavefront argmax.
+// Restates Util::Crosrng_ms for every (particle-offset, reference) pair of an 8 x 8 tile:
+//   per Fourier bin k:  [16 rows = 8 m x (Re,Im) D] x [rings] x [16 cols = 8 refs x (Re,Im) C]
+//   a=c1d1 b=c1d2 c=c2d1 d=c2d2 ;  Q_k = (a+d) + i(c-b) ;  T_k = (a-d) - i(b+c)
+//   Z_k = Q_k + i T_k,  Z_{N-k} = conj(Q_k) + i conj(T_k)  -> one N-point complex inverse
+//   FFT yields q (real part) and t (imaginary part) of Crosrng_ms together.
+struct Cand { float val; float tot; int jtot; int refmir; };   // refmir = ref | mirror << 16
+
+template <int N> struct IfftPlan;
+template <> struct IfftPlan<256> { static constexpr int R1 = 16, R2 = 16; };
+template <> struct IfftPlan<128> { static constexpr int R1 = 16, R2 = 8; };
+template <> struct IfftPlan<64>  { static constexpr int R1 = 8,  R2 = 8; };
+template <> struct IfftPlan<32>  { static constexpr int R1 = 8,  R2 = 4; };
+
+template <int N> __device__ __forceinline__ int zaddr(int pair, int slot)
+{
+    // pair stride 2N+32 dwords; low nibble of the slot rotated by the pair index so that the
+    // 16 lanes of a ds_write_b64 group (16 pairs, same bin) fall on distinct banks
+    int s = (slot & ~15) | ((slot + pair) & 15);
+    return pair * (2 * N + 32) + 2 * s;
+}
+
+template <int N>
+__global__ __launch_bounds__(256, 1) void ccf_kernel(DevGeom g, const float *__restrict__ A,
+                                                     const float *__restrict__ B, int n_mtile, int nrtile,
+                                                     int refs_per_tile, int nref, Cand *__restrict__ cand)
+{
+    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
+    extern __shared__ __align__(16) float Z[];
+    __shared__ Cand pc[64];
+    // same-m-tile blocks differ by 8 in blockIdx so they tend to share an XCD (L2 reuse of A)
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * nrtile), rem = bid - grp * 8 * nrtile;
+    const int rtile = rem >> 3, mtile = grp * 8 + (rem & 7);
+    if (mtile >= n_mtile) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- phase 1: contraction, one bin per wave at a time
+    {
+        const int row = lane & 15, kk = lane >> 4;
+        const float *Arow = A + (size_t)(2 * mtile + (row >> 3)) * g.a_blk + (row & 7) + kk * 8;
+        const float *Bcol = B + (size_t)rtile * g.LBP * 16 + (lane & 15) + kk * 16;
+        const int odd = lane & 1;
+        const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);
+        for (int k = wave; k < g.nbins; k += 4) {
+            const int e0 = g.bin_off[k], cnt = g.bin_off[k + 1] - e0, p0 = g.bin_offp[k];
+            const int nstep = (cnt + 3) >> 2;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *ap = Arow + (size_t)e0 * 8;
+            const float *bp = Bcol + (size_t)p0 * 16;
+            for (int s = 0; s < nstep; s++) {
+                float a = ap[s * 32];
+                float b = bp[s * 64];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+            // 2x2 block exchange between the Re/Im column lanes of one reference
+            float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
+            float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+            float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
+            float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
+            float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+            *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, k)) = make_float2(apd + bpc, cmb + amd);
+            *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: N-point inverse FFT of every pair, 16 lanes per transform, then argmax
+    const int nvalid = min(refs_per_tile, nref - rtile * refs_per_tile);
+    {
+        const int j = lane & 15, sub = lane >> 4;
+        for (int round = 0; round < 4; round++) {
+            const int pair = wave * 16 + round * 4 + sub;
+            const bool live = (pair & 7) < nvalid;
+            float2 v[16];
+            if (live && j < R2) {
+#pragma unroll
+                for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, R2 * k1 + j));
+                Dft<1, R1>::run(v);
+#pragma unroll
+                for (int n0 = 0; n0 < R1; n0++) {
+                    float2 o = v[n0];
+                    if (n0 > 0) {
+                        float2 t = g.tw[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
+                        o = cmul(o, make_float2(t.x, -t.y));   // e^{+2 pi i n0 j / N}
+                    }
+                    v[n0] = o;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (live && j < R2) {
+#pragma unroll
+                for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, n0 * R2 + j)) = v[n0];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float bq = -1.0e20f, bt = -1.0e20f;
+            int iq = 0, it = 0;
+            if (live && j < R1) {
+#pragma unroll
+                for (int k0 = 0; k0 < R2; k0++) v[k0] = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, j * R2 + k0));
+                Dft<1, R2>::run(v);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (live && j < R1) {
+#pragma unroll
+                for (int n1 = 0; n1 < R2; n1++) {
+                    const int idx = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
+                    *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, idx)) = v[n1];
+                    if (v[n1].x >= bq) { bq = v[n1].x; iq = idx; }
+                    if (v[n1].y >= bt) { bt = v[n1].y; it = idx; }
+                }
+            }
+            // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=)
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                float oq = __shfl_xor(bq, o); int oiq = __shfl_xor(iq, o);
+                float ot = __shfl_xor(bt, o); int oit = __shfl_xor(it, o);
+                if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
+                if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (live && j == 0) {
+                // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
+                const bool mir = !(bq >= bt);
+                const int jt = mir ? it : iq;
+                double t7[7];
+#pragma unroll
+                for (int k = -3; k <= 3; k++) {
+                    float2 zz = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, (jt + k + N) & (N - 1)));
+                    t7[k + 3] = mir ? (double)zz.y : (double)zz.x;
+                }
+                // Util::prb1d, npoint 7
+                double c2 = 49. * t7[0] + 6. * t7[1] - 21. * t7[2] - 32. * t7[3] - 27. * t7[4] - 6. * t7[5] + 31. * t7[6];
+                double c3 = 5. * t7[0] - 3. * t7[2] - 4. * t7[3] - 3. * t7[4] + 5. * t7[6];
+                float pos = 0.f;
+                if (c3 != 0.0) pos = (float)(c2 / (2.0 * c3) - 4);
+                Cand c;
+                c.val = mir ? bt : bq;
+                c.jtot = jt + 1;
+                c.tot = (float)(jt + 1) + pos;
+                c.refmir = (rtile * refs_per_tile + (pair & 7)) | ((mir ? 1 : 0) << 16);
+                pc[pair] = c;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins)
+    if (tid < 8) {
+        Cand best; best.val = -1.0e23f; best.tot = 0.f; best.jtot = 0; best.refmir = 0;
+        for (int rr = 0; rr < nvalid; rr++) {
+            Cand c = pc[tid * 8 + rr];
+            if (c.val >= best.val) best = c;
+        }
+        cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: per-particle reduction over search offsets (y outer, x inner) and reference tiles with
+// the ">=" rule of Util::multiref_polar_ali_2d, ang_n, the ormq tail and combine_params2
+// (test_mref_gpu_align.py:1043-1049).
+__global__ void finalize_kernel(DevGeom g, const Cand *__restrict__ cand, int nrtile, int n,
+                                float *__restrict__ state, ra_result *__restrict__ res,
+                                const float *__restrict__ cs)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    float peak = -1.0e23f;
+    Cand best; best.val = peak; best.tot = 1.f; best.jtot = 1; best.refmir = 0;
+    int bs = 0;
+    const int nx1 = 2 * g.nkx + 1;
+    for (int s = 0; s < g.nshift; s++) {
+        const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
+        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
+        for (int rt = 0; rt < nrtile; rt++) {
+            Cand c = cand[((size_t)p * g.nshift_pad + s) * nrtile + rt];
+            if (c.val >= peak) { peak = c.val; best = c; bs = s; }
+        }
+    }
+    const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
+    // Util::ang_n, mode F
+    const float ang = fmodf(((best.tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
+    const float ixw = g.shift_x[bs], iyw = g.shift_y[bs];
+    const float sx = -ixw, sy = -iyw;
+    const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
+    const float sxs = sx * co - sy * so, sys = sx * so + sy * co;
+    // combine_params2(0,-sxi,-syi,0, ang,sxs,sys,mirror) in double: rotate the pre-shift, add
+    const double a = (double)ang * M_PI / 180.0, c = cos(a), s = sin(a);
+    const double tx = c * (double)(-w.sxi) + s * (double)(-w.syi) + (double)sxs;
+    const double ty = -s * (double)(-w.sxi) + c * (double)(-w.syi) + (double)sys;
+    double alpha = atan2(s, c) * 180.0 / M_PI;
+    alpha = fmod(alpha, 360.0);
+    if (alpha < 0) alpha += 360.0;
+    if (alpha >= 360.0) alpha -= 360.0;
+    ra_result r;
+    r.alpha = (float)alpha; r.sx = (float)tx; r.sy = (float)ty;
+    r.mirror = mirror; r.ref_id = ref; r.peak = peak; r.angle_bin = best.jtot; r.shift_idx = bs;
+    res[p] = r;
+    state[2 * p] = w.sxi + ixw;
+    state[2 * p + 1] = w.syi + iyw;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: rot_shift2D(img, alpha, sx, sy, mirror) ("quadratic", "background") and per-class
+// even/odd accumulation (test_mref_gpu_align.py:1055-1057; kernel_sum_oe :48-80).
+// The arithmetic follows the reference tree's own restatement of
+// rot_scale_trans2D_background / quadri_background (notebook/02 cell 2).
+__device__ __forceinline__ float quadri_background_1b(const float *fdata, int nx, int ny, float xx, float yy,
+                                                      int xnew, int ynew)
+{
+#pragma clang fp contract(off)
+    float x = xx, y = yy;
+    if ((x < 1.0f) || (x >= (float)(nx + 1)) || (y < 1.0f) || (y >= (float)(ny + 1))) { x = (float)xnew; y = (float)ynew; }
+    int i = (int)x, j = (int)y;
+    float dx0 = x - i, dy0 = y - j;
+    int ip1 = i + 1, im1 = i - 1, jp1 = j + 1, jm1 = j - 1;
+    if (ip1 > nx) ip1 -= nx;
+    if (im1 < 1) im1 += nx;
+    if (jp1 > ny) jp1 -= ny;
+    if (jm1 < 1) jm1 += ny;
+#define RA_FD(i_, j_) fdata[((j_) - 1) * nx + ((i_) - 1)]
+    float f0 = RA_FD(i, j);
+    float c1 = RA_FD(ip1, j) - f0;
+    float c2 = (c1 - f0 + RA_FD(im1, j)) * 0.5f;
+    float c3 = RA_FD(i, jp1) - f0;
+    float c4 = (c3 - f0 + RA_FD(i, jm1)) * 0.5f;
+    float dxb = dx0 - 1, dyb = dy0 - 1;
+    int hxc = (dx0 >= 0) ? 1 : -1, hyc = (dy0 >= 0) ? 1 : -1;
+    int ic = i + hxc, jc = j + hyc;
+    if (ic > nx) ic -= nx; else if (ic < 1) ic += nx;
+    if (jc > ny) jc -= ny; else if (jc < 1) jc += ny;
+    float c5 = ((RA_FD(ic, jc) - f0 - hxc * c1 - (hxc * (hxc - 1.0f)) * c2 - hyc * c3 - (hyc * (hyc - 1.0f)) * c4) * (hxc * hyc));
+#undef RA_FD
+    return f0 + dx0 * (c1 + dxb * c2 + dy0 * c5) + dy0 * (c3 + dyb * c4);
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__restrict__ particles, int n,
+                                                        int index0, const ra_result *__restrict__ res,
+                                                        float *__restrict__ aligned, float *__restrict__ sums,
+                                                        int *__restrict__ counts)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) float img[];
+    const int p = blockIdx.x, tid = threadIdx.x, npix = nx * nx;
+    if (p >= n) return;
+    const float *src = particles + (size_t)p * npix;
+    for (int i = tid; i < npix; i += blockDim.x) img[i] = src[i];
+    const ra_result r = res[p];
+    __syncthreads();
+    const float ang = r.alpha * (float)M_PI / 180.0f;
+    float delx = r.sx, dely = r.sy;
+    while (delx >= (float)nx) delx -= nx;
+    while (delx <= -(float)nx) delx += nx;
+    while (dely >= (float)nx) dely -= nx;
+    while (dely <= -(float)nx) dely += nx;
+    const int xc = nx / 2, yc = nx / 2;
+    const float shiftxc = xc + delx, shiftyc = yc + dely;
+    const float cang = (float)cos((double)ang), sang = (float)sin((double)ang);
+    float *dsum = sums ? sums + ((size_t)r.ref_id * 2 + ((index0 + p) & 1)) * npix : nullptr;
+    float *dal = aligned ? aligned + (size_t)p * npix : nullptr;
+    const int mstart = 1 - nx % 2;
+    for (int i = tid; i < npix; i += blockDim.x) {
+        const int iy = i / nx, ix = i - iy * nx;
+        float y = (float)iy - shiftyc;
+        float ycang = y * cang + yc;
+        float ysang = -y * sang + xc;
+        float x = (float)ix - shiftxc;
+        float xold = x * cang + ysang;
+        float yold = x * sang + ycang;
+        float v = quadri_background_1b(img, nx, nx, xold + 1.0f, yold + 1.0f, ix + 1, iy + 1);
+        // xform.mirror(x): columns [1 - nx%2, nx) reversed
+        int ox = ix;
+        if (r.mirror && ix >= mstart) ox = mstart + (nx - 1) - ix;
+        const int o = iy * nx + ox;
+        if (dal) dal[o] = v;
+        if (dsum) atomicAdd(dsum + o, v);
+    }
+    if (counts && tid == 0) atomicAdd(counts + r.ref_id, 1);
+}
+
+// K5: new references from the class sums: (even + odd) * (1/count), then
+// normalize.mask(no_sigma=1) (test_mref_gpu_align.py:534-535, 563)
+__global__ __launch_bounds__(256) void update_refs_kernel(int nx, const float *__restrict__ sums,
+                                                          const int *__restrict__ counts, int min_count,
+                                                          const float *__restrict__ mask, float *__restrict__ refs)
+{
+    __shared__ double sh[2][4];
+    __shared__ int shn[4];
+    const int r = blockIdx.x, tid = threadIdx.x, npix = nx * nx;
+    const int cnt = counts[r];
+    if (cnt < min_count) return;
+    const float sc = (float)(1.0 / (double)(float)cnt);
+    const float *ev = sums + (size_t)r * 2 * npix, *od = ev + npix;
+    float *dst = refs + (size_t)r * npix;
+    double s = 0, q = 0; int nm = 0;
+    for (int i = tid; i < npix; i += blockDim.x) {
+        float v = (ev[i] + od[i]) * sc;
+        dst[i] = v;
+        if (mask[i] > 0.5f) { s += v; q += v * (double)v; nm++; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); nm += __shfl_xor(nm, o); }
+    if ((tid & 63) == 0) { sh[0][tid >> 6] = s; sh[1][tid >> 6] = q; shn[tid >> 6] = nm; }
+    __syncthreads();
+    s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    nm = shn[0] + shn[1] + shn[2] + shn[3];
+    const float mean = (float)s / nm;
+    const float sigma = sqrtf((float)((q - s * s / nm) / (nm - 1)));
+    for (int i = tid; i < npix; i += blockDim.x) dst[i] = (dst[i] - mean) / sigma;
+}
+
+// particle preprocessing: subtract the mean under the mask (normalize.mask no_sigma=0,
+// test_mref_gpu_align.py:342)
+__global__ __launch_bounds__(256) void normalize_particles_kernel(int nx, const float *__restrict__ mask,
+                                                                  float *__restrict__ particles, int n)
+{
+    __shared__ double sh[4];
+    __shared__ int shn[4];
+    const int p = blockIdx.x, tid = threadIdx.x, npix = nx * nx;
+    if (p >= n) return;
+    float *img = particles + (size_t)p * npix;
+    double s = 0; int nm = 0;
+    for (int i = tid; i < npix; i += blockDim.x)
+        if (mask[i] > 0.5f) { s += img[i]; nm++; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); nm += __shfl_xor(nm, o); }
+    if ((tid & 63) == 0) { sh[tid >> 6] = s; shn[tid >> 6] = nm; }
+    __syncthreads();
+    s = sh[0] + sh[1] + sh[2] + sh[3];
+    nm = shn[0] + shn[1] + shn[2] + shn[3];
+    const float mean = nm ? (float)s / nm : 0.f;
+    for (int i = tid; i < npix; i += blockDim.x) img[i] = (img[i] - mean) / 1.0f;
+}
+
+}  // namespace ralign

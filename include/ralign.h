@@ -1,0 +1,172 @@
+/*
+ * ralign.h -- C ABI of the MI355X-native 2-D alignment engine (libralign_hip.so).
+ *
+ * Two layers, both plain C (pointers and sizes only):
+ *
+ *  (1) the reference's own ctypes surface, symbol for symbol
+ *      (/root/reference/cuda/gpu_aln_noref.h:52-113, cuda/gpu_aln_common.h:62-83,
+ *       ctypes mirrors at test_mref_gpu_align.py:91-149), so that the reference drivers can
+ *      load this library in place of cuda/gpu_aln_pack.so;
+ *  (2) a handle-based `ra_*` API with int error codes that takes DEVICE pointers
+ *      (inputs already resident in HBM) and an optional HIP stream; this is what the
+ *      Python host side (cryo_ralib_amd/) and bench.py call.
+ *
+ * Results follow the EMAN2 CPU path (Util.multiref_polar_ali_2d / ormq semantics),
+ * the API shape follows the reference's CUDA library.  See DESIGN.md.
+ */
+#ifndef RALIGN_H
+#define RALIGN_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ PODs */
+
+/* reference: cuda/gpu_aln_common.h:62-74 ; ctypes test_mref_gpu_align.py:112-123 (32 bytes) */
+typedef struct AlignConfig {
+    unsigned int sbj_num;    /* particles per device batch                       */
+    unsigned int ref_num;    /* references                                       */
+    unsigned int img_dim;    /* nx (square images)                               */
+    unsigned int ring_num;   /* numr[-3]: outer radius `ou` (rings 1..ring_num)  */
+    unsigned int ring_len;   /* reference passes 256; informational here: ring lengths follow Numrinit */
+    float shift_step;
+    float shift_rng_x;
+    float shift_rng_y;
+} AlignConfig;
+
+/* reference: cuda/gpu_aln_common.h:76-83 ; ctypes test_mref_gpu_align.py:125-134 (24 bytes).
+ * shift_x/shift_y hold the accumulated centre offset (== inverse_transform2 of xform.align2d);
+ * it is both input and output of every *_run call.  The caller converts to EMAN2 parameters
+ * exactly as test_mref_gpu_align.py:578-588 does. */
+typedef struct AlignParam {
+    int   sbj_id;
+    int   ref_id;
+    float shift_x;
+    float shift_y;
+    float angle;
+    bool  mirror;
+} AlignParam;
+
+/* ------------------------------------------- (1) reference-compatible names */
+
+/* cuda/gpu_aln_noref.h:52 */
+void print_gpu_info(const unsigned int device_idx);
+/* cuda/gpu_aln_noref.h:58 */
+void gpu_clear(void);
+/* cuda/gpu_aln_noref.h:62-65.  Returns host-visible (pinned) memory of num_particles entries. */
+AlignParam *pre_align_init(const unsigned int num_particles, const AlignConfig *aln_cfg,
+                           const unsigned int device_id);
+/* cuda/gpu_aln_noref.h:67-72 */
+bool pre_align_size_check(const unsigned int num_particles, const AlignConfig *cfg,
+                          const unsigned int device_id, const float request, const bool verbose);
+/* cuda/gpu_aln_noref.h:74-77 ; batch_type "sbj_batch" | "ref_batch" */
+void pre_align_fetch(const float **img_data, const unsigned int img_num, const char *batch_type);
+/* cuda/gpu_aln_noref.h:81 : single-reference search, parameters only */
+void pre_align_run(const int start_idx, const int stop_idx);
+/* cuda/gpu_aln_noref.h:82 : single-reference search + transform; returns DEVICE pointer to the
+ * aligned images [stop-start][nx][nx] (borrowed until the next run/fetch) */
+void *pre_align_run_m(const int start_idx, const int stop_idx);
+/* cuda/gpu_aln_noref.h:83 : multi-reference search + transform; same return */
+void *mref_align_run(const int start_idx, const int stop_idx);
+/* cuda/gpu_aln_noref.h:84 : multi-reference search + transform + per-class even/odd sums;
+ * returns HOST-readable float[2][R][nx][nx] (even block, then odd block;
+ * test_mref_cheng_yu_bdb_cuda.py:550-551) */
+float *mref_align_run_m(const int start_idx, const int stop_idx);
+/* cuda/gpu_aln_noref.h:113 : per-class member counts of the last mref_align_run_m */
+int *get_num_ref(void);
+/* cuda/gpu_aln_noref.cu:119 (exported, not in the header) */
+void reset_shifts(const float shift_range, const float shift_step);
+
+/* ------------------------------------------------------ (2) handle-based API */
+
+#define RA_OK            0
+#define RA_ERR_ARG      -1   /* invalid argument / geometry                   */
+#define RA_ERR_HIP      -2   /* HIP runtime failure (message via ra_last_error) */
+#define RA_ERR_STATE    -3   /* call out of protocol order                    */
+#define RA_ERR_NOMEM    -4
+
+#define RA_MODE_MREF     0   /* Util.multiref_polar_ali_2d: Normalize_ring, out-of-range shifts reset */
+#define RA_MODE_REFFREE  1   /* sp_alignment.ormq: no Normalize_ring, shifts clamped                 */
+
+typedef struct ra_config {
+    int   nx;             /* image size (square)                                   */
+    int   first_ring;     /* --ir                                                  */
+    int   last_ring;      /* --ou                                                  */
+    int   ring_skip;      /* --rs                                                  */
+    float xrng, yrng;     /* --xr --yr                                             */
+    float step;           /* --ts                                                  */
+    int   nref;           /* references (1 in RA_MODE_REFFREE)                     */
+    int   mode;           /* RA_MODE_*                                             */
+    int   device;         /* HIP ordinal                                           */
+    int   chunk;          /* particles per internal pass (0 = auto)                */
+} ra_config;
+
+typedef struct ra_engine ra_engine;
+
+/* per-particle result record written by ra_align (device or host memory, 32 bytes) */
+typedef struct ra_result {
+    float alpha, sx, sy;  /* EMAN2 xform.align2d parameters (combine_params2 output) */
+    int   mirror;
+    int   ref_id;
+    float peak;           /* CCF peak (qn or qm)                                   */
+    int   angle_bin;      /* jtot: 1-based integer angular bin of the peak         */
+    int   shift_idx;      /* index of the winning search offset (y outer, x inner) */
+} ra_result;
+
+const char *ra_last_error(void);
+int  ra_create(ra_engine **out, const ra_config *cfg);
+void ra_destroy(ra_engine *e);
+/* use `hip_stream` (a hipStream_t) for all subsequent work; NULL = default stream */
+int  ra_set_stream(ra_engine *e, void *hip_stream);
+/* geometry queries */
+int  ra_num_shifts(const ra_engine *e);
+int  ra_maxrin(const ra_engine *e);
+int  ra_lcirc(const ra_engine *e);
+/* change the search window without re-allocating (reset_shifts analogue); the number of
+ * offsets may not grow beyond what ra_create sized */
+int  ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step);
+
+/* references: d_refs [nref][nx][nx] device, ALREADY normalised under the mask
+ * (test_mref_gpu_align.py:336).  Polar transform, ring FFT and ring weights
+ * (Polar2Dm/Frngs/Applyws, :1015-1017) happen on the device. */
+int  ra_set_references(ra_engine *e, const float *d_refs);
+/* diagnostic: copy the prepared references in EMAN2 packing [nref][lcirc] to host */
+int  ra_get_prepared_references(ra_engine *e, float *h_crefim);
+
+/* search: d_particles [n][nx][nx] device; d_state [n][2] device, accumulated centre offset
+ * (in/out); d_result [n] device.  cs = average-centre correction (RA_MODE_REFFREE; NULL = 0).
+ * Asynchronous on the engine's stream. */
+int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
+              ra_result *d_result, const float *cs);
+/* apply rot_shift2D with the parameters in d_result and write the aligned images
+ * (d_aligned [n][nx][nx], may be NULL) and/or add them into the class sums
+ * (d_sums [nref][2][nx][nx] +=, d_counts [nref] +=, may be NULL);
+ * even/odd = (index0 + i) % 2 (test_mref_gpu_align.py:1056). */
+int  ra_transform_accumulate(ra_engine *e, const float *d_particles, int n, int index0,
+                             const ra_result *d_result, float *d_aligned,
+                             float *d_sums, int *d_counts);
+/* new references from the (all-reduced) class sums: (even+odd)/count then
+ * normalize.mask(no_sigma=1) under model_circle(last_ring)
+ * (test_mref_gpu_align.py:534-535, 563).  Classes with count < min_count are left
+ * untouched in d_refs (the caller re-seeds them, :523-528). */
+int  ra_update_references(ra_engine *e, const float *d_sums, const int *d_counts,
+                          int min_count, float *d_refs);
+/* particle preprocessing on device: subtract the mean under model_circle(last_ring)
+ * (normalize.mask no_sigma=0, test_mref_gpu_align.py:342), in place */
+int  ra_normalize_particles(ra_engine *e, float *d_particles, int n);
+/* block until the engine's stream is idle */
+int  ra_sync(ra_engine *e);
+
+/* timing of the dominant kernel with HIP events on the engine's stream:
+ * accumulated milliseconds and launch count since the last reset */
+int  ra_kernel_time(ra_engine *e, int enable, double *ms_ccf, int *launches_ccf,
+                    double *ms_polar, int *launches_polar);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
