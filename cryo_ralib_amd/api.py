@@ -73,6 +73,9 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch bundles its own HIP runtime (libamdhip64.so.7); it must be the one already mapped when
+    # this library is opened, otherwise the process ends up with two runtimes and no device
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise EngineError("HIP alignment library not built: %s (run `python -m cryo_ralib_amd.build`)" % p)
     L = ctypes.CDLL(p)

@@ -1,0 +1,87 @@
+"""Particle sharding and the one collective of the path.
+
+The reference shards particles contiguously over MPI ranks with MPI_start_end
+(test_mref_gpu_align.py:289,1384) and, once per iteration, reduces the 2R class sums and
+R counts to rank 0 (reduce_EMData_to_root x 2R + mpi_reduce, :495-499) and broadcasts the
+new references back (bcast_EMData_to_all x R, :572-575).  Here that is ONE in-place
+all-reduce (RCCL over xGMI when the tensors live in HBM, gloo on CPU tensors in the tests)
+of a single flat buffer [R*2*nx*nx sums | R counts | extra]; every rank then performs the
+same deterministic reference update, which replaces the broadcast.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .geometry import mpi_start_end
+
+
+def init_from_env(backend=None):
+    """one process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(total, world, rank):
+    """contiguous particle range of `rank` (MPI_start_end rule)."""
+    return mpi_start_end(total, world, rank)
+
+
+class ClassSumBuffer:
+    """flat fp32 buffer [R][2][nx][nx] sums | [R] counts | [extra] scalars, all-reduced in place.
+
+    Counts travel as fp32 inside the same buffer (exact below 2^24 members per class per
+    rank-sum, i.e. 16.7 M particles per class) so that one collective suffices."""
+
+    def __init__(self, nref, nx, device, extra=0):
+        self.nref, self.nx, self.extra = nref, nx, extra
+        self.nsum = nref * 2 * nx * nx
+        self.flat = torch.zeros(self.nsum + nref + extra, dtype=torch.float32, device=device)
+        self.sums = self.flat[:self.nsum].view(nref, 2, nx, nx)
+        self.counts_f = self.flat[self.nsum:self.nsum + nref]
+        self.extra_f = self.flat[self.nsum + nref:]
+        self.counts_i = torch.zeros(nref, dtype=torch.int32, device=device)
+
+    def zero_(self):
+        self.flat.zero_()
+        self.counts_i.zero_()
+
+    def all_reduce(self):
+        """sum over ranks; afterwards counts_i holds the global member counts on every rank."""
+        self.counts_f.copy_(self.counts_i.to(torch.float32))
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.counts_i.copy_(self.counts_f.round().to(torch.int32))
+        return self
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

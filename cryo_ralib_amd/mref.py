@@ -1,0 +1,222 @@
+"""Host-side iteration drivers of the alignment path.
+
+`MrefAligner` / `mref_ali2d_gpu` mirror the reference's `mref_ali2d_gpu`
+(test_mref_gpu_align.py:222-612): preprocessing (:333-345), one search + transform +
+class accumulation per iteration (:408-484), the cross-rank reduction (:495-499), the
+vanished-class rule (:523-528), (even+odd)/n and re-normalisation (:534-535, 563), and the
+AlignParam -> xform.align2d conversion (:578-588).  `RefFreeAligner` / `ali2d_base_gpu`
+mirror `ali2d_base_gpu_isac_CLEAN` (test_reffree_gpu_align.py:153-577).
+
+All heavy work is in the HIP engine (api.Engine); torch supplies device memory, the stream
+and the RCCL collective.  The FSC-driven low-pass filter and centring of the reference's
+`user_func` (:555) are not on the measured hot path and not built yet;
+`user_func=None` reproduces the reference run with an identity user function.
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import api, dist, geometry
+
+
+class MrefAligner:
+    def __init__(self, particles, refs, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
+                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0):
+        """particles: [n][nx][nx] float32 numpy array or CUDA tensor holding THIS rank's shard;
+        refs: [R][nx][nx]; index0 = global index of particles[0] (even/odd split)."""
+        self.dev = torch.device("cuda", device)
+        self.particles = self._to_dev(particles)
+        self.refs = self._to_dev(refs).clone()
+        self.n, self.nx = self.particles.shape[0], self.particles.shape[-1]
+        self.nref = self.refs.shape[0]
+        self.ou, self.xr, self.yr, self.ts = int(ou), float(xr), float(yr), float(ts)
+        self.index0 = int(index0)
+        self.total_nima = int(total_nima if total_nima is not None else self.n)
+        self.myid, self.main_node = myid, main_node
+        # "Shift or radius is too large - particle crosses image boundary" (:314-315) is raised by ra_create
+        self.engine = api.Engine(self.nx, self.ou, self.xr, self.yr, self.ts, self.nref, api.RA_MODE_MREF,
+                                 first_ring=ir, ring_skip=rs, device=device, chunk=chunk)
+        self.engine.use_current_stream()
+        self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        self.state = self.engine.new_state(self.n)
+        self.result = self.engine.new_result(self.n)
+        self.buf = dist.ClassSumBuffer(self.nref, self.nx, self.dev)
+        self.iteration = 0
+        self.rng = random.Random(rand_seed)       # seed(rand_seed) on the main node (:352)
+        self.class_sizes = []
+        if preprocess:
+            self._normalize_refs_all()
+            self.engine.normalize_particles(self.particles)    # :342
+
+    def _to_dev(self, a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+        return a.to(self.dev, dtype=torch.float32).contiguous()
+
+    def _normalize_refs(self, idx=None):
+        # normalize.mask(no_sigma=1) (:336, :563): mean 0, sigma 1 under the mask
+        sel = self.mask > 0.5
+        idx = list(range(self.nref)) if idx is None else list(idx)
+        if not idx:
+            return
+        sub = self.refs[idx]
+        v = sub[:, sel].double()
+        n = v.shape[1]
+        mean = (v.sum(1) / n).float()
+        var = ((v * v).sum(1) - v.sum(1) ** 2 / n) / (n - 1)
+        sigma = var.float().sqrt()
+        self.refs[idx] = (sub - mean[:, None, None]) / sigma[:, None, None]
+
+    def _normalize_refs_all(self):
+        self._normalize_refs(None)
+
+    def search(self):
+        """pre_align_fetch("ref_batch") + mref_align_run + kernel_sum_oe of one iteration (:410-453)."""
+        self.engine.set_references(self.refs)
+        self.engine.align(self.particles, self.state, self.result)
+        self.buf.zero_()
+        self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
+                                         self.buf.counts_i)
+
+    def reduce_and_update(self, user_func=None):
+        """cross-rank sum (:495-499) then the reference update every rank repeats (:517-575)."""
+        self.buf.all_reduce()
+        counts = self.buf.counts_i.cpu().numpy()
+        self.class_sizes.append(counts.copy())
+        vanished = [j for j in range(self.nref) if counts[j] < 4]
+        self.engine.update_references(self.buf.sums, self.buf.counts_i, self.refs, 4)
+        for j in vanished:
+            # "if vanished, put a random image (only from main node!) there" (:523-528)
+            k = self.rng.randint(0, self.n - 1)
+            img = self.particles[k].clone()
+            if dist.dist.is_initialized() and dist.dist.get_world_size() > 1:
+                dist.dist.broadcast(img, src=self.main_node)
+            self.refs[j].copy_(img)
+        if user_func is not None:
+            self.refs = user_func(self.refs, self.buf, counts)
+        if user_func is not None:
+            self._normalize_refs_all()      # :563
+        elif vanished:
+            self._normalize_refs(vanished)  # the others were normalised by the update kernel
+        self.iteration += 1
+        return counts
+
+    def iterate(self, user_func=None):
+        self.search()
+        return self.reduce_and_update(user_func)
+
+    def params(self):
+        """per-particle (alpha, sx, sy, mirror, ref_id, peak) of the last search."""
+        r = api.Engine.result_to_numpy(self.result)
+        return r
+
+    def align_params(self):
+        """AlignParam view (shift_x, shift_y, angle, mirror, ref_id) as the reference's library
+        exposes it, and the EMAN2 conversion of :578-588."""
+        r = self.params()
+        st = self.state.cpu().numpy()
+        return geometry.alignparam_to_eman2(r["alpha"], st[:, 0], st[:, 1], r["mirror"]), r["ref_id"]
+
+    def close(self):
+        self.engine.close()
+
+
+def mref_ali2d_gpu(stack, refim, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, rand_seed=1000, device=0,
+                   index0=0, total_nima=None, user_func=None, chunk=0, on_iteration=None):
+    """Multi-reference alignment of this rank's shard `stack` against `refim`
+    (mirror of mref_ali2d_gpu, test_mref_gpu_align.py:222).  Returns
+    (params records, class averages [R][nx][nx] numpy, list of class-size arrays)."""
+    al = MrefAligner(stack, refim, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, rand_seed, True, chunk)
+    max_iter = int(maxit) if int(maxit) > 0 else 10
+    for it in range(max_iter):
+        counts = al.iterate(user_func)
+        if on_iteration is not None:
+            on_iteration(it, al, counts)
+    al.engine.sync()
+    out = al.params().copy(), al.refs.cpu().numpy(), al.class_sizes
+    al.close()
+    return out
+
+
+class RefFreeAligner:
+    """single-reference alignment to the running average (ali2d_base_gpu_isac_CLEAN,
+    test_reffree_gpu_align.py:153-577; CPU twin ali2d_base -> ali2d_single_iter -> ormq)."""
+
+    def __init__(self, particles, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
+                 preprocess=False, chunk=0):
+        self.dev = torch.device("cuda", device)
+        if isinstance(particles, np.ndarray):
+            particles = torch.from_numpy(np.ascontiguousarray(particles, np.float32))
+        self.particles = particles.to(self.dev, dtype=torch.float32).contiguous()
+        self.n, self.nx = self.particles.shape[0], self.particles.shape[-1]
+        self.ou = int(ou)
+        self.index0 = int(index0)
+        self.total_nima = int(total_nima if total_nima is not None else self.n)
+        self.engine = api.Engine(self.nx, self.ou, xr, yr, ts, 1, api.RA_MODE_REFFREE, first_ring=ir, ring_skip=rs,
+                                 device=device, chunk=chunk)
+        self.engine.use_current_stream()
+        self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        if preprocess:
+            self.engine.normalize_particles(self.particles)
+        self.state = self.engine.new_state(self.n)
+        self.result = self.engine.new_result(self.n)
+        self.buf = dist.ClassSumBuffer(1, self.nx, self.dev, extra=2)
+        self.tavg = torch.zeros((1, self.nx, self.nx), device=self.dev)
+        self.cs = [0.0, 0.0]
+        self.iteration = 0
+        self.criteria = []
+
+    def _sum_oe_raw(self):
+        # iteration 0: plain even/odd sums of the raw particles (sum_oe, :365)
+        self.buf.zero_()
+        par = (torch.arange(self.n, device=self.dev) + self.index0) % 2
+        self.buf.sums[0, 0] = self.particles[par == 0].sum(0)
+        self.buf.sums[0, 1] = self.particles[par == 1].sum(0)
+        self.buf.counts_i[0] = self.n
+
+    def iterate(self, center=0):
+        if self.iteration == 0:
+            self._sum_oe_raw()
+        self.buf.all_reduce()
+        # tavg = (ave1 + ave2) / total_nima (:380); criterion a1 = sum_mask tavg^2 (:396)
+        self.tavg[0] = (self.buf.sums[0, 0] + self.buf.sums[0, 1]) / float(self.total_nima)
+        a1 = float((self.tavg[0][self.mask > 0.5] ** 2).sum().item())
+        self.criteria.append(a1)
+        cs = [0.0, 0.0]
+        if center == -1 and self.iteration > 0:
+            # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410); the fshift of tavg by -cs
+            # belongs to the reference-update row f-1 and is not built yet
+            cs = [float(self.buf.extra_f[0].item()) / self.total_nima, float(self.buf.extra_f[1].item()) / self.total_nima]
+        self.cs = cs
+        self.engine.set_references(self.tavg)
+        self.engine.align(self.particles, self.state, self.result, cs if (cs[0] or cs[1]) else None)
+        self.buf.zero_()
+        self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
+                                         self.buf.counts_i)
+        r = self.result.view(torch.float32)
+        mir = self.result[:, 3]
+        sx = r[:, 1].double()
+        self.buf.extra_f[0] = torch.where(mir == 0, sx, -sx).sum().float()
+        self.buf.extra_f[1] = r[:, 2].double().sum().float()
+        self.iteration += 1
+        return a1
+
+    def params(self):
+        return api.Engine.result_to_numpy(self.result)
+
+    def close(self):
+        self.engine.close()
+
+
+def ali2d_base_gpu(stack, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, device=0, index0=0, total_nima=None,
+                   center=0, chunk=0):
+    """mirror of ali2d_base_gpu_isac_CLEAN; returns (params records, final average, criteria).
+    Rows of initial2Dparams.txt are (alpha, sx, sy, mirror) (test_reffree_gpu_align.py:561-569)."""
+    al = RefFreeAligner(stack, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, False, chunk)
+    for _ in range(int(maxit)):
+        al.iterate(center)
+    al.engine.sync()
+    out = al.params().copy(), al.tavg[0].cpu().numpy(), al.criteria
+    al.close()
+    return out
