@@ -66,11 +66,11 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
 #pragma clang fp contract(off)
     int ix = (int)xold, iy = (int)yold;
     float ydif = yold - iy, xdif = xold - ix;
-    // out-of-window offsets (masked later) may leave the image: clamp the taps
-    ix = min(max(ix, 1), nx - 1);
-    iy = min(max(iy, 1), nx - 1);
-    const float *p = img + (iy - 1) * nx + (ix - 1);
-    float f00 = p[0], f10 = p[1], f01 = p[nx], f11 = p[nx + 1];
+    // a sample may land exactly on the last column / row (zero-weight tap one past the image),
+    // and out-of-window offsets (masked later) may leave it altogether: clamp every tap
+    const int x0 = min(max(ix, 1), nx) - 1, x1 = min(x0 + 1, nx - 1);
+    const int y0 = min(max(iy, 1), nx) - 1, y1 = min(y0 + 1, nx - 1);
+    float f00 = img[y0 * nx + x0], f10 = img[y0 * nx + x1], f01 = img[y1 * nx + x0], f11 = img[y1 * nx + x1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
 

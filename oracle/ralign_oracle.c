@@ -64,12 +64,17 @@ int orc_rings_init(orc_rings *rg, int first_ring, int last_ring, int skip)
 /* --------------------------------------------------------- interpolation */
 
 /* Util::bilinear : 1-based coordinates, no bounds check, no wrap */
-static inline float bilinear_1b(float xold, float yold, int nsam, const float *xim)
+static inline float bilinear_1b(float xold, float yold, int nsam, int nrow, const float *xim)
 {
     int ixold = (int)xold, iyold = (int)yold;
     float ydif = yold - iyold, xdif = xold - ixold;
-    const float *p = xim + (size_t)(iyold - 1) * nsam + (ixold - 1);
-    float f00 = p[0], f10 = p[1], f01 = p[nsam], f11 = p[nsam + 1];
+    /* EMAN2 reads xim(ixold+1, .) / xim(., iyold+1) unchecked; search_range lets a sample land
+     * exactly on the last column / row (xdif or ydif == 0), where that tap lies one past the
+     * image and carries zero weight.  Clamp the tap instead of reading out of bounds. */
+    int x0 = ixold < 1 ? 1 : (ixold > nsam ? nsam : ixold), x1 = x0 + 1 > nsam ? nsam : x0 + 1;
+    int y0 = iyold < 1 ? 1 : (iyold > nrow ? nrow : iyold), y1 = y0 + 1 > nrow ? nrow : y0 + 1;
+    float f00 = xim[(size_t)(y0 - 1) * nsam + (x0 - 1)], f10 = xim[(size_t)(y0 - 1) * nsam + (x1 - 1)];
+    float f01 = xim[(size_t)(y1 - 1) * nsam + (x0 - 1)], f11 = xim[(size_t)(y1 - 1) * nsam + (x1 - 1)];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
 
@@ -141,7 +146,7 @@ static inline float quadri_background_1b(float xx, float yy, int nxdata, int nyd
 
 static inline float interp_1b(float x, float y, int nx, int ny, const float *im, int interp)
 {
-    return interp == ORC_INTERP_QUADRI ? quadri_1b(x, y, nx, ny, im) : bilinear_1b(x, y, nx, im);
+    return interp == ORC_INTERP_QUADRI ? quadri_1b(x, y, nx, ny, im) : bilinear_1b(x, y, nx, ny, im);
 }
 
 /* ------------------------------------------------------------- Polar2Dm */

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the N>1 host path: contiguous sharding, the single all-reduce
+of [sums | counts | extra] and the max-over-ranks timing reduction."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, total, nref, nx, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from cryo_ralib_amd import dist as rdist
+    r, _, w = rdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = rdist.shard_range(total, world, rank)
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randn((total, nx, nx), generator=g)
+    cls = torch.randint(0, nref, (total,), generator=g)
+    buf = rdist.ClassSumBuffer(nref, nx, torch.device("cpu"), extra=2)
+    buf.zero_()
+    for i in range(lo, hi):
+        buf.sums[cls[i], i % 2] += imgs[i]
+        buf.counts_i[cls[i]] += 1
+    buf.extra_f[0] = float(hi - lo)
+    buf.all_reduce()
+    t = rdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    s = rdist.sum_over_ranks(1.0, torch.device("cpu"))
+    rdist.barrier()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), sums=buf.sums.numpy(), counts=buf.counts_i.numpy(),
+             extra=buf.extra_f.numpy(), lo=lo, hi=hi, t=t, s=s)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_class_sum_allreduce_world2(tmp_path):
+    world, total, nref, nx = 2, 37, 3, 8
+    port = 29500 + (os.getpid() % 400)
+    mp.spawn(_worker, args=(world, port, total, nref, nx, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / ("r%d.npz" % r)) for r in range(world)]
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randn((total, nx, nx), generator=g)
+    cls = torch.randint(0, nref, (total,), generator=g)
+    want = torch.zeros((nref, 2, nx, nx)); cnt = np.zeros(nref, np.int32)
+    for i in range(total):
+        want[cls[i], i % 2] += imgs[i]
+        cnt[cls[i]] += 1
+    assert outs[0]["hi"] == outs[1]["lo"] and outs[0]["lo"] == 0 and outs[1]["hi"] == total
+    for o in outs:
+        np.testing.assert_allclose(o["sums"], want.numpy(), atol=1e-5)
+        np.testing.assert_array_equal(o["counts"], cnt)
+        assert o["extra"][0] == total and o["t"] == 2.0 and o["s"] == 2.0
+    np.testing.assert_array_equal(outs[0]["sums"], outs[1]["sums"])      # every rank holds identical sums
