@@ -357,7 +357,9 @@ __global__ void apply_cs_kernel(int n, const float *__restrict__ cs, const ra_re
 extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_state, ra_result *d_result,
                         const float *cs)
 {
-    if (!e || !d_particles || !d_state || !d_result || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    if (!d_particles || !d_state || !d_result) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (!e->refs_ready) { g_last_error = "ra_set_references has not been called"; return RA_ERR_STATE; }
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
@@ -399,8 +401,9 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
 extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, int n, int index0,
                                        const ra_result *d_result, float *d_aligned, float *d_sums, int *d_counts)
 {
-    if (!e || !d_particles || !d_result || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (n == 0) return RA_OK;
+    if (!d_particles || !d_result) { g_last_error = "null argument"; return RA_ERR_ARG; }
     hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, e->geo.nx, d_particles, n, index0,
                        d_result, d_aligned, d_sums, d_counts);
     RA_HIP(hipGetLastError());
@@ -419,8 +422,9 @@ extern "C" int ra_update_references(ra_engine *e, const float *d_sums, const int
 
 extern "C" int ra_normalize_particles(ra_engine *e, float *d_particles, int n)
 {
-    if (!e || !d_particles || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (n == 0) return RA_OK;
+    if (!d_particles) { g_last_error = "null argument"; return RA_ERR_ARG; }
     hipLaunchKernelGGL(normalize_particles_kernel, dim3(n), dim3(256), 0, e->stream, e->geo.nx, e->dg.mask,
                        d_particles, n);
     RA_HIP(hipGetLastError());

@@ -23,7 +23,7 @@ def rot_shift2d_np(img, ang, sx, sy, mirror):
     a = f(ang) * f(math.pi) / f(180.0)
     xc, yc = nx // 2, ny // 2
     shiftxc, shiftyc = f(xc) + f(sx), f(yc) + f(sy)
-    cang, sang = f(math.cos(a)), f(math.sin(a))
+    cang, sang = f(math.cos(float(a))), f(math.sin(float(a)))
     iy, ix = np.mgrid[0:ny, 0:nx]
     y = iy.astype(f) - shiftyc
     ycang = y * cang + f(yc)

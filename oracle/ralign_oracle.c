@@ -512,7 +512,9 @@ void orc_rot_shift2d(const float *in, float *out, int nx, int ny,
     dely = restrict2(dely, ny);
     int xc = nx / 2, yc = ny / 2;
     float shiftxc = xc + delx, shiftyc = yc + dely;
-    float cang = cosf(ang), sang = sinf(ang);
+    /* EMAN2: `float cang = cos(ang)` on a float argument; evaluated here in double and rounded,
+     * which is what the unqualified C `cos` gives and what the device code can reproduce exactly */
+    float cang = (float)cos((double)ang), sang = (float)sin((double)ang);
     for (int iy = 0; iy < ny; iy++) {
         float y = (float)iy - shiftyc;
         float ycang = y * cang + yc;
