@@ -38,7 +38,7 @@ struct ra_engine {
     hipStream_t stream = nullptr;
     int chunk = 0;
     int shift_cap = 0, pad_cap = 0;     // search offsets the tables / workspace were sized for
-    int nrtile = 1, refs_per_tile = 1;
+    int nrtile = 1;
     std::vector<void *> owned;          // device allocations freed at destroy
     float *d_A = nullptr;               // [chunk * ngroup + 2][a_blk]
     Cand *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
@@ -93,7 +93,8 @@ static int build_device_geometry(ra_engine *e)
     d.nn_weight = g.nn_weight; d.mode = e->cfg.mode;
     int sbuf = (g.lring + 31) / 32 * 32 + 8;    // == 8 (mod 32): the 4 offsets of an entry hit disjoint banks
     d.sbuf = sbuf;
-    d.a_blk = (g.LB + 4) * 8;
+    d.a_blk = g.LBP * 8 + 64;
+    build_a_src(g, sbuf);
 
     // FFT work lists
     std::vector<int4> A, B, C;
@@ -140,6 +141,11 @@ static int build_device_geometry(ra_engine *e)
     if ((rc = upload(e, g.bin_offp, &d.bin_offp))) return rc;
     if ((rc = upload(e, g.ent_src, &d.ent_src))) return rc;
     if ((rc = upload(e, g.ent_wgt, &d.ent_wgt))) return rc;
+    {
+        const int *tmp_a;
+        if ((rc = upload(e, g.a_src, &tmp_a))) return rc;
+        d.a_src4 = reinterpret_cast<const int4 *>(tmp_a);
+    }
     // shift tables are sized for the create-time window; ra_reset_shifts rewrites them
     std::vector<float> sx(g.shift_x), sy(g.shift_y);
     if ((rc = upload(e, sx, &d.shift_x))) return rc;
@@ -168,7 +174,7 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
 
 extern "C" const char *ra_last_error(void) { return g_last_error.c_str(); }
 
-typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, int, Cand *);
+typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, Cand *);
 static ccf_fn select_ccf(int maxrin)
 {
     switch (maxrin) {
@@ -204,6 +210,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         delete e;
         return RA_ERR_ARG;
     }
+    if (e->geo.nring > 4 * RA_CCF_MAXNS) {
+        g_last_error = "more than 48 rings are not supported by the CCF kernel yet";
+        delete e;
+        return RA_ERR_ARG;
+    }
     if (!select_ccf(e->geo.maxrin)) {
         g_last_error = "maxrin not supported by the CCF kernel (32..256)";
         delete e;
@@ -214,12 +225,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
 
     e->shift_cap = e->geo.nshift; e->pad_cap = e->geo.nshift_pad;
     e->nrtile = (cfg->nref + 7) / 8;
-    e->refs_per_tile = (cfg->nref + e->nrtile - 1) / e->nrtile;
     const Geometry &g = e->geo;
     const int npix_pad = (g.nx * g.nx + 3) & ~3;
-    e->lds_polar = (size_t)(npix_pad + 4 * e->dg.sbuf + 64) * sizeof(float);
+    e->lds_polar = (size_t)(npix_pad + 4 * e->dg.sbuf + 144) * sizeof(float);
     e->lds_ref = (size_t)(npix_pad + e->dg.sbuf + 8) * sizeof(float);
-    e->lds_ccf = (size_t)64 * (2 * g.maxrin + 32) * sizeof(float);
+    e->lds_ccf = (size_t)64 * (2 * (g.maxrin + g.maxrin / 16) + 2) * sizeof(float);
     e->lds_xf = (size_t)npix_pad * sizeof(float);
     const size_t lds_max = 160 * 1024;
     if (e->lds_polar > lds_max || e->lds_ccf > lds_max) {
@@ -309,7 +319,7 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     RA_HIP(hipGetLastError());
     int total = e->nrtile * g.LBP * 16;
     hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
-                       e->cfg.nref, e->refs_per_tile, e->nrtile, e->d_B);
+                       e->cfg.nref, e->nrtile, e->d_B);
     RA_HIP(hipGetLastError());
     e->refs_ready = true;
     return RA_OK;
@@ -380,14 +390,14 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             evc = next_events(e->ev_ccf, e->ev_used_ccf);
         }
         if (evp) RA_HIP(hipEventRecord(evp->first, e->stream));
-        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(256), e->lds_polar, e->stream, e->dg, part, st, cn, e->d_A);
+        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, part, st, cn, e->d_A);
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, e->stream));
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         const int nblk = ((n_mtile + 7) / 8) * 8 * e->nrtile;
         if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
-        hipLaunchKernelGGL(ccf, dim3(nblk), dim3(256), e->lds_ccf, e->stream, e->dg, e->d_A, e->d_B, n_mtile, e->nrtile,
-                           e->refs_per_tile, e->cfg.nref, e->d_cand);
+        hipLaunchKernelGGL(ccf, dim3(nblk), dim3(RA_CCF_THREADS), e->lds_ccf, e->stream, e->dg, e->d_A, e->d_B, n_mtile,
+                           e->nrtile, e->cfg.nref, e->d_cand);
         RA_HIP(hipGetLastError());
         if (evc) RA_HIP(hipEventRecord(evc->second, e->stream));
         hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, e->d_cand, e->nrtile,
@@ -509,7 +519,7 @@ size_t legacy_bytes(unsigned num_particles, const AlignConfig *c)
         return (size_t)-1;
     size_t npix = (size_t)c->img_dim * c->img_dim;
     size_t chunk = std::min<size_t>(8192, (c->sbj_num + 1) & ~1u);
-    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * (size_t)(g.LB + 4) * 8 * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * 16;
+    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * ((size_t)g.LBP * 8 + 64) * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * 16;
     size_t imgs = ((size_t)c->sbj_num * 2 + c->ref_num * 3) * npix * 4;
     return ws + imgs + (size_t)num_particles * 64;
 }

@@ -30,6 +30,10 @@ struct Geometry {
     std::vector<int> bin_offp;     // [nbins+1] prefix of padded counts   (B layout)
     std::vector<int> ent_src;      // [LB] float offset (ring_off[i] + 2k) of entry e=(k,i)
     std::vector<float> ent_wgt;    // [LB] Applyws weight of entry (wr, halved on a short ring's Nyquist)
+    // A / B operand layout of the contraction: per bin k a [row or col][KP_k] panel, KP_k = ring
+    // count padded to a multiple of 4, so that MFMA lane (row, kk) owns KP_k/4 CONTIGUOUS floats
+    std::vector<int> a_src;        // [LBP*8] per A-block float: source offset inside the 4 ring
+                                   //   buffers ((row>>1)*sbuf + ring_off + 2k + (row&1)), -1 = zero pad
     // search offsets
     int nkx = 0, nky = 0, nshift = 0, nshift_pad = 0;
     float step = 1.f;
@@ -118,6 +122,19 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
             g.ent_wgt[e] = (k == n / 2 && n != g.maxrin) ? 0.5f * g.wr[i] : g.wr[i];
         }
     return true;
+}
+
+// A-operand gather table for LDS ring-buffer stride `sbuf` (see Geometry::a_src)
+inline void build_a_src(Geometry &g, int sbuf)
+{
+    g.a_src.assign((size_t)g.LBP * 8, -1);
+    for (int k = 0; k < g.nbins; k++) {
+        const int cnt = g.bin_off[k + 1] - g.bin_off[k], kp = g.bin_offp[k + 1] - g.bin_offp[k];
+        for (int row = 0; row < 8; row++)
+            for (int j = 0; j < cnt; j++)
+                g.a_src[(size_t)g.bin_offp[k] * 8 + row * kp + j] =
+                    (row >> 1) * sbuf + g.ent_src[g.bin_off[k] + j] + (row & 1);
+    }
 }
 
 // search offsets in Util::multiref_polar_ali_2d order (y outer, x inner), full window

@@ -36,12 +36,13 @@ struct DevGeom {
     float nn_weight;
     int mode;                     // RA_MODE_*
     int sbuf;                     // LDS stride of one ring buffer (floats)
-    int a_blk;                    // floats per A block of 4 particle-offsets: (LB+4)*8
+    int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
     const float *samp_dx, *samp_dy, *samp_w;
     const int *samp_dst;
     const int *bin_off, *bin_offp;
     const int *ent_src;
+    const int4 *a_src4;           // [LBP*2] gather table of the A write-out, 4 floats per entry
     const float *ent_wgt;
     const float *shift_x, *shift_y;
     const float2 *tw;             // e^{-2 pi i k / maxrin}, k < maxrin
@@ -206,23 +207,25 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
 // Restates Polar2Dm / Normalize_ring / Frngs as called inside Util.multiref_polar_ali_2d
 // (reference call site test_mref_gpu_align.py:1043-1044; ormq for RA_MODE_REFFREE).
 //   particles [n][nx*nx], state [n][2] (accumulated centre offset), A blocks out.
-// One workgroup per particle; 4 offsets per pass.  LDS: image + 4 ring buffers.
-__global__ __launch_bounds__(256) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
-                                                        const float *__restrict__ state, int n,
-                                                        float *__restrict__ A)
+// One workgroup (16 waves) per particle; 4 offsets per pass.  LDS: image + 4 ring buffers.
+// Output: per block of 4 offsets, per bin k a panel [8 rows = 4 offsets x (Re,Im)][KP_k rings].
+#define RA_POLAR_THREADS 1024
+__global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
+                                                                     const float *__restrict__ state, int n,
+                                                                     float *__restrict__ A)
 {
     extern __shared__ __align__(16) float lds[];
     const int npix = g.nx * g.nx;
     float *img = lds;
     float *bufs = lds + ((npix + 3) & ~3);
-    float *red = bufs + 4 * g.sbuf;      // [4 waves][8] partials, then [8] avg/rsg
+    float *red = bufs + 4 * g.sbuf;      // [16 waves][8] partials, then [8] avg / 1/sigma
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6;
     if (p >= n) return;
 
     const float *src = particles + (size_t)p * npix;
     for (int i = tid; i < npix; i += blockDim.x) img[i] = src[i];
-    // the padding slots of every ring buffer must read as finite numbers
     for (int i = tid; i < 4 * g.sbuf; i += blockDim.x) bufs[i] = 0.f;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
@@ -258,26 +261,30 @@ __global__ __launch_bounds__(256) void polar_fft_kernel(DevGeom g, const float *
             __syncthreads();
             if (tid < 4) {
                 float a = 0.f, q = 0.f;
-                for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) { a += red[wv * 8 + tid]; q += red[wv * 8 + 4 + tid]; }
+                for (int wv = 0; wv < nwave; wv++) { a += red[wv * 8 + tid]; q += red[wv * 8 + 4 + tid]; }
                 const float nn = g.nn_weight;
                 float avg = a / nn;
                 float sgm = sqrtf((q - a * a / nn) / nn);
-                red[32 + tid] = avg;
-                red[36 + tid] = 1.0f / sgm;
+                red[128 + tid] = avg;
+                red[132 + tid] = 1.0f / sgm;
             }
             __syncthreads();
         } else {
-            if (tid < 4) { red[32 + tid] = 0.f; red[36 + tid] = 1.f; }
+            if (tid < 4) { red[128 + tid] = 0.f; red[132 + tid] = 1.f; }
             __syncthreads();
         }
-        ring_fft_all(g, bufs, 4, red + 32, red + 36);
+        ring_fft_all(g, bufs, 4, red + 128, red + 132);
 
-        // bin-major write-out: entry e = (bin k, ring i), 4 offsets x (re, im) per entry
-        float *dstA = A + ((size_t)p * ngroup + grp) * g.a_blk;
-        for (int f = tid; f < g.LB * 4; f += blockDim.x) {
-            int e = f >> 2, m4 = f & 3;
-            float2 v = *reinterpret_cast<const float2 *>(bufs + m4 * g.sbuf + g.ent_src[e]);
-            *reinterpret_cast<float2 *>(dstA + 2 * f) = v;
+        // write-out through the gather table: 4 consecutive rings of one (bin, row) per thread
+        float4 *dstA = reinterpret_cast<float4 *>(A + ((size_t)p * ngroup + grp) * g.a_blk);
+        for (int q = tid; q < g.LBP * 2; q += blockDim.x) {
+            const int4 sidx = g.a_src4[q];
+            float4 v;
+            v.x = sidx.x >= 0 ? bufs[sidx.x] : 0.f;
+            v.y = sidx.y >= 0 ? bufs[sidx.y] : 0.f;
+            v.z = sidx.z >= 0 ? bufs[sidx.z] : 0.f;
+            v.w = sidx.w >= 0 ? bufs[sidx.w] : 0.f;
+            dstA[q] = v;
         }
         __syncthreads();
     }
@@ -307,24 +314,24 @@ __global__ __launch_bounds__(256) void ref_polar_fft_kernel(DevGeom g, const flo
     for (int i = tid; i < g.lring; i += blockDim.x) out[(size_t)r * g.lring + i] = bufs[i];
 }
 
-// K0b: Applyws + 1/maxrin, packed bin-major as the MFMA B operand:
-//   B[rtile][entryP][16 cols], col = 2*(ref in tile) + (0: Re, 1: Im); padded entries zero.
+// K0b: Applyws + 1/maxrin, packed as the MFMA B operand:
+//   B[rtile][bin k][16 cols][KP_k rings], col = 2*(ref in tile) + (0: Re, 1: Im); padding zero.
 // (Applyws: test_mref_gpu_align.py:1017)
-__global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, int nref, int refs_per_tile,
-                                 int nrtile, float *__restrict__ B)
+__global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, int nref, int nrtile,
+                                 float *__restrict__ B)
 {
-    const int total = nrtile * g.LBP * 16;
+    const int per_tile = g.LBP * 16, total = nrtile * per_tile;
     const float inv = 1.0f / (float)g.maxrin;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        int col = idx & 15, ep = (idx >> 4) % g.LBP, rt = idx / (16 * g.LBP);
-        // locate the bin of padded entry ep
+        const int rt = idx / per_tile, f = idx - rt * per_tile;
         int lo = 0, hi = g.nbins - 1;
-        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (g.bin_offp[mid] <= ep) lo = mid; else hi = mid - 1; }
-        int k = lo, j = ep - g.bin_offp[k], cnt = g.bin_off[k + 1] - g.bin_off[k];
-        int rr = col >> 1, ref = rt * refs_per_tile + rr;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (g.bin_offp[mid] * 16 <= f) lo = mid; else hi = mid - 1; }
+        const int k = lo, kp = g.bin_offp[k + 1] - g.bin_offp[k], cnt = g.bin_off[k + 1] - g.bin_off[k];
+        const int rem = f - g.bin_offp[k] * 16, col = rem / kp, j = rem - col * kp;
+        const int ref = rt * 8 + (col >> 1);
         float v = 0.f;
-        if (j < cnt && rr < refs_per_tile && ref < nref) {
-            int e = g.bin_off[k] + j;
+        if (j < cnt && ref < nref) {
+            const int e = g.bin_off[k] + j;
             v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
         }
         B[idx] = v;
@@ -359,6 +366,9 @@ __global__ void unpack_refs_kernel(DevGeom g, const float *__restrict__ refspec,
 //   a=c1d1 b=c1d2 c=c2d1 d=c2d2 ;  Q_k = (a+d) + i(c-b) ;  T_k = (a-d) - i(b+c)
 //   Z_k = Q_k + i T_k,  Z_{N-k} = conj(Q_k) + i conj(T_k)  -> one N-point complex inverse
 //   FFT yields q (real part) and t (imaginary part) of Crosrng_ms together.
+// 8 waves: phase 1 gives each wave every 8th bin (operands straight from HBM/L2 into registers:
+// each MFMA lane owns KP/4 contiguous floats of its row, fetched as 16-B loads one bin ahead);
+// phase 2 transforms 4 pairs per wave and round, 16 lanes per transform.
 struct Cand { float val; float tot; int jtot; int refmir; };   // refmir = ref | mirror << 16
 
 template <int N> struct IfftPlan;
@@ -367,20 +377,27 @@ template <> struct IfftPlan<128> { static constexpr int R1 = 16, R2 = 8; };
 template <> struct IfftPlan<64>  { static constexpr int R1 = 8,  R2 = 8; };
 template <> struct IfftPlan<32>  { static constexpr int R1 = 8,  R2 = 4; };
 
-template <int N> __device__ __forceinline__ int zaddr(int pair, int slot)
-{
-    // pair stride 2N+32 dwords; low nibble of the slot rotated by the pair index so that the
-    // 16 lanes of a ds_write_b64 group (16 pairs, same bin) fall on distinct banks
-    int s = (slot & ~15) | ((slot + pair) & 15);
-    return pair * (2 * N + 32) + 2 * s;
-}
+// LDS image of the CCF spectra: one complex slot padded in after every 16, pair stride 2*(N+N/16)+2
+// dwords.  This makes (i) the 16 pairs x same-bin ds_write_b64 of phase 1, (ii) the contiguous
+// and (iii) the stride-16 accesses of the two FFT passes bank-conflict free, with pairs p and
+// p+16 sharing a half-wave in phase 2 (their bases differ by 32 banks mod 64).
+template <int N> struct ZLayout {
+    static constexpr int kPairStride = 2 * (N + N / 16) + 2;
+    static __device__ __forceinline__ int addr(int pair, int slot) { return pair * kPairStride + 2 * (slot + (slot >> 4)); }
+};
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+#define RA_CCF_THREADS 512
+#define RA_CCF_MAXNS 12     // KP_k / 4 <= 12 rings per MFMA lane (nring <= 48)
 
 template <int N>
-__global__ __launch_bounds__(256, 1) void ccf_kernel(DevGeom g, const float *__restrict__ A,
-                                                     const float *__restrict__ B, int n_mtile, int nrtile,
-                                                     int refs_per_tile, int nref, Cand *__restrict__ cand)
+__global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const float *__restrict__ A,
+                                                                const float *__restrict__ B, int n_mtile, int nrtile,
+                                                                int nref, Cand *__restrict__ cand)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
+    typedef ZLayout<N> ZL;
     extern __shared__ __align__(16) float Z[];
     __shared__ Cand pc[64];
     // same-m-tile blocks differ by 8 in blockIdx so they tend to share an XCD (L2 reuse of A)
@@ -389,83 +406,109 @@ __global__ __launch_bounds__(256, 1) void ccf_kernel(DevGeom g, const float *__r
     const int rtile = rem >> 3, mtile = grp * 8 + (rem & 7);
     if (mtile >= n_mtile) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = RA_CCF_THREADS / 64;
 
-    // ---- phase 1: contraction, one bin per wave at a time
+    // ---- phase 1: contraction, every 8th bin per wave, operands prefetched one bin ahead
     {
-        const int row = lane & 15, kk = lane >> 4;
-        const float *Arow = A + (size_t)(2 * mtile + (row >> 3)) * g.a_blk + (row & 7) + kk * 8;
-        const float *Bcol = B + (size_t)rtile * g.LBP * 16 + (lane & 15) + kk * 16;
+        const int r16 = lane & 15, kk = lane >> 4;
+        const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
+        const float *Bt = B + (size_t)rtile * g.LBP * 16;
         const int odd = lane & 1;
         const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);
-        for (int k = wave; k < g.nbins; k += 4) {
-            const int e0 = g.bin_off[k], cnt = g.bin_off[k + 1] - e0, p0 = g.bin_offp[k];
-            const int nstep = (cnt + 3) >> 2;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float *ap = Arow + (size_t)e0 * 8;
-            const float *bp = Bcol + (size_t)p0 * 16;
-            for (int s = 0; s < nstep; s++) {
-                float a = ap[s * 32];
-                float b = bp[s * 64];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        float a_cur[RA_CCF_MAXNS], b_cur[RA_CCF_MAXNS], a_nxt[RA_CCF_MAXNS], b_nxt[RA_CCF_MAXNS];
+        int ns_cur = 0, ns_nxt = 0;
+        auto fetch = [&](int k, float *av, float *bv, int &ns) {
+            const int p0 = g.bin_offp[k], kp = g.bin_offp[k + 1] - p0;
+            ns = kp >> 2;
+            const float *pa = Ablk + (size_t)p0 * 8 + (r16 & 7) * kp + kk * ns;
+            const float *pb = Bt + (size_t)p0 * 16 + r16 * kp + kk * ns;
+#pragma unroll
+            for (int q = 0; q < RA_CCF_MAXNS / 4; q++) {
+                if (4 * q < ns) {
+                    f4u va = *reinterpret_cast<const f4u *>(pa + 4 * q);
+                    f4u vb = *reinterpret_cast<const f4u *>(pb + 4 * q);
+                    av[4 * q] = va.x; av[4 * q + 1] = va.y; av[4 * q + 2] = va.z; av[4 * q + 3] = va.w;
+                    bv[4 * q] = vb.x; bv[4 * q + 1] = vb.y; bv[4 * q + 2] = vb.z; bv[4 * q + 3] = vb.w;
+                }
             }
+        };
+        if (wave < g.nbins) fetch(wave, a_cur, b_cur, ns_cur);
+        for (int k = wave; k < g.nbins; k += NW) {
+            const bool more = k + NW < g.nbins;
+            if (more) fetch(k + NW, a_nxt, b_nxt, ns_nxt);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < RA_CCF_MAXNS; s++)
+                if (s < ns_cur) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[s], acc, 0, 0, 0);
             // 2x2 block exchange between the Re/Im column lanes of one reference
             float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
             float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
             float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
             float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
             float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
-            *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, k)) = make_float2(apd + bpc, cmb + amd);
-            *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
+            *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
+            *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < RA_CCF_MAXNS; s++) { a_cur[s] = a_nxt[s]; b_cur[s] = b_nxt[s]; }
+                ns_cur = ns_nxt;
+            }
+        }
+    }
+    // twiddles e^{+2 pi i n0 j / N} of this lane for the first FFT pass (j = lane & 15)
+    float2 twl[16];
+    {
+        const int j = lane & 15;
+#pragma unroll
+        for (int n0 = 0; n0 < 16; n0++) {
+            float2 t = g.tw[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
+            twl[n0] = make_float2(t.x, -t.y);
         }
     }
     __syncthreads();
 
-    // ---- phase 2: N-point inverse FFT of every pair, 16 lanes per transform, then argmax
-    const int nvalid = min(refs_per_tile, nref - rtile * refs_per_tile);
+    // ---- phase 2: N-point inverse FFT of every live pair, 16 lanes per transform, then argmax.
+    // pair = 16*sub + b, b = (ref slot, particle-offset parity): liveness depends on b only,
+    // so a wave is either wholly busy or wholly idle in a round.
+    const int nvalid = min(8, nref - rtile * 8);
     {
         const int j = lane & 15, sub = lane >> 4;
-        for (int round = 0; round < 4; round++) {
-            const int pair = wave * 16 + round * 4 + sub;
-            const bool live = (pair & 7) < nvalid;
+        const int nlive = 2 * nvalid;                 // live b values: (b & 7) < nvalid
+        for (int idx = wave; idx < nlive; idx += NW) {
+            const int b = (idx / nvalid) * 8 + idx % nvalid;
+            const int pair = 16 * sub + b;
             float2 v[16];
-            if (live && j < R2) {
+            if (j < R2) {
 #pragma unroll
-                for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, R2 * k1 + j));
+                for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, R2 * k1 + j));
                 Dft<1, R1>::run(v);
 #pragma unroll
-                for (int n0 = 0; n0 < R1; n0++) {
-                    float2 o = v[n0];
-                    if (n0 > 0) {
-                        float2 t = g.tw[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
-                        o = cmul(o, make_float2(t.x, -t.y));   // e^{+2 pi i n0 j / N}
-                    }
-                    v[n0] = o;
-                }
+                for (int n0 = 1; n0 < R1; n0++) v[n0] = cmul(v[n0], twl[n0]);
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (live && j < R2) {
+            if (j < R2) {
 #pragma unroll
-                for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, n0 * R2 + j)) = v[n0];
+                for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pair, n0 * R2 + j)) = v[n0];
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             float bq = -1.0e20f, bt = -1.0e20f;
             int iq = 0, it = 0;
-            if (live && j < R1) {
+            if (j < R1) {
 #pragma unroll
-                for (int k0 = 0; k0 < R2; k0++) v[k0] = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, j * R2 + k0));
+                for (int k0 = 0; k0 < R2; k0++) v[k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, j * R2 + k0));
                 Dft<1, R2>::run(v);
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (live && j < R1) {
+            if (j < R1) {
 #pragma unroll
                 for (int n1 = 0; n1 < R2; n1++) {
-                    const int idx = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
-                    *reinterpret_cast<float2 *>(Z + zaddr<N>(pair, idx)) = v[n1];
-                    if (v[n1].x >= bq) { bq = v[n1].x; iq = idx; }
-                    if (v[n1].y >= bt) { bt = v[n1].y; it = idx; }
+                    const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
+                    *reinterpret_cast<float2 *>(Z + ZL::addr(pair, ix)) = v[n1];
+                    if (v[n1].x >= bq) { bq = v[n1].x; iq = ix; }
+                    if (v[n1].y >= bt) { bt = v[n1].y; it = ix; }
                 }
             }
             // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=)
@@ -478,14 +521,14 @@ __global__ __launch_bounds__(256, 1) void ccf_kernel(DevGeom g, const float *__r
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (live && j == 0) {
+            if (j == 0) {
                 // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
                 const bool mir = !(bq >= bt);
                 const int jt = mir ? it : iq;
                 double t7[7];
 #pragma unroll
                 for (int k = -3; k <= 3; k++) {
-                    float2 zz = *reinterpret_cast<const float2 *>(Z + zaddr<N>(pair, (jt + k + N) & (N - 1)));
+                    float2 zz = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, (jt + k + N) & (N - 1)));
                     t7[k + 3] = mir ? (double)zz.y : (double)zz.x;
                 }
                 // Util::prb1d, npoint 7
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void ccf_kernel(DevGeom g, const float *__r
                 c.val = mir ? bt : bq;
                 c.jtot = jt + 1;
                 c.tot = (float)(jt + 1) + pos;
-                c.refmir = (rtile * refs_per_tile + (pair & 7)) | ((mir ? 1 : 0) << 16);
+                c.refmir = (rtile * 8 + (pair & 7)) | ((mir ? 1 : 0) << 16);
                 pc[pair] = c;
             }
         }
