@@ -91,10 +91,21 @@ static int build_device_geometry(ra_engine *e)
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
     d.nn_weight = g.nn_weight; d.mode = e->cfg.mode;
+    d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
     int sbuf = (g.lring + 31) / 32 * 32 + 8;    // == 8 (mod 32): the 4 offsets of an entry hit disjoint banks
     d.sbuf = sbuf;
     d.a_blk = g.LBP * 8 + 64;
-    build_a_src(g, sbuf);
+    // classes of bins with equal ring-slot count
+    d.n_class = 0;
+    for (int k = 0; k < g.nbins; k++) {
+        int ns = (g.bin_offp[k + 1] - g.bin_offp[k]) / 4;
+        if (d.n_class == 0 || d.class_ns[d.n_class - 1] != ns) {
+            if (d.n_class == 8) { g_last_error = "too many bin classes"; return RA_ERR_ARG; }
+            d.class_k0[d.n_class] = k; d.class_ns[d.n_class] = ns; d.n_class++;
+        }
+    }
+    d.class_k0_end = g.nbins;
+    build_operand_tables(g, sbuf);
 
     // FFT work lists
     std::vector<int4> A, B, C;
@@ -146,6 +157,7 @@ static int build_device_geometry(ra_engine *e)
         if ((rc = upload(e, g.a_src, &tmp_a))) return rc;
         d.a_src4 = reinterpret_cast<const int4 *>(tmp_a);
     }
+    if ((rc = upload(e, g.b_src, &d.b_src))) return rc;
     // shift tables are sized for the create-time window; ra_reset_shifts rewrites them
     std::vector<float> sx(g.shift_x), sy(g.shift_y);
     if ((rc = upload(e, sx, &d.shift_x))) return rc;
@@ -394,7 +406,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, e->stream));
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
-        const int nblk = ((n_mtile + 7) / 8) * 8 * e->nrtile;
+        const int nblk = n_mtile;
         if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
         hipLaunchKernelGGL(ccf, dim3(nblk), dim3(RA_CCF_THREADS), e->lds_ccf, e->stream, e->dg, e->d_A, e->d_B, n_mtile,
                            e->nrtile, e->cfg.nref, e->d_cand);

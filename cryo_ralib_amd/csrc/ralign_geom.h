@@ -30,10 +30,8 @@ struct Geometry {
     std::vector<int> bin_offp;     // [nbins+1] prefix of padded counts   (B layout)
     std::vector<int> ent_src;      // [LB] float offset (ring_off[i] + 2k) of entry e=(k,i)
     std::vector<float> ent_wgt;    // [LB] Applyws weight of entry (wr, halved on a short ring's Nyquist)
-    // A / B operand layout of the contraction: per bin k a [row or col][KP_k] panel, KP_k = ring
-    // count padded to a multiple of 4, so that MFMA lane (row, kk) owns KP_k/4 CONTIGUOUS floats
-    std::vector<int> a_src;        // [LBP*8] per A-block float: source offset inside the 4 ring
-                                   //   buffers ((row>>1)*sbuf + ring_off + 2k + (row&1)), -1 = zero pad
+    std::vector<int> a_src;        // [LBP*8]  see build_operand_tables
+    std::vector<int> b_src;        // [LBP*16]
     // search offsets
     int nkx = 0, nky = 0, nshift = 0, nshift_pad = 0;
     float step = 1.f;
@@ -124,16 +122,43 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
     return true;
 }
 
-// A-operand gather table for LDS ring-buffer stride `sbuf` (see Geometry::a_src)
-inline void build_a_src(Geometry &g, int sbuf)
+// Operand panels of the contraction.  For bin k with KP_k = 4*ns padded rings, ring j of the
+// bin is MFMA k-slot (kk = j / ns, s = j % ns).  The ns steps of a lane are stored in chunks of
+// width w = 4,...,4,[2],[1]; inside a chunk the order is [kk][row][w], so one w-wide load per
+// lane is a fully coalesced wave access (lane = kk*16 + row).  An A block holds 8 rows
+// (4 particle-offsets x Re/Im), the B tile 16 columns (8 references x Re/Im).
+// panel_pos(ns, rows, kk, row, s): float offset inside the bin's panel.
+inline int panel_pos(int ns, int rows, int kk, int row, int s)
+{
+    int off = 0, s0 = 0;
+    for (int i = 0; i < (ns >> 2); i++) {
+        if (s < s0 + 4) return off + (kk * rows + row) * 4 + (s - s0);
+        off += 4 * rows * 4; s0 += 4;
+    }
+    if (ns & 2) {
+        if (s < s0 + 2) return off + (kk * rows + row) * 2 + (s - s0);
+        off += 4 * rows * 2; s0 += 2;
+    }
+    return off + (kk * rows + row);
+}
+
+// a_src: per A-block float, the source offset inside the 4 LDS ring buffers (stride sbuf), -1 = 0
+// b_src: per B-tile float, (entry e << 4 | col), -1 = 0
+inline void build_operand_tables(Geometry &g, int sbuf)
 {
     g.a_src.assign((size_t)g.LBP * 8, -1);
+    g.b_src.assign((size_t)g.LBP * 16, -1);
     for (int k = 0; k < g.nbins; k++) {
         const int cnt = g.bin_off[k + 1] - g.bin_off[k], kp = g.bin_offp[k + 1] - g.bin_offp[k];
-        for (int row = 0; row < 8; row++)
-            for (int j = 0; j < cnt; j++)
-                g.a_src[(size_t)g.bin_offp[k] * 8 + row * kp + j] =
-                    (row >> 1) * sbuf + g.ent_src[g.bin_off[k] + j] + (row & 1);
+        const int ns = kp / 4;
+        for (int j = 0; j < cnt; j++) {
+            const int kk = j / ns, s = j % ns, e = g.bin_off[k] + j;
+            for (int row = 0; row < 8; row++)
+                g.a_src[(size_t)g.bin_offp[k] * 8 + panel_pos(ns, 8, kk, row, s)] =
+                    (row >> 1) * sbuf + g.ent_src[e] + (row & 1);
+            for (int col = 0; col < 16; col++)
+                g.b_src[(size_t)g.bin_offp[k] * 16 + panel_pos(ns, 16, kk, col, s)] = (e << 4) | col;
+        }
     }
 }
 

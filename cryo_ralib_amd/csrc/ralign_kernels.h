@@ -35,14 +35,19 @@ struct DevGeom {
     float step, xrng, yrng;
     float nn_weight;
     int mode;                     // RA_MODE_*
+    int dbg;                      // RALIGN_DEBUG bit mask (profiling experiments only; 0 in production)
     int sbuf;                     // LDS stride of one ring buffer (floats)
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
+    int n_class;                  // bins with the same ring-slot count ns form contiguous classes
+    int class_k0[8], class_ns[8]; // class c = bins [class_k0[c], class_k0[c+1]) ; class_k0[n_class] = nbins
+    int class_k0_end;
     const float *samp_dx, *samp_dy, *samp_w;
     const int *samp_dst;
     const int *bin_off, *bin_offp;
     const int *ent_src;
     const int4 *a_src4;           // [LBP*2] gather table of the A write-out, 4 floats per entry
+    const int *b_src;             // [LBP*16] (entry << 4 | col) of every B-tile float, -1 = zero
     const float *ent_wgt;
     const float *shift_x, *shift_y;
     const float2 *tw;             // e^{-2 pi i k / maxrin}, k < maxrin
@@ -314,8 +319,8 @@ __global__ __launch_bounds__(256) void ref_polar_fft_kernel(DevGeom g, const flo
     for (int i = tid; i < g.lring; i += blockDim.x) out[(size_t)r * g.lring + i] = bufs[i];
 }
 
-// K0b: Applyws + 1/maxrin, packed as the MFMA B operand:
-//   B[rtile][bin k][16 cols][KP_k rings], col = 2*(ref in tile) + (0: Re, 1: Im); padding zero.
+// K0b: Applyws + 1/maxrin, packed as the MFMA B operand (layout: ralign_geom.h panel_pos):
+//   B[rtile][LBP*16], column = 2*(ref in tile) + (0: Re, 1: Im); padding zero.
 // (Applyws: test_mref_gpu_align.py:1017)
 __global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, int nref, int nrtile,
                                  float *__restrict__ B)
@@ -324,15 +329,11 @@ __global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, i
     const float inv = 1.0f / (float)g.maxrin;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int rt = idx / per_tile, f = idx - rt * per_tile;
-        int lo = 0, hi = g.nbins - 1;
-        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (g.bin_offp[mid] * 16 <= f) lo = mid; else hi = mid - 1; }
-        const int k = lo, kp = g.bin_offp[k + 1] - g.bin_offp[k], cnt = g.bin_off[k + 1] - g.bin_off[k];
-        const int rem = f - g.bin_offp[k] * 16, col = rem / kp, j = rem - col * kp;
-        const int ref = rt * 8 + (col >> 1);
+        const int code = g.b_src[f];
         float v = 0.f;
-        if (j < cnt && ref < nref) {
-            const int e = g.bin_off[k] + j;
-            v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
+        if (code >= 0) {
+            const int e = code >> 4, col = code & 15, ref = rt * 8 + (col >> 1);
+            if (ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
         }
         B[idx] = v;
     }
@@ -386,75 +387,92 @@ template <int N> struct ZLayout {
     static __device__ __forceinline__ int addr(int pair, int slot) { return pair * kPairStride + 2 * (slot + (slot >> 4)); }
 };
 
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+// phase 1 of ccf_kernel for one class of bins (same number NS of ring slots per MFMA lane, so
+// every load and MFMA below has a static shape).  Wave w takes bins k0+w, k0+w+NW, ...; the
+// operands of the next bin are requested before the current one is multiplied.
+template <int NS> struct Operands { float a[NS], b[NS]; };
+
+template <int NS>
+__device__ __forceinline__ void load_operands(Operands<NS> &o, const float *__restrict__ pa, const float *__restrict__ pb,
+                                              int la, int lb)
+{
+    constexpr int N4 = NS >> 2;
+#pragma unroll
+    for (int q = 0; q < N4; q++) {
+        float4 va = *reinterpret_cast<const float4 *>(pa + q * 128 + la * 4);
+        float4 vb = *reinterpret_cast<const float4 *>(pb + q * 256 + lb * 4);
+        o.a[4 * q] = va.x; o.a[4 * q + 1] = va.y; o.a[4 * q + 2] = va.z; o.a[4 * q + 3] = va.w;
+        o.b[4 * q] = vb.x; o.b[4 * q + 1] = vb.y; o.b[4 * q + 2] = vb.z; o.b[4 * q + 3] = vb.w;
+    }
+    int oa = N4 * 128, ob = N4 * 256;
+    if constexpr ((NS & 2) != 0) {
+        float2 va = *reinterpret_cast<const float2 *>(pa + oa + la * 2);
+        float2 vb = *reinterpret_cast<const float2 *>(pb + ob + lb * 2);
+        o.a[4 * N4] = va.x; o.a[4 * N4 + 1] = va.y; o.b[4 * N4] = vb.x; o.b[4 * N4 + 1] = vb.y;
+        oa += 64; ob += 128;
+    }
+    if constexpr ((NS & 1) != 0) { o.a[NS - 1] = pa[oa + la]; o.b[NS - 1] = pb[ob + lb]; }
+}
+
+template <int N, int NS>
+__device__ __forceinline__ void contract_bin(const Operands<NS> &o, float *Z, int pair, int odd, int k)
+{
+    typedef ZLayout<N> ZL;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[s], o.b[s], acc, 0, 0, 0);
+    // 2x2 block exchange between the Re/Im column lanes of one reference
+    float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
+    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
+    float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
+    float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+    *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
+    *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
+}
+
+template <int N, int NS, int NW>
+__device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, const float *__restrict__ Bt, float *Z,
+                                               int kbeg, int kend, int p0_class, int wave, int la, int lb, int pair,
+                                               int odd)
+{
+    // panel of bin k in this class starts at (p0_class + (k - kbeg) * 4*NS) entries
+    int k = kbeg + wave;
+    if (k >= kend) return;
+    Operands<NS> cur, nxt;
+    load_operands<NS>(cur, Ablk + (size_t)(p0_class + (k - kbeg) * 4 * NS) * 8, Bt + (size_t)(p0_class + (k - kbeg) * 4 * NS) * 16, la, lb);
+    while (true) {
+        const int k1 = k + NW;
+        if (k1 < kend)
+            load_operands<NS>(nxt, Ablk + (size_t)(p0_class + (k1 - kbeg) * 4 * NS) * 8, Bt + (size_t)(p0_class + (k1 - kbeg) * 4 * NS) * 16, la, lb);
+        contract_bin<N, NS>(cur, Z, pair, odd, k);
+        if (k1 >= kend) break;
+        const int k2 = k1 + NW;
+        if (k2 < kend)
+            load_operands<NS>(cur, Ablk + (size_t)(p0_class + (k2 - kbeg) * 4 * NS) * 8, Bt + (size_t)(p0_class + (k2 - kbeg) * 4 * NS) * 16, la, lb);
+        contract_bin<N, NS>(nxt, Z, pair, odd, k1);
+        if (k2 >= kend) break;
+        k = k2;
+    }
+}
 
 #define RA_CCF_THREADS 512
 #define RA_CCF_MAXNS 12     // KP_k / 4 <= 12 rings per MFMA lane (nring <= 48)
 
 template <int N>
 __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const float *__restrict__ A,
-                                                                const float *__restrict__ B, int n_mtile, int nrtile,
-                                                                int nref, Cand *__restrict__ cand)
+                                                             const float *__restrict__ B, int n_mtile, int nrtile,
+                                                             int nref, Cand *__restrict__ cand)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     typedef ZLayout<N> ZL;
     extern __shared__ __align__(16) float Z[];
     __shared__ Cand pc[64];
-    // same-m-tile blocks differ by 8 in blockIdx so they tend to share an XCD (L2 reuse of A)
-    const int bid = blockIdx.x;
-    const int grp = bid / (8 * nrtile), rem = bid - grp * 8 * nrtile;
-    const int rtile = rem >> 3, mtile = grp * 8 + (rem & 7);
+    const int mtile = blockIdx.x;
     if (mtile >= n_mtile) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = RA_CCF_THREADS / 64;
 
-    // ---- phase 1: contraction, every 8th bin per wave, operands prefetched one bin ahead
-    {
-        const int r16 = lane & 15, kk = lane >> 4;
-        const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
-        const float *Bt = B + (size_t)rtile * g.LBP * 16;
-        const int odd = lane & 1;
-        const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);
-        float a_cur[RA_CCF_MAXNS], b_cur[RA_CCF_MAXNS], a_nxt[RA_CCF_MAXNS], b_nxt[RA_CCF_MAXNS];
-        int ns_cur = 0, ns_nxt = 0;
-        auto fetch = [&](int k, float *av, float *bv, int &ns) {
-            const int p0 = g.bin_offp[k], kp = g.bin_offp[k + 1] - p0;
-            ns = kp >> 2;
-            const float *pa = Ablk + (size_t)p0 * 8 + (r16 & 7) * kp + kk * ns;
-            const float *pb = Bt + (size_t)p0 * 16 + r16 * kp + kk * ns;
-#pragma unroll
-            for (int q = 0; q < RA_CCF_MAXNS / 4; q++) {
-                if (4 * q < ns) {
-                    f4u va = *reinterpret_cast<const f4u *>(pa + 4 * q);
-                    f4u vb = *reinterpret_cast<const f4u *>(pb + 4 * q);
-                    av[4 * q] = va.x; av[4 * q + 1] = va.y; av[4 * q + 2] = va.z; av[4 * q + 3] = va.w;
-                    bv[4 * q] = vb.x; bv[4 * q + 1] = vb.y; bv[4 * q + 2] = vb.z; bv[4 * q + 3] = vb.w;
-                }
-            }
-        };
-        if (wave < g.nbins) fetch(wave, a_cur, b_cur, ns_cur);
-        for (int k = wave; k < g.nbins; k += NW) {
-            const bool more = k + NW < g.nbins;
-            if (more) fetch(k + NW, a_nxt, b_nxt, ns_nxt);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < RA_CCF_MAXNS; s++)
-                if (s < ns_cur) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[s], acc, 0, 0, 0);
-            // 2x2 block exchange between the Re/Im column lanes of one reference
-            float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-            float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
-            float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
-            float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
-            float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
-            *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
-            *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
-            if (more) {
-#pragma unroll
-                for (int s = 0; s < RA_CCF_MAXNS; s++) { a_cur[s] = a_nxt[s]; b_cur[s] = b_nxt[s]; }
-                ns_cur = ns_nxt;
-            }
-        }
-    }
     // twiddles e^{+2 pi i n0 j / N} of this lane for the first FFT pass (j = lane & 15)
     float2 twl[16];
     {
@@ -465,13 +483,42 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
             twl[n0] = make_float2(t.x, -t.y);
         }
     }
+
+    // the reference tiles are swept by the same workgroup so that the second and later sweeps
+    // find this tile's A panels in L2 / Infinity Cache instead of HBM
+    for (int rtile = 0; rtile < nrtile; rtile++) {
+    if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
+        Cand c; c.val = 0.f; c.tot = 1.f; c.jtot = 1; c.refmir = min(rtile * 8 + (tid & 7), nref - 1);
+        pc[tid] = c;
+    }
+    // ---- phase 1: contraction, class by class (static shapes inside a class)
+    if (!(g.dbg & 2)) {
+        const int r16 = lane & 15, kk = lane >> 4;
+        const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
+        const float *Bt = B + (size_t)rtile * g.LBP * 16;
+        const int odd = lane & 1;
+        const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);
+        const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
+        int p0 = 0;
+        for (int c = 0; c < g.n_class; c++) {
+            const int kb = g.class_k0[c], ke = (c + 1 < g.n_class) ? g.class_k0[c + 1] : g.class_k0_end, ns = g.class_ns[c];
+            switch (ns) {
+#define RA_CASE(NSV) case NSV: contract_class<N, NSV, NW>(Ablk, Bt, Z, kb, ke, p0, wave, la, lb, pair, odd); break;
+                RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6)
+                RA_CASE(7) RA_CASE(8) RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12)
+#undef RA_CASE
+            default: break;
+            }
+            p0 += (ke - kb) * 4 * ns;
+        }
+    }
     __syncthreads();
 
     // ---- phase 2: N-point inverse FFT of every live pair, 16 lanes per transform, then argmax.
     // pair = 16*sub + b, b = (ref slot, particle-offset parity): liveness depends on b only,
     // so a wave is either wholly busy or wholly idle in a round.
     const int nvalid = min(8, nref - rtile * 8);
-    {
+    if (!(g.dbg & 1)) {
         const int j = lane & 15, sub = lane >> 4;
         const int nlive = 2 * nvalid;                 // live b values: (b & 7) < nvalid
         for (int idx = wave; idx < nlive; idx += NW) {
@@ -555,6 +602,8 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
         }
         cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
     }
+    __syncthreads();
+    }   // rtile
 }
 
 // ------------------------------------------------------------------------------------------
