@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
-    "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
+    "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
 ]
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library(path=None):
     L.ra_update_references.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.ra_normalize_particles.argtypes = [vp, vp, ctypes.c_int]
     L.ra_sync.argtypes = [vp]
+    L.ra_debug_spectra.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     L.ra_kernel_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     # reference surface (test_mref_gpu_align.py:95-97 sets the pointer returns to c_ulonglong)
@@ -240,6 +241,15 @@ class Engine:
     def normalize_particles(self, particles):
         _check(self.lib.ra_normalize_particles(self.handle, self._ptr(particles, self.torch.float32),
                                                particles.shape[0]), "ra_normalize_particles")
+
+    def debug_spectra(self, particles, state):
+        """ring spectra [n][num_shifts][lcirc] (EMAN2 packing) of the polar / ring-FFT stage alone"""
+        n = particles.shape[0]
+        out = np.zeros((n, self.num_shifts, self.lcirc), np.float32)
+        _check(self.lib.ra_debug_spectra(self.handle, self._ptr(particles, self.torch.float32), n,
+                                         self._ptr(state, self.torch.float32), out.ctypes.data_as(ctypes.c_void_p)),
+               "ra_debug_spectra")
+        return out
 
     def sync(self):
         _check(self.lib.ra_sync(self.handle), "ra_sync")

@@ -128,6 +128,57 @@ static int build_device_geometry(ra_engine *e)
     while (B.size() % 16) B.push_back(make_int4(0, 0, 0, 0));
     d.n_itemA = (int)A.size(); d.n_itemB = (int)B.size(); d.n_itemC = (int)C.size();
 
+    // wave-job schedule of the polar kernel: ring instances (offset slot, ring) sorted by ring
+    // length (longest first), cut into jobs of 64/LR instances of one length
+    std::vector<float2> qtab;
+    std::vector<int4> ringinfo(g.nring);
+    std::vector<float> ringw(g.nring);
+    std::vector<int4> inst;
+    std::vector<float> instw;
+    std::vector<int4> jobs;
+    {
+        std::vector<int> qoff(32, -1);
+        const double qpi = 2 * atan(1.0);
+        for (int i = 0; i < g.nring; i++) {
+            const int n = g.numr[3 * i + 2], lg = ilog2_floor(n);
+            if (qoff[lg] < 0) {
+                qoff[lg] = (int)qtab.size();
+                const int lt = n / 4;
+                const double dfi = qpi / lt;
+                for (int jt = 0; jt < lt; jt++) {
+                    float fi = (float)(dfi * jt);
+                    qtab.push_back(make_float2(sinf(fi), cosf(fi)));
+                }
+            }
+            ringinfo[i] = make_int4(g.ring_off[i], g.numr[3 * i], n, qoff[lg]);
+            ringw[i] = (float)(g.numr[3 * i] * 2 * M_PI / (float)n);
+        }
+        auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
+        const int lanes_of[6] = {16, 8, 8, 4, 4, 4};
+        for (int lg = 8; lg >= 3; lg--) {
+            const int n = 1 << lg, code = code_of(n);
+            std::vector<int4> cls;
+            std::vector<float> clsw;
+            for (int sft = 0; sft < 4; sft++)
+                for (int i = 0; i < g.nring; i++)
+                    if (g.numr[3 * i + 2] == n) {
+                        cls.push_back(make_int4(sft | (i << 8), g.ring_off[i], qoff[lg], g.numr[3 * i]));
+                        clsw.push_back(ringw[i]);
+                    }
+            const int per_job = 64 / lanes_of[code];
+            for (size_t b = 0; b < cls.size(); b += per_job) {
+                const int cnt = (int)std::min<size_t>(per_job, cls.size() - b);
+                jobs.push_back(make_int4(code, (int)inst.size(), cnt, 0));
+                for (int c = 0; c < cnt; c++) { inst.push_back(cls[b + c]); instw.push_back(clsw[b + c]); }
+            }
+        }
+        for (int i = 0; i < g.nring; i++)
+            if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
+    }
+    d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
+    d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
+    d.pst = g.nx + 2 * d.bd;
+
     std::vector<float2> tw(g.maxrin);
     for (int k = 0; k < g.maxrin; k++) {
         double a = -2.0 * M_PI * k / g.maxrin;
@@ -158,6 +209,12 @@ static int build_device_geometry(ra_engine *e)
         d.a_src4 = reinterpret_cast<const int4 *>(tmp_a);
     }
     if ((rc = upload(e, g.b_src, &d.b_src))) return rc;
+    {
+        const int *tmp_p;
+        if ((rc = upload(e, g.ent_apos, &tmp_p))) return rc;
+        d.ent_apos = reinterpret_cast<const int2 *>(tmp_p);
+    }
+    if ((rc = upload(e, g.bin_first, &d.bin_first))) return rc;
     // shift tables are sized for the create-time window; ra_reset_shifts rewrites them
     std::vector<float> sx(g.shift_x), sy(g.shift_y);
     if ((rc = upload(e, sx, &d.shift_x))) return rc;
@@ -167,6 +224,12 @@ static int build_device_geometry(ra_engine *e)
     if ((rc = upload(e, B, &d.itemB))) return rc;
     if ((rc = upload(e, C, &d.itemC))) return rc;
     if ((rc = upload(e, mask, &d.mask))) return rc;
+    if ((rc = upload(e, jobs, &d.jobs))) return rc;
+    if ((rc = upload(e, inst, &d.inst))) return rc;
+    if ((rc = upload(e, instw, &d.instw))) return rc;
+    if ((rc = upload(e, qtab, &d.qtab))) return rc;
+    if ((rc = upload(e, ringinfo, &d.ringinfo))) return rc;
+    if ((rc = upload(e, ringw, &d.ringw))) return rc;
     const int *tmp_i; const float *tmp_f;
     if ((rc = upload(e, g.ring_off, &tmp_i))) return rc; e->d_ring_off = (int *)tmp_i;
     if ((rc = upload(e, g.numr, &tmp_i))) return rc; e->d_numr = (int *)tmp_i;
@@ -239,7 +302,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->nrtile = (cfg->nref + 7) / 8;
     const Geometry &g = e->geo;
     const int npix_pad = (g.nx * g.nx + 3) & ~3;
-    e->lds_polar = (size_t)(npix_pad + 4 * e->dg.sbuf + 144) * sizeof(float);
+    e->lds_polar = (size_t)(((e->dg.pst * e->dg.pst + 3) & ~3) + 4 * e->dg.sbuf + 2 * g.maxrin + 2 * e->dg.n_qtab + 2 + 5 * e->dg.n_inst +
+                            4 * e->dg.n_job + 32 + 8 * g.nring) * sizeof(float);
     e->lds_ref = (size_t)(npix_pad + e->dg.sbuf + 8) * sizeof(float);
     e->lds_ccf = (size_t)64 * (2 * (g.maxrin + g.maxrin / 16) + 2) * sizeof(float);
     e->lds_xf = (size_t)npix_pad * sizeof(float);
@@ -417,6 +481,23 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipGetLastError());
     }
     (void)ngroup;
+    return RA_OK;
+}
+
+extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, const float *d_state, float *h_out)
+{
+    if (!e || !d_particles || !d_state || !h_out || n < 1 || n > e->chunk) { g_last_error = "bad argument"; return RA_ERR_ARG; }
+    const Geometry &g = e->geo;
+    hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);
+    RA_HIP(hipGetLastError());
+    float *d_out = nullptr;
+    const size_t cnt = (size_t)n * g.nshift * g.lcirc;
+    RA_HIP(hipMalloc((void **)&d_out, cnt * sizeof(float)));
+    hipLaunchKernelGGL(unpack_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, e->d_A, n, e->d_numr, d_out);
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(h_out, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    RA_HIP(he);
     return RA_OK;
 }
 

@@ -32,6 +32,7 @@ struct Geometry {
     std::vector<float> ent_wgt;    // [LB] Applyws weight of entry (wr, halved on a short ring's Nyquist)
     std::vector<int> a_src;        // [LBP*8]  see build_operand_tables
     std::vector<int> b_src;        // [LBP*16]
+    std::vector<int> ent_apos;     // [LB*2] {A-block float offset of entry e at row 0, chunk width}
     // search offsets
     int nkx = 0, nky = 0, nshift = 0, nshift_pad = 0;
     float step = 1.f;
@@ -148,11 +149,14 @@ inline void build_operand_tables(Geometry &g, int sbuf)
 {
     g.a_src.assign((size_t)g.LBP * 8, -1);
     g.b_src.assign((size_t)g.LBP * 16, -1);
+    g.ent_apos.assign((size_t)g.LB * 2, 0);
     for (int k = 0; k < g.nbins; k++) {
         const int cnt = g.bin_off[k + 1] - g.bin_off[k], kp = g.bin_offp[k + 1] - g.bin_offp[k];
         const int ns = kp / 4;
         for (int j = 0; j < cnt; j++) {
             const int kk = j / ns, s = j % ns, e = g.bin_off[k] + j;
+            g.ent_apos[2 * e] = g.bin_offp[k] * 8 + panel_pos(ns, 8, kk, 0, s);
+            g.ent_apos[2 * e + 1] = panel_pos(ns, 8, kk, 1, s) - panel_pos(ns, 8, kk, 0, s);
             for (int row = 0; row < 8; row++)
                 g.a_src[(size_t)g.bin_offp[k] * 8 + panel_pos(ns, 8, kk, row, s)] =
                     (row >> 1) * sbuf + g.ent_src[e] + (row & 1);

@@ -48,11 +48,22 @@ struct DevGeom {
     const int *ent_src;
     const int4 *a_src4;           // [LBP*2] gather table of the A write-out, 4 floats per entry
     const int *b_src;             // [LBP*16] (entry << 4 | col) of every B-tile float, -1 = zero
+    const int2 *ent_apos;         // [LB] {A-block offset of the entry at row 0, row stride}
+    const int *bin_first;         // [nbins] first ring holding bin k
     const float *ent_wgt;
     const float *shift_x, *shift_y;
     const float2 *tw;             // e^{-2 pi i k / maxrin}, k < maxrin
     const int4 *itemA, *itemB, *itemC;
     const float *mask;            // model_circle(last_ring) [nx*nx]
+    // wave-job schedule of the polar kernel (4 search offsets per pass)
+    int n_job, n_qtab, n_inst;
+    int bd, pst;                  // zero border and row stride of the padded LDS image
+    const int4 *jobs;             // {size code, first instance, instance count, 0}
+    const int4 *inst;             // {offset slot 0..3 | ring << 8, ring_off, qtab offset, radius}, by ring length
+    const float *instw;           // Normalize_ring weight of the instance's ring
+    const float2 *qtab;           // first-quadrant (sinf, cosf) of alrl_ms per ring length
+    const int4 *ringinfo;         // per ring {ring_off, radius, length, qtab offset}
+    const float *ringw;           // per ring Normalize_ring weight r*2pi/n
 };
 
 // ------------------------------------------------------------------------------------------
@@ -77,6 +88,20 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
     const int x0 = min(max(ix, 1), nx) - 1, x1 = min(x0 + 1, nx - 1);
     const int y0 = min(max(iy, 1), nx) - 1, y1 = min(y0 + 1, nx - 1);
     float f00 = img[y0 * nx + x0], f10 = img[y0 * nx + x1], f01 = img[y1 * nx + x0], f11 = img[y1 * nx + x1];
+    return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+}
+
+// the same interpolation on an LDS image with a zero border of `bd` pixels (row stride `st`):
+// every tap of every search offset, including the zero-weight taps one past the image and the
+// taps of offsets outside the particle's window (masked later), stays inside the padded
+// array, so no clamping is needed.  `base` = img + (bd-1)*st + (bd-1) absorbs the 1-based origin.
+__device__ __forceinline__ float bilinear_pad(const float *base, int st, float xold, float yold)
+{
+#pragma clang fp contract(off)
+    const int ix = (int)xold, iy = (int)yold;
+    const float ydif = yold - iy, xdif = xold - ix;
+    const float *p = base + iy * st + ix;
+    const float f00 = p[0], f10 = p[1], f01 = p[st], f11 = p[st + 1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
 
@@ -212,83 +237,207 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
 // Restates Polar2Dm / Normalize_ring / Frngs as called inside Util.multiref_polar_ali_2d
 // (reference call site test_mref_gpu_align.py:1043-1044; ormq for RA_MODE_REFFREE).
 //   particles [n][nx*nx], state [n][2] (accumulated centre offset), A blocks out.
-// One workgroup (16 waves) per particle; 4 offsets per pass.  LDS: image + 4 ring buffers.
-// Output: per block of 4 offsets, per bin k a panel [8 rows = 4 offsets x (Re,Im)][KP_k rings].
+// One workgroup (16 waves) per particle, 4 search offsets per pass; LDS holds the image and 4
+// ring buffers.  Work is cut into wave-jobs: a wave takes 64/LR rings of one length (LR lanes
+// per ring), samples them straight into registers (bilinear taps from the LDS image, sample
+// positions rebuilt from the alrl_ms quadrant table), runs the n/2-point complex FFT as
+// DFT-R1 (registers) -> LDS transpose -> DFT-LR (registers) and the real-FFT split step, with
+// wave-local synchronisation only.  Normalize_ring's affine map is applied after the
+// (linear) FFT: X_k' = (X_k - avg n [k==0]) / sigma.
+// Output: per block of 4 offsets, the bin-major operand panels of ccf_kernel.
 #define RA_POLAR_THREADS 1024
+
+// wave-local hand-off through LDS: all earlier LDS traffic of this wave retired, and the
+// compiler may not move memory operations across this point
+#define RA_WAVE_SYNC()                                               \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
+    } while (0)
+
+template <int R1, int LR>
+__device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
+                                         const float2 *qt_s, const float *ctr, float *red, const int4 *inst_s,
+                                         const float *instw_s, int inst0, int count, int zero)
+{
+    // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
+    // inside the job instead of hoisted out of the pass loop for all six variants (VGPR spills)
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+
+    constexpr int H = R1 * LR, NR = 2 * H, LT = NR / 4;
+    const int sub = lane / LR, t = lane % LR;
+    if (sub >= count) return;
+    const int4 in = inst_s[inst0 + sub];
+    const int slot = in.x & 255, ring = in.x >> 8;
+    float *buf = bufs + slot * g.sbuf + in.y;
+    const float rad = (float)in.w, wt = instw_s[inst0 + sub];
+    const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
+    const float2 *qt = qt_s + in.z;
+    float av = 0.f, sq = 0.f;
+    float2 v[R1];
+#pragma unroll
+    for (int a = 0; a < R1; a++) {
+        float val[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = 2 * (LR * a + t) + u;        // sample index on the ring
+            const int qd = j / LT, jt = j % LT;
+            const float2 sc = qt[jt];
+            float x, y;
+            {
+#pragma clang fp contract(off)
+                x = sc.x * rad; y = sc.y * rad;
+            }
+            // alrl_ms quadrant mirroring: (x,y), (y,-x), (-x,-y), (-y,x)
+            float ox = (qd & 1) ? y : x, oy = (qd & 1) ? x : y;
+            ox = (qd & 2) ? -ox : ox;
+            oy = ((qd + 1) & 2) ? -oy : oy;
+            const float s = bilinear_pad(imgb, g.pst, ox + cx, oy + cy);
+            val[u] = s;
+            av += s * wt;
+            sq += s * s * wt;
+        }
+        v[a] = make_float2(val[0], val[1]);
+        if (a & 1) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 samples' taps in flight (VGPR budget)
+    }
+    if (g.dbg & 256) {   // diagnostic: leave the raw samples in natural order, no FFT
+#pragma unroll
+        for (int a = 0; a < R1; a++) *reinterpret_cast<float2 *>(buf + 2 * (LR * a + t)) = v[a];
+        return;
+    }
+    Dft<-1, R1>::run(v);
+    // element (row c, column t) is parked at LR*c + ((t + c) mod LR): conflict-free both ways
+#pragma unroll
+    for (int c = 0; c < R1; c++) {
+        float2 o = v[c];
+        if (c > 0) o = cmul(o, tw_s[(t * c * (g.maxrin / H)) & (g.maxrin - 1)]);
+        *reinterpret_cast<float2 *>(buf + 2 * (LR * c + ((t + c) & (LR - 1)))) = o;
+    }
+    RA_WAVE_SYNC();
+    float2 z[LR];
+    if (t < R1) {
+#pragma unroll
+        for (int b = 0; b < LR; b++) z[b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * t + ((b + t) & (LR - 1))));
+        Dft<-1, LR>::run(z);
+    }
+    RA_WAVE_SYNC();
+    if (t < R1) {
+#pragma unroll
+        for (int e = 0; e < LR; e++) *reinterpret_cast<float2 *>(buf + 2 * (t + R1 * e)) = z[e];
+    }
+    RA_WAVE_SYNC();
+    // split step X_k <- (Z_k, Z_{H-k}), k = 0..H/2, in place; X_0 and X_H are real
+    for (int k = t; k <= H / 2; k += LR) {
+        float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
+        if (k == 0) {
+            *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
+            *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+        } else {
+            float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
+            float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+            float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+            float2 w = tw_s[k * (g.maxrin / NR)];
+            float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+            *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
+            if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+        }
+    }
+    // Normalize_ring partial sums of this ring -> its own slot (summed in ring order later)
+#pragma unroll
+    for (int o = LR / 2; o > 0; o >>= 1) { av += __shfl_xor(av, o); sq += __shfl_xor(sq, o); }
+    if (t == 0) { red[24 + 2 * (slot * g.nring + ring)] = av; red[25 + 2 * (slot * g.nring + ring)] = sq; }
+}
+
 __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
                                                                      const float *__restrict__ state, int n,
                                                                      float *__restrict__ A)
 {
     extern __shared__ __align__(16) float lds[];
-    const int npix = g.nx * g.nx;
+    const int npad = g.pst * g.pst;
     float *img = lds;
-    float *bufs = lds + ((npix + 3) & ~3);
-    float *red = bufs + 4 * g.sbuf;      // [16 waves][8] partials, then [8] avg / 1/sigma
+    float *bufs = lds + ((npad + 3) & ~3);
+    float2 *tw_s = reinterpret_cast<float2 *>(bufs + 4 * g.sbuf);     // [maxrin]
+    float2 *qt_s = tw_s + g.maxrin;                                    // [n_qtab]
+    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));   // [n_inst]
+    int4 *jobs_s = inst_s + g.n_inst;                                  // [n_job]
+    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);      // [n_inst]
+    float *red = instw_s + g.n_inst;    // [8] -, [8] avg / rsigma, [8] centres, [4*nring*2] ring partials
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
     if (p >= n) return;
 
-    const float *src = particles + (size_t)p * npix;
-    for (int i = tid; i < npix; i += blockDim.x) img[i] = src[i];
+    const float *src = particles + (size_t)p * g.nx * g.nx;
+    for (int i = tid; i < npad; i += blockDim.x) {
+        const int y = i / g.pst - g.bd, x = i % g.pst - g.bd;
+        img[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.nx) ? src[y * g.nx + x] : 0.f;
+    }
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    for (int i = tid; i < g.maxrin; i += blockDim.x) tw_s[i] = g.tw[i];
+    for (int i = tid; i < g.n_qtab; i += blockDim.x) qt_s[i] = g.qtab[i];
+    for (int i = tid; i < g.n_inst; i += blockDim.x) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
+    for (int i = tid; i < g.n_job; i += blockDim.x) jobs_s[i] = g.jobs[i];
     for (int i = tid; i < 4 * g.sbuf; i += blockDim.x) bufs[i] = 0.f;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
-    __syncthreads();
 
     const int ngroup = g.nshift_pad / 4;
     for (int grp = 0; grp < ngroup; grp++) {
-        float cx[4], cy[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            int si = min(grp * 4 + s, g.nshift - 1);
-            cx[s] = cxf + g.shift_x[si];
-            cy[s] = cyf + g.shift_y[si];
+        if (tid < 4) {
+            int si = min(grp * 4 + tid, g.nshift - 1);
+            red[16 + 2 * tid] = cxf + g.shift_x[si];
+            red[17 + 2 * tid] = cyf + g.shift_y[si];
         }
-        float av[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < g.lcirc; i += blockDim.x) {
-            const float dx = g.samp_dx[i], dy = g.samp_dy[i], wt = g.samp_w[i];
-            const int dst = g.samp_dst[i];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float v = bilinear_1b(img, g.nx, dx + cx[s], dy + cy[s]);
-                bufs[s * g.sbuf + dst] = v;
-                av[s] += v * wt;
-                sq[s] += v * v * wt;
+        __syncthreads();
+        if (!(g.dbg & 16)) {
+#pragma unroll 1
+            for (int job = wave; job < g.n_job; job += nwave) {
+                const int4 jd = jobs_s[job];
+                switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+                case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                }
             }
         }
-        if (g.mode == RA_MODE_MREF) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float a = wave_sum(av[s]), q = wave_sum(sq[s]);
-                if (lane == 0) { red[wave * 8 + s] = a; red[wave * 8 + 4 + s] = q; }
-            }
-            __syncthreads();
-            if (tid < 4) {
+        __syncthreads();
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n, then * 1/sigma
+        if (tid < 4) {
+            float avg = 0.f, rsg = 1.f;
+            if (g.mode == RA_MODE_MREF) {
+                // ring order, like Normalize_ring's own loop (fixed order: bitwise reproducible)
                 float a = 0.f, q = 0.f;
-                for (int wv = 0; wv < nwave; wv++) { a += red[wv * 8 + tid]; q += red[wv * 8 + 4 + tid]; }
+                for (int i = 0; i < g.nring; i++) { a += red[24 + 2 * (tid * g.nring + i)]; q += red[25 + 2 * (tid * g.nring + i)]; }
                 const float nn = g.nn_weight;
-                float avg = a / nn;
-                float sgm = sqrtf((q - a * a / nn) / nn);
-                red[128 + tid] = avg;
-                red[132 + tid] = 1.0f / sgm;
+                avg = a / nn;
+                rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
             }
-            __syncthreads();
-        } else {
-            if (tid < 4) { red[128 + tid] = 0.f; red[132 + tid] = 1.f; }
-            __syncthreads();
+            red[8 + tid] = avg; red[12 + tid] = rsg;
         }
-        ring_fft_all(g, bufs, 4, red + 128, red + 132);
-
-        // write-out through the gather table: 4 consecutive rings of one (bin, row) per thread
+        __syncthreads();
+        if (g.mode == RA_MODE_MREF && tid < 4 * g.nring) {
+            const int s = tid / g.nring, i = tid - s * g.nring;
+            const int4 ri = g.ringinfo[i];
+            bufs[s * g.sbuf + ri.x] -= red[8 + s] * (float)ri.z;
+        }
+        __syncthreads();
+        // write-out through the gather table: 4 consecutive ring slots of one (bin, row) per thread
         float4 *dstA = reinterpret_cast<float4 *>(A + ((size_t)p * ngroup + grp) * g.a_blk);
+        if (!(g.dbg & 64))
         for (int q = tid; q < g.LBP * 2; q += blockDim.x) {
             const int4 sidx = g.a_src4[q];
+            auto fetch = [&](int idx) -> float {
+                if (idx < 0) return 0.f;
+                const int m4 = (idx >= g.sbuf) + (idx >= 2 * g.sbuf) + (idx >= 3 * g.sbuf);
+                return bufs[idx] * red[12 + m4];
+            };
             float4 v;
-            v.x = sidx.x >= 0 ? bufs[sidx.x] : 0.f;
-            v.y = sidx.y >= 0 ? bufs[sidx.y] : 0.f;
-            v.z = sidx.z >= 0 ? bufs[sidx.z] : 0.f;
-            v.w = sidx.w >= 0 ? bufs[sidx.w] : 0.f;
+            v.x = fetch(sidx.x); v.y = fetch(sidx.y); v.z = fetch(sidx.z); v.w = fetch(sidx.w);
             dstA[q] = v;
         }
         __syncthreads();
@@ -356,6 +505,29 @@ __global__ void unpack_refs_kernel(DevGeom g, const float *__restrict__ refspec,
             else if (j == 1) v = s[n] * ((n == g.maxrin) ? w : 0.5f * w);
             else v = s[j] * w;
             d[j] = v;
+        }
+    }
+}
+
+// diagnostic: A panels -> ring spectra in EMAN2 packing [n][nshift][lcirc] (what Frngs leaves in
+// `cimage` inside Util.multiref_polar_ali_2d), for bin-for-bin tests of the polar kernel
+__global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, int n, const int *__restrict__ numr,
+                                      float *__restrict__ out)
+{
+    const int m = blockIdx.x;                  // particle * nshift + shift
+    const int p = m / g.nshift, sft = m - p * g.nshift;
+    if (p >= n) return;
+    const float *blk = A + ((size_t)p * (g.nshift_pad / 4) + (sft >> 2)) * g.a_blk;
+    float *dst = out + (size_t)m * g.lcirc;
+    const int row0 = (sft & 3) * 2;
+    for (int i = 0; i < g.nring; i++) {
+        const int nlen = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
+        for (int j = threadIdx.x; j < nlen; j += blockDim.x) {
+            // packed slot j: 0 -> Re X0, 1 -> Re X(n/2), 2k -> Re Xk, 2k+1 -> Im Xk
+            const int k = (j == 0) ? 0 : (j == 1 ? nlen / 2 : j >> 1), comp = (j < 2) ? 0 : (j & 1);
+            const int e = g.bin_off[k] + (i - g.bin_first[k]);
+            const int2 ap = g.ent_apos[e];
+            dst[o + j] = blk[ap.x + (row0 + comp) * ap.y];
         }
     }
 }

@@ -158,6 +158,10 @@ int  ra_update_references(ra_engine *e, const float *d_sums, const int *d_counts
 /* particle preprocessing on device: subtract the mean under model_circle(last_ring)
  * (normalize.mask no_sigma=0, test_mref_gpu_align.py:342), in place */
 int  ra_normalize_particles(ra_engine *e, float *d_particles, int n);
+/* diagnostic: run only the polar / ring-FFT stage on n <= chunk particles and return the ring
+ * spectra of every search offset in EMAN2 packing, h_out [n][num_shifts][lcirc] (what
+ * Polar2Dm -> Normalize_ring -> Frngs leave in `cimage` inside Util.multiref_polar_ali_2d) */
+int  ra_debug_spectra(ra_engine *e, const float *d_particles, int n, const float *d_state, float *h_out);
 /* block until the engine's stream is idle */
 int  ra_sync(ra_engine *e);
 
