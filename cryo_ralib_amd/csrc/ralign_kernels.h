@@ -100,7 +100,7 @@ __device__ __forceinline__ float bilinear_pad(const float *base, int st, float x
 #pragma clang fp contract(off)
     const int ix = (int)xold, iy = (int)yold;
     const float ydif = yold - iy, xdif = xold - ix;
-    const float *p = base + iy * st + ix;
+    const float *p = base + (__mul24(iy, st) + ix);     // 24-bit multiply: full-rate VALU
     const float f00 = p[0], f10 = p[1], f01 = p[st], f11 = p[st + 1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
@@ -282,8 +282,11 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         float val[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int j = 2 * (LR * a + t) + u;        // sample index on the ring
-            const int qd = j / LT, jt = j % LT;
+            // sample index on the ring j = 2*(LR*a + t) + u; when 2*LR <= LT the quadrant of j
+            // depends on `a` alone and is resolved at compile time
+            int qd, jt;
+            if constexpr (2 * LR <= LT) { qd = (2 * LR * a) / LT; jt = (2 * LR * a) % LT + 2 * t + u; }
+            else { const int j = 2 * (LR * a + t) + u; qd = j / LT; jt = j % LT; }
             const float2 sc = qt[jt];
             float x, y;
             {

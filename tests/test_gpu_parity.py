@@ -88,6 +88,38 @@ def test_prepared_references_match_applyws():
     eng.close()
 
 
+@pytest.mark.parametrize("nx,ou,xr,mode", [(90, 36, 3, api.RA_MODE_MREF), (90, 36, 3, api.RA_MODE_REFFREE),
+                                           (32, 12, 2, api.RA_MODE_MREF), (64, 25, 4, api.RA_MODE_MREF)])
+def test_polar_ring_fft_stage_bin_for_bin(nx, ou, xr, mode):
+    """first kernel alone: Polar2Dm -> (Normalize_ring) -> Frngs of every search offset, compared
+    element by element with the oracle in EMAN2's packed ring layout."""
+    n = 3
+    refs = synth.make_references(2, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    eng = api.Engine(nx, ou, xr, xr, 1.0, 2 if mode == api.RA_MODE_MREF else 1, mode)
+    st = np.zeros((n, 2), np.float32)
+    st[1] = (1, -1)
+    got = eng.debug_spectra(torch.from_numpy(parts).to(eng.dev), torch.from_numpy(st).to(eng.dev))
+    sh = geometry.shift_list(xr, xr, 1.0)
+    assert got.shape == (n, len(sh), rg.lcirc)
+    cnx = nx // 2 + 1
+    mashi = cnx - ou - 2
+    for p in range(n):
+        for s in range(len(sh)):
+            # offsets outside the particle's window are masked later and may differ (zero border vs clamped taps)
+            lo = geometry.search_range(nx, ou, st[p, 0], xr), geometry.search_range(nx, ou, st[p, 1], xr)
+            if not (-lo[0][0] <= sh[s, 0] <= lo[0][1] and -lo[1][0] <= sh[s, 1] <= lo[1][1]):
+                continue
+            c = orc.polar2dm(parts[p], cnx + st[p, 0] + sh[s, 0], cnx + st[p, 1] + sh[s, 1], rg)
+            if mode == api.RA_MODE_MREF:
+                c = orc.normalize_ring(c, rg)
+            want = orc.frngs(c, rg)
+            assert np.abs(got[p, s] - want).max() < 1e-5 * np.abs(want).max(), (p, s)
+    assert mashi > 0
+    eng.close()
+
+
 @pytest.mark.parametrize("sigma,n", [(0.25, 256), (1.0, 256)])
 def test_mref_search_headline_config(sigma, n):
     nx, ou, nref, xr = 90, 36, 10, 3
