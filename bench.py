@@ -150,6 +150,18 @@ def main():
     ms_ccf, n_ccf, ms_polar, n_polar = al.engine.kernel_time(False)
 
     if rank == 0:
+        # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
+        # gfx950 + WRITE_SIZE, per particle), scaled to this run's particles per launch
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")) as f:
+                pm = json.load(f)
+            if (nx, ou, nref) == (90, 36, 10):
+                per_particle = pm["kernels"]["ralign::ccf_kernel<256>"]["hbm_bytes_per_dispatch_corrected"] / \
+                    pm["particles_per_dispatch"]
+                traffic = per_particle * (n * args.steps / max(n_ccf, 1))
+        except (OSError, KeyError, ValueError):
+            pass
         total = n * world * args.steps
         polar_f, ccf_f, S, L, M = algorithmic_flops(nx, ou, xr, xr, 1.0, nref)
         # average launch: total particles through the kernel / launches
@@ -166,7 +178,7 @@ def main():
                                    "all-reduce + reference update)" % (n, nx, nx, nref, xr, ou),
                        "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
                          "kernel": "ccf_kernel<%d> (Crosrng_ms contraction + IFFT + argmax)" % M,
                          "flops_per_particle": ccf_f, "particles_per_launch": part_per_launch,
                          "avg_launch_ms": avg_ms, "launches": n_ccf,
