@@ -128,6 +128,7 @@ def main():
     rank, local, world = rdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the alignment engine has no CPU path")
+    local = local % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nx, ou, xr, nref, n = args.nx, args.ou, args.xr, args.nref, args.particles

@@ -382,7 +382,6 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
     for (int i = tid; i < g.n_qtab; i += blockDim.x) qt_s[i] = g.qtab[i];
     for (int i = tid; i < g.n_inst; i += blockDim.x) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
     for (int i = tid; i < g.n_job; i += blockDim.x) jobs_s[i] = g.jobs[i];
-    for (int i = tid; i < 4 * g.sbuf; i += blockDim.x) bufs[i] = 0.f;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
 

@@ -26,7 +26,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RALIGN_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (RCCL refuses duplicate devices)
+            backend = os.environ.get("RALIGN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
