@@ -1,0 +1,148 @@
+"""Command-line entry points with the reference's arguments.
+
+  test_mref_gpu_align.py    data_stack reference_stack outdir <maskfile> --ir --ou --rs --xr --yr --ts
+                            --center --maxit --CTF --snr --function --rand_seed --gpu_devices --gpu_info --MPI --EQ
+                            (test_mref_gpu_align.py:1136-1160)
+  test_reffree_gpu_align.py data_stack outdir <maskfile> --ir --ou --rs --xr --yr --ts --maxit --center ...
+                            (test_reffree_gpu_align.py:911-985)
+
+One process per GPU: run under `python -m torch.distributed.run --nproc-per-node N` instead of the
+reference's `mpirun -np N`; particles are sharded with MPI_start_end, class sums go through one
+RCCL all-reduce.  Outputs: per iteration `aqm%03d.<ext>` class averages (reference :519,564), at the end
+`params.txt` rows `idx angle_psi shift_x shift_y mirror class` / `initial2Dparams.txt` rows
+`alpha sx sy mirror`.  Flags the engine does not implement yet (--CTF, --function filtering/centring,
+a mask file, --MPI CPU path) are accepted and reported, not silently ignored.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+
+def _common(p):
+    p.add_argument("--ir", type=float, default=1)
+    p.add_argument("--ou", type=float, default=-1)
+    p.add_argument("--rs", type=float, default=1)
+    p.add_argument("--ts", default="1")
+    p.add_argument("--maxit", type=float, default=10)
+    p.add_argument("--CTF", action="store_true")
+    p.add_argument("--snr", type=float, default=1.0)
+    p.add_argument("--function", default="ref_ali2d")
+    p.add_argument("--rand_seed", type=int, default=1000)
+    p.add_argument("--gpu_devices", default="")
+    p.add_argument("--gpu_info", action="store_true")
+    p.add_argument("--MPI", action="store_true")
+    p.add_argument("--EQ", action="store_true")
+    p.add_argument("--ext", default="mrcs", help="format of the written stacks: mrcs | npy | hdf")
+
+
+def _first(v):
+    """the reference uses only stage 0 of "4 2 1 1"-style lists (test_reffree_gpu_align.py:355-357)"""
+    return float(str(v).split()[0])
+
+
+def _setup(args):
+    import torch
+    from . import dist as rdist
+    if args.gpu_devices:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu_devices)     # CUDA_VISIBLE_DEVICES analogue (:1239-1250)
+    rank, local, world = rdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: the alignment engine has no CPU path")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    if args.gpu_info:
+        from . import api
+        api.load_library().print_gpu_info(local)
+        raise SystemExit(0)
+    for flag, name in ((args.CTF, "--CTF"), (args.MPI, "--MPI (CPU path)"), (args.EQ, "--EQ")):
+        if flag and rank == 0:
+            print("warning: %s is not implemented by the MI355X engine and is ignored" % name, file=sys.stderr)
+    return rank, local, world
+
+
+def main_mref(argv=None):
+    p = argparse.ArgumentParser(prog="test_mref_gpu_align.py")
+    p.add_argument("stack"); p.add_argument("refstack"); p.add_argument("outdir"); p.add_argument("maskfile", nargs="?")
+    p.add_argument("--xr", default="0"); p.add_argument("--yr", default="0")
+    p.add_argument("--center", type=float, default=1)
+    _common(p)
+    args = p.parse_args(argv)
+    rank, local, world = _setup(args)
+    from . import stackio, dist as rdist
+    from .mref import MrefAligner
+    if args.maskfile and rank == 0:
+        print("warning: mask files are not supported, using model_circle(ou)", file=sys.stderr)
+    data = stackio.read_stack(args.stack)
+    refs = stackio.read_stack(args.refstack)
+    total, nx = data.shape[0], data.shape[-1]
+    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2            # last_ring default (:311)
+    lo, hi = rdist.shard_range(total, world, rank)
+    xr, yr, ts = _first(args.xr), _first(args.yr), _first(args.ts)
+    al = MrefAligner(data[lo:hi], refs, ou, xr, yr, ts, int(args.ir), int(args.rs), device=local, index0=lo,
+                     total_nima=total, rand_seed=args.rand_seed, preprocess=True)
+    if rank == 0:
+        os.makedirs(args.outdir, exist_ok=True)
+    maxit = int(args.maxit) if int(args.maxit) > 0 else 10
+    for it in range(maxit):
+        counts = al.iterate()
+        if rank == 0:
+            stackio.write_stack(os.path.join(args.outdir, "aqm%03d.%s" % (it, args.ext)), al.refs.cpu().numpy())
+            print("ITERATION #%3d" % (it + 1))
+            for j, c in enumerate(counts):
+                print("   group #%3d   number of particles = %7d" % (j, c))
+    r = al.params()
+    rows = [(lo + i, float(r["alpha"][i]), float(r["sx"][i]), float(r["sy"][i]), int(r["mirror"][i]), int(r["ref_id"][i]))
+            for i in range(hi - lo)]
+    if world > 1:
+        import torch.distributed as td
+        gathered = [None] * world
+        td.all_gather_object(gathered, rows)
+        rows = [x for part in gathered for x in part]
+    if rank == 0:
+        stackio.write_text_rows(os.path.join(args.outdir, "params.txt"), rows)
+        stackio.write_stack(os.path.join(args.outdir, "multi_ref.%s" % args.ext), al.refs.cpu().numpy())
+    al.close()
+    return 0
+
+
+def main_reffree(argv=None):
+    p = argparse.ArgumentParser(prog="test_reffree_gpu_align.py")
+    p.add_argument("stack"); p.add_argument("outdir"); p.add_argument("maskfile", nargs="?")
+    p.add_argument("--xr", default="4 2 1 1"); p.add_argument("--yr", default="-1")
+    p.add_argument("--center", type=float, default=-1)
+    p.add_argument("--nomirror", action="store_true"); p.add_argument("--dst", type=float, default=0.0)
+    p.add_argument("--Fourvar", action="store_true"); p.add_argument("--mode", default="F")
+    p.add_argument("--random_method", default="")
+    _common(p)
+    args = p.parse_args(argv)
+    rank, local, world = _setup(args)
+    from . import stackio, dist as rdist
+    from .mref import RefFreeAligner
+    data = stackio.read_stack(args.stack)
+    total, nx = data.shape[0], data.shape[-1]
+    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2
+    xr = _first(args.xr)
+    yr = xr if _first(args.yr) < 0 else _first(args.yr)
+    lo, hi = rdist.shard_range(total, world, rank)
+    al = RefFreeAligner(data[lo:hi], ou, xr, yr, _first(args.ts), int(args.ir), int(args.rs), device=local, index0=lo,
+                        total_nima=total)
+    maxit = int(args.maxit) if int(args.maxit) > 0 else 10
+    for it in range(maxit):
+        a1 = al.iterate(int(args.center))
+        if rank == 0:
+            print("Iteration #%4d   Criterion = %15.8e" % (it + 1, a1))
+    r = al.params()
+    rows = [(float(r["alpha"][i]), float(r["sx"][i]), float(r["sy"][i]), int(r["mirror"][i])) for i in range(hi - lo)]
+    if world > 1:
+        import torch.distributed as td
+        gathered = [None] * world
+        td.all_gather_object(gathered, rows)
+        rows = [x for part in gathered for x in part]
+    if rank == 0:
+        os.makedirs(args.outdir, exist_ok=True)
+        stackio.write_text_rows(os.path.join(args.outdir, "initial2Dparams.txt"), rows)
+        stackio.write_stack(os.path.join(args.outdir, "aqfinal.%s" % args.ext), al.tavg.cpu().numpy())
+    al.close()
+    return 0

@@ -457,3 +457,23 @@ def test_full_size_properties():
     assert (r2["ref_id"] == ref_before).mean() > 0.999
     assert np.abs(al.state.cpu().numpy()).max() <= 8 + xr
     al.close()
+
+
+def test_command_line_entry_points(tmp_path):
+    """the named entry points end to end on .mrcs stacks: outputs exist, classes are recovered"""
+    from cryo_ralib_amd import cli, stackio
+    nx, ou, nref, xr, n = 32, 12, 3, 2, 120
+    refs = synth.make_references(nref, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, 0.25)
+    stackio.write_stack(str(tmp_path / "stack.mrcs"), parts)
+    stackio.write_stack(str(tmp_path / "refs.mrcs"), refs)
+    out = tmp_path / "out"
+    assert cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out), "--ou=12", "--xr=2",
+                          "--yr=2", "--maxit=3"]) == 0
+    rows = np.loadtxt(out / "params.txt")
+    assert rows.shape == (n, 6) and (rows[:, 5].astype(int) == truth["cls"]).mean() > 0.98
+    assert stackio.read_stack(str(out / "aqm002.mrcs")).shape == (nref, nx, nx)
+    out2 = tmp_path / "out2"
+    assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
+                             "--center=0"]) == 0
+    assert np.loadtxt(out2 / "initial2Dparams.txt").shape == (n, 4)

@@ -108,3 +108,30 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle-free", ""), f
+
+
+def test_stack_io_round_trip(tmp_path):
+    from cryo_ralib_amd import stackio
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(5, 12, 12)).astype(np.float32)
+    for ext in ("npy", "mrcs"):
+        p = str(tmp_path / ("s." + ext))
+        stackio.write_stack(p, a)
+        np.testing.assert_array_equal(stackio.read_stack(p), a)
+    with pytest.raises((RuntimeError, ValueError)):
+        stackio.read_stack(str(tmp_path / "missing.hdf"))
+    stackio.write_text_rows(str(tmp_path / "p.txt"), [(0, 1.968414, 1.102456, 2.963881, 0, 0)])
+    row = open(tmp_path / "p.txt").read().split()
+    assert [float(x) for x in row] == [0, 1.968414, 1.102456, 2.963881, 0, 0]      # notebook/03 cell 6 column order
+
+
+def test_cli_flags_match_reference():
+    from cryo_ralib_amd import cli
+    import argparse
+    # test_mref_gpu_align.py:1142-1159 and test_reffree_gpu_align.py:918-935 flag names
+    src = open(os.path.join(ROOT, "cryo_ralib_amd", "cli.py")).read()
+    for flag in ("--ir", "--ou", "--rs", "--xr", "--yr", "--ts", "--center", "--maxit", "--CTF", "--snr", "--function",
+                 "--rand_seed", "--gpu_devices", "--gpu_info", "--MPI", "--EQ", "--nomirror", "--dst", "--Fourvar",
+                 "--mode", "--random_method"):
+        assert '"%s"' % flag in src, flag
+    assert cli._first("4 2 1 1") == 4.0 and cli._first(3) == 3.0
