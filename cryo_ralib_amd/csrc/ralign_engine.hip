@@ -45,6 +45,8 @@ struct ra_engine {
     float *d_refspec = nullptr;         // [nref][lring]
     float *d_B = nullptr;               // [nrtile][LBP][16]
     float *d_cs = nullptr;              // [2]
+    float *d_alscratch = nullptr;       // [chunk][nx*nx] aligned images of one chunk (deterministic class sums)
+    bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
@@ -318,21 +320,24 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
 
     // workspace: bin-major spectra of `chunk` particles + candidate records
     int chunk = cfg->chunk > 0 ? cfg->chunk : 8192;
-    chunk = (chunk + 1) & ~1;
+    chunk = std::min((chunk + 1) & ~1, 32768);      // class_sum_kernel keeps a chunk's member list in LDS
     e->chunk = chunk;
     const int ngroup = g.nshift_pad / 4;
     if ((rc = dev_alloc(e, &e->d_A, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
         (rc = dev_alloc(e, &e->d_cand, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)) ||
         (rc = dev_alloc(e, &e->d_refspec, (size_t)cfg->nref * g.lring, true)) ||
         (rc = dev_alloc(e, &e->d_B, (size_t)e->nrtile * g.LBP * 16, true)) ||
-        (rc = dev_alloc(e, &e->d_cs, 2, true))) {
+        (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
+        (rc = dev_alloc(e, &e->d_alscratch, (size_t)chunk * g.nx * g.nx, false))) {
         ra_destroy(e);
         return rc;
     }
+    e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
     return RA_OK;
 }
@@ -507,9 +512,24 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
     if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (n == 0) return RA_OK;
     if (!d_particles || !d_result) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, e->geo.nx, d_particles, n, index0,
-                       d_result, d_aligned, d_sums, d_counts);
-    RA_HIP(hipGetLastError());
+    const int nx = e->geo.nx, npix = nx * nx;
+    if (!d_sums || e->atomic_sums) {
+        hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, nx, d_particles, n, index0,
+                           d_result, d_aligned, d_sums, d_counts);
+        RA_HIP(hipGetLastError());
+        return RA_OK;
+    }
+    // deterministic path: aligned images of a chunk, then particle-order sums per (class, parity)
+    for (int start = 0; start < n; start += e->chunk) {
+        const int cn = std::min(e->chunk, n - start);
+        float *al = d_aligned ? d_aligned + (size_t)start * npix : e->d_alscratch;
+        hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(256), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
+                           cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
+        RA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(class_sum_kernel, dim3(2 * e->cfg.nref, (npix + 255) / 256), dim3(256), (size_t)cn * sizeof(int), e->stream, npix, al,
+                           d_result + start, cn, index0 + start, d_sums, d_counts);
+        RA_HIP(hipGetLastError());
+    }
     return RA_OK;
 }
 

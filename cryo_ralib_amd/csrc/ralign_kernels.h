@@ -904,6 +904,41 @@ __global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__r
     if (counts && tid == 0) atomicAdd(counts + r.ref_id, 1);
 }
 
+// K4b: per-class even/odd sums in PARTICLE ORDER (the order Util.add_img is called in on the CPU
+// path, test_mref_gpu_align.py:1056-1057), hence bitwise reproducible: one workgroup per
+// (class, parity, 256-pixel tile) walks the batch and adds the aligned images that belong to it.
+// Same scan-all-particles shape as the reference's cu_average_batch_m (gpu_aln_noref.cu:1232-1274).
+__global__ __launch_bounds__(256) void class_sum_kernel(int npix, const float *__restrict__ aligned,
+                                                        const ra_result *__restrict__ res, int n, int index0,
+                                                        float *__restrict__ sums, int *__restrict__ counts)
+{
+    extern __shared__ int members[];          // [n] particle indices of this (class, parity), ascending
+    __shared__ int nmem;
+    const int seg = blockIdx.x, cls = seg >> 1, par = seg & 1;
+    const int pix = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool live = pix < npix;
+    // wave 0 compacts the member list in particle order (ballot + prefix count keeps the order)
+    if (threadIdx.x < 64) {
+        int base = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + threadIdx.x;
+            const bool mine = i < n && res[i].ref_id == cls && ((index0 + i) & 1) == par;
+            const unsigned long long m = __ballot(mine);
+            if (mine) members[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = i;
+            base += __popcll(m);
+        }
+        if (threadIdx.x == 0) nmem = base;
+    }
+    __syncthreads();
+    const int cnt = nmem;
+    if (live) {
+        float acc = sums[(size_t)seg * npix + pix];
+        for (int j = 0; j < cnt; j++) acc += aligned[(size_t)members[j] * npix + pix];
+        sums[(size_t)seg * npix + pix] = acc;
+    }
+    if (counts && blockIdx.y == 0 && threadIdx.x == 0 && cnt) atomicAdd(counts + cls, cnt);
+}
+
 // K5: new references from the class sums: (even + odd) * (1/count), then
 // normalize.mask(no_sigma=1) (test_mref_gpu_align.py:534-535, 563)
 __global__ __launch_bounds__(256) void update_refs_kernel(int nx, const float *__restrict__ sums,

@@ -477,3 +477,34 @@ def test_command_line_entry_points(tmp_path):
     assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
                              "--center=0"]) == 0
     assert np.loadtxt(out2 / "initial2Dparams.txt").shape == (n, 4)
+
+
+def test_class_sums_are_bitwise_reproducible():
+    """class sums are accumulated in particle order (like Util.add_img on the CPU path): two runs agree bit for bit"""
+    nx, ou, nref, xr, n = 90, 36, 4, 3, 300
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    outs = []
+    for _ in range(2):
+        eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, chunk=128)
+        gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
+        gc = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
+        eng.transform_accumulate(tp, res, 3, None, gs, gc)
+        eng.sync()
+        outs.append((gs.cpu().numpy().copy(), gc.cpu().numpy().copy(), eng.result_to_numpy(res).copy()))
+        eng.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][1].sum() == n
+    # and they equal a particle-order float32 accumulation of the engine's own aligned images
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    al = torch.zeros((n, nx, nx), device=eng.dev)
+    eng.transform_accumulate(tp, res, 3, al, None, None)
+    eng.sync()
+    a = al.cpu().numpy(); r = eng.result_to_numpy(res)
+    want = np.zeros((nref, 2, nx, nx), np.float32)
+    for i in range(n):
+        want[r["ref_id"][i], (3 + i) % 2] += a[i]
+    np.testing.assert_array_equal(outs[0][0], want)
+    eng.close()
