@@ -408,18 +408,21 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             }
         }
         __syncthreads();
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n, then * 1/sigma
-        if (tid < 4) {
-            float avg = 0.f, rsg = 1.f;
-            if (g.mode == RA_MODE_MREF) {
-                // ring order, like Normalize_ring's own loop (fixed order: bitwise reproducible)
-                float a = 0.f, q = 0.f;
-                for (int i = 0; i < g.nring; i++) { a += red[24 + 2 * (tid * g.nring + i)]; q += red[25 + 2 * (tid * g.nring + i)]; }
-                const float nn = g.nn_weight;
-                avg = a / nn;
-                rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n, then * 1/sigma.
+        // Wave s (< 4) reduces the ring partials of offset s with a fixed butterfly (reproducible).
+        if (wave < 4) {
+            float a = 0.f, q = 0.f;
+            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
+            a = wave_sum(a); q = wave_sum(q);
+            if (lane == 0) {
+                float avg = 0.f, rsg = 1.f;
+                if (g.mode == RA_MODE_MREF) {
+                    const float nn = g.nn_weight;
+                    avg = a / nn;
+                    rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+                }
+                red[8 + wave] = avg; red[12 + wave] = rsg;
             }
-            red[8 + tid] = avg; red[12 + tid] = rsg;
         }
         __syncthreads();
         if (g.mode == RA_MODE_MREF && tid < 4 * g.nring) {
@@ -630,6 +633,100 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
     }
 }
 
+// phase 2 of ccf_kernel for NP pairs handled by the same 16-lane group: N-point complex inverse
+// FFT (radix R1 x R2 through the LDS image), argmax of real (q) and imaginary (t) parts with the
+// ">=" / last-index rule, prb1d on the 7-point neighbourhood of the winner.
+template <int N, int NP>
+__device__ __forceinline__ void ifft_argmax(float *Z, Cand *pc, const float2 *twl, int pairA, int pairB, int j, int rtile)
+{
+    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
+    typedef ZLayout<N> ZL;
+    const int pr[2] = {pairA, pairB};
+    float2 v[NP][16];
+    if (j < R2) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int k1 = 0; k1 < R1; k1++) v[q][k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], R2 * k1 + j));
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            Dft<1, R1>::run(v[q]);
+#pragma unroll
+            for (int n0 = 1; n0 < R1; n0++) v[q][n0] = cmul(v[q][n0], twl[n0]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (j < R2) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pr[q], n0 * R2 + j)) = v[q][n0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (j < R1) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int k0 = 0; k0 < R2; k0++) v[q][k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], j * R2 + k0));
+#pragma unroll
+        for (int q = 0; q < NP; q++) Dft<1, R2>::run(v[q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float bq[NP], bt[NP];
+    int iq[NP], it[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        bq[q] = -1.0e20f; bt[q] = -1.0e20f; iq[q] = 0; it[q] = 0;
+        if (j < R1) {
+#pragma unroll
+            for (int n1 = 0; n1 < R2; n1++) {
+                const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
+                *reinterpret_cast<float2 *>(Z + ZL::addr(pr[q], ix)) = v[q][n1];
+                if (v[q][n1].x >= bq[q]) { bq[q] = v[q][n1].x; iq[q] = ix; }
+                if (v[q][n1].y >= bt[q]) { bt[q] = v[q][n1].y; it[q] = ix; }
+            }
+        }
+        // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            float oq = __shfl_xor(bq[q], o); int oiq = __shfl_xor(iq[q], o);
+            float ot = __shfl_xor(bt[q], o); int oit = __shfl_xor(it[q], o);
+            if (oq > bq[q] || (oq == bq[q] && oiq > iq[q])) { bq[q] = oq; iq[q] = oiq; }
+            if (ot > bt[q] || (ot == bt[q] && oit > it[q])) { bt[q] = ot; it[q] = oit; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (j < NP) {
+        // lane q of the group finishes pair q: qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
+        const float mq = (j == 0) ? bq[0] : bq[NP - 1], mt = (j == 0) ? bt[0] : bt[NP - 1];
+        const int miq = (j == 0) ? iq[0] : iq[NP - 1], mit = (j == 0) ? it[0] : it[NP - 1];
+        const int pair = (j == 0) ? pr[0] : pr[NP - 1];
+        const bool mir = !(mq >= mt);
+        const int jt = mir ? mit : miq;
+        double t7[7];
+#pragma unroll
+        for (int k = -3; k <= 3; k++) {
+            float2 zz = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, (jt + k + N) & (N - 1)));
+            t7[k + 3] = mir ? (double)zz.y : (double)zz.x;
+        }
+        // Util::prb1d, npoint 7
+        double c2 = 49. * t7[0] + 6. * t7[1] - 21. * t7[2] - 32. * t7[3] - 27. * t7[4] - 6. * t7[5] + 31. * t7[6];
+        double c3 = 5. * t7[0] - 3. * t7[2] - 4. * t7[3] - 3. * t7[4] + 5. * t7[6];
+        float pos = 0.f;
+        if (c3 != 0.0) pos = (float)(c2 / (2.0 * c3) - 4);
+        Cand c;
+        c.val = mir ? mt : mq;
+        c.jtot = jt + 1;
+        c.tot = (float)(jt + 1) + pos;
+        c.refmir = (rtile * 8 + (pair & 7)) | ((mir ? 1 : 0) << 16);
+        pc[pair] = c;
+    }
+}
+
 #define RA_CCF_THREADS 512
 #define RA_CCF_MAXNS 12     // KP_k / 4 <= 12 rings per MFMA lane (nring <= 48)
 
@@ -690,80 +787,19 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
 
     // ---- phase 2: N-point inverse FFT of every live pair, 16 lanes per transform, then argmax.
     // pair = 16*sub + b, b = (ref slot, particle-offset parity): liveness depends on b only,
-    // so a wave is either wholly busy or wholly idle in a round.
+    // so a wave is either wholly busy or wholly idle in a round.  A wave transforms two pairs
+    // per lane group at a time (independent register chains hide the DFT's dependent latency).
     const int nvalid = min(8, nref - rtile * 8);
     if (!(g.dbg & 1)) {
         const int j = lane & 15, sub = lane >> 4;
         const int nlive = 2 * nvalid;                 // live b values: (b & 7) < nvalid
-        for (int idx = wave; idx < nlive; idx += NW) {
-            const int b = (idx / nvalid) * 8 + idx % nvalid;
-            const int pair = 16 * sub + b;
-            float2 v[16];
-            if (j < R2) {
-#pragma unroll
-                for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, R2 * k1 + j));
-                Dft<1, R1>::run(v);
-#pragma unroll
-                for (int n0 = 1; n0 < R1; n0++) v[n0] = cmul(v[n0], twl[n0]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (j < R2) {
-#pragma unroll
-                for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pair, n0 * R2 + j)) = v[n0];
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            float bq = -1.0e20f, bt = -1.0e20f;
-            int iq = 0, it = 0;
-            if (j < R1) {
-#pragma unroll
-                for (int k0 = 0; k0 < R2; k0++) v[k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, j * R2 + k0));
-                Dft<1, R2>::run(v);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (j < R1) {
-#pragma unroll
-                for (int n1 = 0; n1 < R2; n1++) {
-                    const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
-                    *reinterpret_cast<float2 *>(Z + ZL::addr(pair, ix)) = v[n1];
-                    if (v[n1].x >= bq) { bq = v[n1].x; iq = ix; }
-                    if (v[n1].y >= bt) { bt = v[n1].y; it = ix; }
-                }
-            }
-            // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=)
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                float oq = __shfl_xor(bq, o); int oiq = __shfl_xor(iq, o);
-                float ot = __shfl_xor(bt, o); int oit = __shfl_xor(it, o);
-                if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
-                if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (j == 0) {
-                // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
-                const bool mir = !(bq >= bt);
-                const int jt = mir ? it : iq;
-                double t7[7];
-#pragma unroll
-                for (int k = -3; k <= 3; k++) {
-                    float2 zz = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, (jt + k + N) & (N - 1)));
-                    t7[k + 3] = mir ? (double)zz.y : (double)zz.x;
-                }
-                // Util::prb1d, npoint 7
-                double c2 = 49. * t7[0] + 6. * t7[1] - 21. * t7[2] - 32. * t7[3] - 27. * t7[4] - 6. * t7[5] + 31. * t7[6];
-                double c3 = 5. * t7[0] - 3. * t7[2] - 4. * t7[3] - 3. * t7[4] + 5. * t7[6];
-                float pos = 0.f;
-                if (c3 != 0.0) pos = (float)(c2 / (2.0 * c3) - 4);
-                Cand c;
-                c.val = mir ? bt : bq;
-                c.jtot = jt + 1;
-                c.tot = (float)(jt + 1) + pos;
-                c.refmir = (rtile * 8 + (pair & 7)) | ((mir ? 1 : 0) << 16);
-                pc[pair] = c;
-            }
+        for (int idx = wave; idx < nlive; idx += 2 * NW) {
+            const int idx2 = idx + NW;
+            const bool two = idx2 < nlive;
+            const int bA = (idx / nvalid) * 8 + idx % nvalid;
+            const int bB = two ? (idx2 / nvalid) * 8 + idx2 % nvalid : bA;
+            if (two) ifft_argmax<N, 2>(Z, pc, twl, 16 * sub + bA, 16 * sub + bB, j, rtile);
+            else ifft_argmax<N, 1>(Z, pc, twl, 16 * sub + bA, 16 * sub + bA, j, rtile);
         }
     }
     __syncthreads();
