@@ -42,6 +42,13 @@ struct ra_engine {
     std::vector<void *> owned;          // device allocations freed at destroy
     float *d_A = nullptr;               // [chunk * ngroup + 2][a_blk]
     Cand *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
+    // second workspace + auxiliary stream: the polar kernel of chunk i+1 (VALU/LDS-bound) runs
+    // beside the contraction kernel of chunk i (HBM-bound) instead of behind it
+    float *d_A2 = nullptr;
+    Cand *d_cand2 = nullptr;
+    hipStream_t s_aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_polar_done[2] = {nullptr, nullptr}, ev_ccf_done[2] = {nullptr, nullptr};
+    bool overlap = false;               // RALIGN_OVERLAP=1 (measured: no net gain on MI355X)
     float *d_refspec = nullptr;         // [nref][lring]
     float *d_B = nullptr;               // [nrtile][LBP][16]
     float *d_cs = nullptr;              // [2]
@@ -330,6 +337,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     const int ngroup = g.nshift_pad / 4;
     if ((rc = dev_alloc(e, &e->d_A, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
         (rc = dev_alloc(e, &e->d_cand, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)) ||
+
         (rc = dev_alloc(e, &e->d_refspec, (size_t)cfg->nref * g.lring, true)) ||
         (rc = dev_alloc(e, &e->d_B, (size_t)e->nrtile * g.LBP * 16, true)) ||
         (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
@@ -338,6 +346,21 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         return rc;
     }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
+    e->overlap = getenv("RALIGN_OVERLAP") && atoi(getenv("RALIGN_OVERLAP")) != 0;
+    if (e->overlap && ((rc = dev_alloc(e, &e->d_A2, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
+                       (rc = dev_alloc(e, &e->d_cand2, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)))) {
+        ra_destroy(e);
+        return rc;
+    }
+    {
+        hipError_t he2 = hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking);
+        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        for (int i = 0; i < 2 && he2 == hipSuccess; i++) {
+            he2 = hipEventCreateWithFlags(&e->ev_polar_done[i], hipEventDisableTiming);
+            if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&e->ev_ccf_done[i], hipEventDisableTiming);
+        }
+        if (he2 != hipSuccess) { g_last_error = std::string("stream/event creation: ") + hipGetErrorString(he2); ra_destroy(e); return RA_ERR_HIP; }
+    }
     *out = e;
     return RA_OK;
 }
@@ -348,6 +371,12 @@ extern "C" void ra_destroy(ra_engine *e)
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     for (void *p : e->owned) (void)hipFree(p);
+    if (e->s_aux) (void)hipStreamDestroy(e->s_aux);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 2; i++) {
+        if (e->ev_polar_done[i]) (void)hipEventDestroy(e->ev_polar_done[i]);
+        if (e->ev_ccf_done[i]) (void)hipEventDestroy(e->ev_ccf_done[i]);
+    }
     for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -461,8 +490,18 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         hipLaunchKernelGGL(apply_cs_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_cs, d_result, d_state);
         RA_HIP(hipGetLastError());
     }
-    for (int start = 0; start < n; start += e->chunk) {
+    const bool ov = e->overlap && n > e->chunk;
+    hipStream_t sp = e->stream, sc = ov ? e->s_aux : e->stream;
+    if (ov) {
+        RA_HIP(hipEventRecord(e->ev_fork, sp));
+        RA_HIP(hipStreamWaitEvent(sc, e->ev_fork, 0));
+    }
+    int ci = 0;
+    for (int start = 0; start < n; start += e->chunk, ci++) {
         const int cn = std::min(e->chunk, n - start);
+        const int b = ov ? (ci & 1) : 0;
+        float *Abuf = b ? e->d_A2 : e->d_A;
+        Cand *Cbuf = b ? e->d_cand2 : e->d_cand;
         const float *part = d_particles + (size_t)start * npix;
         float *st = d_state + (size_t)start * 2;
         std::pair<hipEvent_t, hipEvent_t> *evp = nullptr, *evc = nullptr;
@@ -470,20 +509,30 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             evp = next_events(e->ev_polar, e->ev_used_polar);
             evc = next_events(e->ev_ccf, e->ev_used_ccf);
         }
-        if (evp) RA_HIP(hipEventRecord(evp->first, e->stream));
-        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, part, st, cn, e->d_A);
+        // the polar kernel of this chunk may not overwrite a workspace the contraction of chunk ci-2 still reads
+        if (ov && ci >= 2) RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[b], 0));
+        if (evp) RA_HIP(hipEventRecord(evp->first, sp));
+        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
-        if (evp) RA_HIP(hipEventRecord(evp->second, e->stream));
+        if (evp) RA_HIP(hipEventRecord(evp->second, sp));
+        if (ov) {
+            RA_HIP(hipEventRecord(e->ev_polar_done[b], sp));
+            RA_HIP(hipStreamWaitEvent(sc, e->ev_polar_done[b], 0));
+        }
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
-        const int nblk = n_mtile;
-        if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
-        hipLaunchKernelGGL(ccf, dim3(nblk), dim3(RA_CCF_THREADS), e->lds_ccf, e->stream, e->dg, e->d_A, e->d_B, n_mtile,
-                           e->nrtile, e->cfg.nref, e->d_cand);
+        if (evc) RA_HIP(hipEventRecord(evc->first, sc));
+        hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sc, e->dg, Abuf, e->d_B, n_mtile,
+                           e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
-        if (evc) RA_HIP(hipEventRecord(evc->second, e->stream));
-        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, e->d_cand, e->nrtile,
+        if (evc) RA_HIP(hipEventRecord(evc->second, sc));
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sc, e->dg, Cbuf, e->nrtile,
                            cn, st, d_result + start, e->d_cs);
         RA_HIP(hipGetLastError());
+        if (ov) RA_HIP(hipEventRecord(e->ev_ccf_done[b], sc));
+    }
+    if (ov) {   // join: later work on the engine's stream sees every chunk finished
+        RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[0], 0));
+        if (ci >= 2) RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[1], 0));
     }
     (void)ngroup;
     return RA_OK;
