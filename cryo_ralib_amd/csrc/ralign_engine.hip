@@ -56,7 +56,9 @@ struct ra_engine {
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
-    size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
+    size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0, lds_fused = 0;
+    float *d_Bf = nullptr;              // [f_nchunk][f_bchunk] unit-major reference stream of the fused kernel
+    bool fused = false;                 // RALIGN_FUSED=1: particle-resident single-kernel search
     bool refs_ready = false;
     // kernel timing
     bool timing = false;
@@ -144,7 +146,8 @@ static int build_device_geometry(ra_engine *e)
     std::vector<float> ringw(g.nring);
     std::vector<int4> inst;
     std::vector<float> instw;
-    std::vector<int4> jobs;
+    std::vector<int4> jobs, f_jobs, f_inst;
+    std::vector<float> f_instw;
     {
         std::vector<int> qoff(32, -1);
         const double qpi = 2 * atan(1.0);
@@ -163,30 +166,107 @@ static int build_device_geometry(ra_engine *e)
             ringw[i] = (float)(g.numr[3 * i] * 2 * M_PI / (float)n);
         }
         auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
-        const int lanes_of[6] = {16, 8, 8, 4, 4, 4};
-        for (int lg = 8; lg >= 3; lg--) {
-            const int n = 1 << lg, code = code_of(n);
-            std::vector<int4> cls;
-            std::vector<float> clsw;
-            for (int sft = 0; sft < 4; sft++)
-                for (int i = 0; i < g.nring; i++)
-                    if (g.numr[3 * i + 2] == n) {
-                        cls.push_back(make_int4(sft | (i << 8), g.ring_off[i], qoff[lg], g.numr[3 * i]));
-                        clsw.push_back(ringw[i]);
-                    }
-            const int per_job = 64 / lanes_of[code];
-            for (size_t b = 0; b < cls.size(); b += per_job) {
-                const int cnt = (int)std::min<size_t>(per_job, cls.size() - b);
-                jobs.push_back(make_int4(code, (int)inst.size(), cnt, 0));
-                for (int c = 0; c < cnt; c++) { inst.push_back(cls[b + c]); instw.push_back(clsw[b + c]); }
-            }
-        }
         for (int i = 0; i < g.nring; i++)
             if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
+        auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
+            const int lanes_of[6] = {16, 8, 8, 4, 4, 4};
+            for (int lg = 8; lg >= 3; lg--) {
+                const int n = 1 << lg, code = code_of(n);
+                std::vector<int4> cls;
+                std::vector<float> clsw;
+                for (int sft = 0; sft < nslot; sft++)
+                    for (int i = 0; i < g.nring; i++)
+                        if (g.numr[3 * i + 2] == n) {
+                            cls.push_back(make_int4(sft | (i << 8), g.ring_off[i], qoff[lg], g.numr[3 * i]));
+                            clsw.push_back(ringw[i]);
+                        }
+                const int per_job = 64 / lanes_of[code];
+                for (size_t b = 0; b < cls.size(); b += per_job) {
+                    const int cnt = (int)std::min<size_t>(per_job, cls.size() - b);
+                    J.push_back(make_int4(code, (int)I.size(), cnt, 0));
+                    for (int c = 0; c < cnt; c++) { I.push_back(cls[b + c]); W.push_back(clsw[b + c]); }
+                }
+            }
+        };
+        make_jobs(4, jobs, inst, instw);
+        make_jobs(2, f_jobs, f_inst, f_instw);
     }
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
+
+    // ---- fused (particle-resident) kernel plan
+    std::vector<int> f_goff, f_aoff, f_uoff, f_bsrc;
+    std::vector<int4> f_units;
+    {
+        const int NWV = RA_POLAR_THREADS / 64;
+        d.f_sbuf = (g.lring + 32 + 31) / 32 * 32 + 16;   // == 16 (mod 32): the two offset slots use disjoint banks; >= 32 floats of slack
+        d.f_n_job = (int)f_jobs.size(); d.f_n_inst = (int)f_inst.size();
+        d.f_ng = (g.nbins + 15) / 16;
+        f_goff.assign(d.f_ng + 1, 0);
+        std::vector<int> gfirst(d.f_ng);
+        for (int gi = 0; gi < d.f_ng; gi++) {
+            int i0 = 0;
+            while (i0 < g.nring && g.numr[3 * i0 + 2] / 2 < 16 * gi) i0++;
+            gfirst[gi] = i0;
+            f_goff[gi + 1] = f_goff[gi] + (g.nring - i0);
+        }
+        d.f_nstep = f_goff[d.f_ng];
+        f_aoff.resize(d.f_nstep);
+        for (int gi = 0; gi < d.f_ng; gi++)
+            for (int st = 0; st < f_goff[gi + 1] - f_goff[gi]; st++) f_aoff[f_goff[gi] + st] = g.ring_off[gfirst[gi] + st] + 32 * gi;
+        const int base = 2 * (g.maxrin + g.maxrin / 16);
+        d.f_ps = base + ((8 - base % 64) + 64) % 64;
+        // references per chunk: the CCF spectra of 2 offsets x rc references must fit beside image and ring buffers
+        auto lds_floats = [&](int rc) {
+            return ((d.pst * d.pst + 3) & ~3) + 2 * d.f_sbuf + 2 * rc * d.f_ps + 2 * g.maxrin + 2 * (int)qtab.size() + 2 +
+                   4 * d.f_n_inst + 4 * d.f_n_job + 8 * rc + d.f_n_inst + d.f_nstep + 32 + 8 * g.nring;
+        };
+        int rc = std::min(16, (e->cfg.nref + 1) & ~1);
+        while (rc > 2 && (size_t)lds_floats(rc) * 4 > 160 * 1024) rc -= 2;
+        d.f_on = ((size_t)lds_floats(rc) * 4 <= 160 * 1024) ? 1 : 0;
+        d.f_nchunk = (e->cfg.nref + rc - 1) / rc;
+        rc = std::min(rc, (((e->cfg.nref + d.f_nchunk - 1) / d.f_nchunk) + 1) & ~1);
+        d.f_rc = rc;
+        e->lds_fused = (size_t)lds_floats(rc) * 4;
+        // units (16-bin group, reference pair), longest first onto the least loaded wave
+        const int nrp = rc / 2;
+        struct U { int gi, rp, w, bbase; };
+        std::vector<U> us;
+        int bb = 0;
+        for (int gi = 0; gi < d.f_ng; gi++)
+            for (int rp = 0; rp < nrp; rp++) {
+                const int wgt = f_goff[gi + 1] - f_goff[gi];
+                us.push_back({gi, rp, wgt, bb});
+                bb += wgt * 64;
+            }
+        d.f_bchunk = bb; d.f_nunit = (int)us.size();
+        std::vector<U> sorted(us);
+        std::stable_sort(sorted.begin(), sorted.end(), [](const U &a, const U &b) { return a.w > b.w; });
+        std::vector<std::vector<U>> per(NWV);
+        std::vector<int> load(NWV, 0);
+        for (auto &u : sorted) {
+            int wv = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            per[wv].push_back(u); load[wv] += u.w + 6;      // + ~6 steps of epilogue per unit
+        }
+        f_uoff.assign(NWV + 1, 0);
+        for (int wv = 0; wv < NWV; wv++) {
+            for (auto &u : per[wv]) f_units.push_back(make_int4(u.gi, u.rp, u.bbase, 0));
+            f_uoff[wv + 1] = (int)f_units.size();
+        }
+        // B stream source table
+        f_bsrc.assign(d.f_bchunk, -1);
+        for (auto &u : us)
+            for (int st = 0; st < u.w; st++) {
+                const int ring = gfirst[u.gi] + st, nlen = g.numr[3 * ring + 2];
+                for (int ln = 0; ln < 64; ln++) {
+                    const int k = 16 * u.gi + (ln >> 2), j = ln & 3;
+                    if (k > nlen / 2 || k >= g.nbins) continue;
+                    const int en = g.bin_off[k] + (ring - g.bin_first[k]);
+                    f_bsrc[u.bbase + st * 64 + ln] = (en << 5) | ((2 * u.rp + (j >> 1)) << 1) | (j & 1);
+                }
+            }
+    }
 
     std::vector<float2> tw(g.maxrin);
     for (int k = 0; k < g.maxrin; k++) {
@@ -236,6 +316,14 @@ static int build_device_geometry(ra_engine *e)
     if ((rc = upload(e, jobs, &d.jobs))) return rc;
     if ((rc = upload(e, inst, &d.inst))) return rc;
     if ((rc = upload(e, instw, &d.instw))) return rc;
+    if ((rc = upload(e, f_jobs, &d.f_jobs))) return rc;
+    if ((rc = upload(e, f_inst, &d.f_inst))) return rc;
+    if ((rc = upload(e, f_instw, &d.f_instw))) return rc;
+    if ((rc = upload(e, f_goff, &d.f_goff))) return rc;
+    if ((rc = upload(e, f_aoff, &d.f_aoff))) return rc;
+    if ((rc = upload(e, f_units, &d.f_units))) return rc;
+    if ((rc = upload(e, f_uoff, &d.f_uoff))) return rc;
+    if ((rc = upload(e, f_bsrc, &d.f_bsrc))) return rc;
     if ((rc = upload(e, qtab, &d.qtab))) return rc;
     if ((rc = upload(e, ringinfo, &d.ringinfo))) return rc;
     if ((rc = upload(e, ringw, &d.ringw))) return rc;
@@ -266,6 +354,18 @@ static ccf_fn select_ccf(int maxrin)
     case 128: return ccf_kernel<128>;
     case 64: return ccf_kernel<64>;
     case 32: return ccf_kernel<32>;
+    default: return nullptr;
+    }
+}
+
+typedef void (*fused_fn)(DevGeom, const float *, float *, int, const float *, ra_result *, int);
+static fused_fn select_fused(int maxrin)
+{
+    switch (maxrin) {
+    case 256: return align_fused_kernel<256>;
+    case 128: return align_fused_kernel<128>;
+    case 64: return align_fused_kernel<64>;
+    case 32: return align_fused_kernel<32>;
     default: return nullptr;
     }
 }
@@ -327,6 +427,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
+    if (he == hipSuccess && e->dg.f_on) he = hipFuncSetAttribute((const void *)select_fused(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_fused);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
 
@@ -346,6 +447,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         return rc;
     }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
+    e->fused = e->dg.f_on && getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) != 0;
+    if (e->dg.f_on && (rc = dev_alloc(e, &e->d_Bf, (size_t)e->dg.f_nchunk * e->dg.f_bchunk, true))) { ra_destroy(e); return rc; }
     e->overlap = getenv("RALIGN_OVERLAP") && atoi(getenv("RALIGN_OVERLAP")) != 0;
     if (e->overlap && ((rc = dev_alloc(e, &e->d_A2, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
                        (rc = dev_alloc(e, &e->d_cand2, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)))) {
@@ -431,6 +534,12 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
                        e->cfg.nref, e->nrtile, e->d_B);
     RA_HIP(hipGetLastError());
+    if (e->dg.f_on) {
+        const int totalf = e->dg.f_nchunk * e->dg.f_bchunk;
+        hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(4096, (totalf + 255) / 256)), dim3(256), 0, e->stream, e->dg,
+                           e->d_refspec, e->cfg.nref, e->d_Bf);
+        RA_HIP(hipGetLastError());
+    }
     e->refs_ready = true;
     return RA_OK;
 }
@@ -489,6 +598,22 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipMemcpyAsync(e->d_cs, cs, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(apply_cs_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_cs, d_result, d_state);
         RA_HIP(hipGetLastError());
+    }
+    if (e->fused) {
+        // particle-resident search: one kernel, no spectra workspace; still launched per chunk so that
+        // one launch stays a bounded unit of work for timing
+        fused_fn fk = select_fused(g.maxrin);
+        for (int start = 0; start < n; start += e->chunk) {
+            const int cn = std::min(e->chunk, n - start);
+            std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
+            if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
+            hipLaunchKernelGGL(fk, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_fused, e->stream, e->dg,
+                               d_particles + (size_t)start * npix, d_state + (size_t)start * 2, cn, e->d_Bf, d_result + start,
+                               e->cfg.nref);
+            RA_HIP(hipGetLastError());
+            if (evc) RA_HIP(hipEventRecord(evc->second, e->stream));
+        }
+        return RA_OK;
     }
     const bool ov = e->overlap && n > e->chunk;
     hipStream_t sp = e->stream, sc = ov ? e->s_aux : e->stream;

@@ -64,6 +64,16 @@ struct DevGeom {
     const float2 *qtab;           // first-quadrant (sinf, cosf) of alrl_ms per ring length
     const int4 *ringinfo;         // per ring {ring_off, radius, length, qtab offset}
     const float *ringw;           // per ring Normalize_ring weight r*2pi/n
+    // fused (particle-resident) kernel: 2 search offsets per pass, spectra never leave the CU
+    int f_on, f_sbuf, f_n_job, f_n_inst;
+    int f_ng, f_rc, f_nchunk, f_ps, f_nstep, f_bchunk, f_nunit;
+    const int4 *f_jobs, *f_inst;
+    const float *f_instw;
+    const int *f_goff;            // [f_ng+1] prefix of ring steps per 16-bin group
+    const int *f_aoff;            // [f_nstep] LDS float offset (ring_off + 32 g) of every (group, ring) step
+    const int4 *f_units;          // per-wave unit lists {group, ref pair, B float offset, 0}
+    const int *f_uoff;            // [17] unit range of every wave
+    const int *f_bsrc;            // [f_bchunk] (entry << 5 | ref in chunk << 1 | comp) of every B float, -1 = 0
 };
 
 // ------------------------------------------------------------------------------------------
@@ -260,7 +270,7 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
 template <int R1, int LR>
 __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                          const float2 *qt_s, const float *ctr, float *red, const int4 *inst_s,
-                                         const float *instw_s, int inst0, int count, int zero)
+                                         const float *instw_s, int inst0, int count, int zero, int sbuf)
 {
     // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
     // inside the job instead of hoisted out of the pass loop for all six variants (VGPR spills)
@@ -271,7 +281,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (sub >= count) return;
     const int4 in = inst_s[inst0 + sub];
     const int slot = in.x & 255, ring = in.x >> 8;
-    float *buf = bufs + slot * g.sbuf + in.y;
+    float *buf = bufs + slot * sbuf + in.y;
     const float rad = (float)in.w, wt = instw_s[inst0 + sub];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
     const float2 *qt = qt_s + in.z;
@@ -398,12 +408,12 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             for (int job = wave; job < g.n_job; job += nwave) {
                 const int4 jd = jobs_s[job];
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
-                case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
-                case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
-                case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
-                case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
-                default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w); break;
+                case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 }
             }
         }
@@ -633,14 +643,14 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
     }
 }
 
-// phase 2 of ccf_kernel for NP pairs handled by the same 16-lane group: N-point complex inverse
-// FFT (radix R1 x R2 through the LDS image), argmax of real (q) and imaginary (t) parts with the
-// ">=" / last-index rule, prb1d on the 7-point neighbourhood of the winner.
-template <int N, int NP>
-__device__ __forceinline__ void ifft_argmax(float *Z, Cand *pc, const float2 *twl, int pairA, int pairB, int j, int rtile)
+// phase 2 for NP pairs handled by the same 16-lane group: N-point complex inverse FFT (radix
+// R1 x R2 through the LDS image laid out by ZL), argmax of real (q) and imaginary (t) parts with
+// the ">=" / last-index rule, prb1d on the 7-point neighbourhood of the winner.  Lanes j < NP
+// return the record of pair j in `out` (refmir holds the mirror bit only).
+template <class ZL, int N, int NP>
+__device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, int pairA, int pairB, int j, Cand &out)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
-    typedef ZLayout<N> ZL;
     const int pr[2] = {pairA, pairB};
     float2 v[NP][16];
     if (j < R2) {
@@ -718,11 +728,21 @@ __device__ __forceinline__ void ifft_argmax(float *Z, Cand *pc, const float2 *tw
         double c3 = 5. * t7[0] - 3. * t7[2] - 4. * t7[3] - 3. * t7[4] + 5. * t7[6];
         float pos = 0.f;
         if (c3 != 0.0) pos = (float)(c2 / (2.0 * c3) - 4);
-        Cand c;
-        c.val = mir ? mt : mq;
-        c.jtot = jt + 1;
-        c.tot = (float)(jt + 1) + pos;
-        c.refmir = (rtile * 8 + (pair & 7)) | ((mir ? 1 : 0) << 16);
+        out.val = mir ? mt : mq;
+        out.jtot = jt + 1;
+        out.tot = (float)(jt + 1) + pos;
+        out.refmir = (mir ? 1 : 0) << 16;
+    }
+}
+
+template <int N, int NP>
+__device__ __forceinline__ void ifft_argmax(float *Z, Cand *pc, const float2 *twl, int pairA, int pairB, int j, int rtile)
+{
+    Cand c;
+    ifft_argmax_core<ZLayout<N>, N, NP>(Z, twl, pairA, pairB, j, c);
+    if (j < NP) {
+        const int pair = (j == 0) ? pairA : pairB;
+        c.refmir |= rtile * 8 + (pair & 7);
         pc[pair] = c;
     }
 }
@@ -814,6 +834,250 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
     }
     __syncthreads();
     }   // rtile
+}
+
+// ------------------------------------------------------------------------------------------
+// K-fused: the whole search of one particle inside one workgroup (16 waves); the particle
+// spectra never leave the CU.  Per pass of 2 search offsets:
+//   P1  wave-jobs: polar sampling + ring FFT of both offsets into two LDS ring buffers
+//       (ring_job, as in polar_fft_kernel), Normalize_ring statistics, DC correction;
+//   P2  CCF contraction on `v_mfma_f32_4x4x1_16b_f32`: one MFMA = 16 Fourier bins x
+//       [4 rows = 2 offsets x (Re,Im) D] x [4 cols = 2 references x (Re,Im) C] for one ring;
+//       A operand straight from the LDS ring buffers, B operand (prepared references, unit-major)
+//       streamed from L2; units (16-bin group, reference pair) are spread over the waves;
+//   P3  one N-point complex inverse FFT per (offset, reference) pair + wavefront argmax;
+//   P4  wave 0 folds the pass into the particle's running best with EMAN2's order
+//       (offsets y-outer/x-inner, references ascending, ">=": later wins).
+// References are processed in chunks of f_rc so that the CCF spectra of a pass fit LDS.
+struct __attribute__((aligned(8))) FusedBest { float val, tot; int jtot, mirror, ref, sidx; };
+
+template <int N> struct ZLayoutF {
+    // pair stride == 8 (mod 64) dwords: the 4 pairs x 4 bins of a ds_write_b64 group and the
+    // partner pairs (p, p+4) of a half-wave in the FFT passes are bank-conflict free
+    static constexpr int kBase = 2 * (N + N / 16);
+    static constexpr int kPairStride = kBase + ((8 - kBase % 64) + 64) % 64;
+    static __device__ __forceinline__ int addr(int pair, int slot) { return pair * kPairStride + 2 * (slot + (slot >> 4)); }
+};
+
+template <int N>
+__global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g, const float *__restrict__ particles,
+                                                                       float *__restrict__ state, int n,
+                                                                       const float *__restrict__ Bf,
+                                                                       ra_result *__restrict__ res, int nref)
+{
+    typedef ZLayoutF<N> ZL;
+    extern __shared__ __align__(16) float lds[];
+    const int npad = g.pst * g.pst;
+    float *img = lds;
+    float *bufs = lds + ((npad + 3) & ~3);                              // [2][f_sbuf]
+    float *Z = bufs + 2 * g.f_sbuf;                                     // [2*f_rc][kPairStride]
+    float2 *tw_s = reinterpret_cast<float2 *>(Z + 2 * g.f_rc * ZL::kPairStride);   // [maxrin]
+    float2 *qt_s = tw_s + g.maxrin;                                     // [n_qtab]
+    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));
+    int4 *jobs_s = inst_s + g.f_n_inst;
+    Cand *pc = reinterpret_cast<Cand *>(jobs_s + g.f_n_job);            // [2*f_rc]
+    float *instw_s = reinterpret_cast<float *>(pc + 2 * g.f_rc);
+    int *aoff_s = reinterpret_cast<int *>(instw_s + g.f_n_inst);        // [f_nstep]
+    float *red = reinterpret_cast<float *>(aoff_s + g.f_nstep);         // as in polar_fft_kernel
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6;
+    if (p >= n) return;
+
+    const float *src = particles + (size_t)p * g.nx * g.nx;
+    for (int i = tid; i < npad; i += blockDim.x) {
+        const int y = i / g.pst - g.bd, x = i % g.pst - g.bd;
+        img[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.nx) ? src[y * g.nx + x] : 0.f;
+    }
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    for (int i = tid; i < g.maxrin; i += blockDim.x) tw_s[i] = g.tw[i];
+    for (int i = tid; i < g.n_qtab; i += blockDim.x) qt_s[i] = g.qtab[i];
+    for (int i = tid; i < g.f_n_inst; i += blockDim.x) { inst_s[i] = g.f_inst[i]; instw_s[i] = g.f_instw[i]; }
+    for (int i = tid; i < g.f_n_job; i += blockDim.x) jobs_s[i] = g.f_jobs[i];
+    for (int i = tid; i < g.f_nstep; i += blockDim.x) aoff_s[i] = g.f_aoff[i];
+    for (int i = tid; i < 2 * g.f_sbuf; i += blockDim.x) bufs[i] = 0.f;   // the slack behind the last ring stays zero
+    const float sx0 = state[2 * p], sy0 = state[2 * p + 1];
+    const Window w = particle_window(g, sx0, sy0);
+    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
+    const int nx1 = 2 * g.nkx + 1;
+
+    FusedBest best; best.val = -1.0e23f; best.tot = 1.f; best.jtot = 1; best.mirror = 0; best.ref = 0; best.sidx = 0;
+    int best_order = -1;
+
+    const int npass = (g.nshift + 1) / 2;
+    for (int pass = 0; pass < npass; pass++) {
+        if (tid < 2) {
+            const int si = min(pass * 2 + tid, g.nshift - 1);
+            red[16 + 2 * tid] = cxf + g.shift_x[si];
+            red[17 + 2 * tid] = cyf + g.shift_y[si];
+        }
+        __syncthreads();
+        // ---- P1: polar sampling + ring FFT of the two offsets
+#pragma unroll 1
+        for (int job = wave; job < g.f_n_job; job += nwave) {
+            const int4 jd = jobs_s[job];
+            switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+            case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
+            }
+        }
+        __syncthreads();
+        if (wave < 2) {      // Normalize_ring statistics of offset slot `wave` (fixed butterfly: reproducible)
+            float a = 0.f, q = 0.f;
+            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
+            a = wave_sum(a); q = wave_sum(q);
+            if (lane == 0) {
+                float avg = 0.f, rsg = 1.f;
+                if (g.mode == RA_MODE_MREF) {
+                    const float nn = g.nn_weight;
+                    avg = a / nn;
+                    rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+                }
+                red[8 + wave] = avg; red[12 + wave] = rsg;
+            }
+        }
+        __syncthreads();
+        if (g.mode == RA_MODE_MREF && tid < 2 * g.nring) {
+            const int s = tid / g.nring, i = tid - s * g.nring;
+            const int4 ri = g.ringinfo[i];
+            bufs[s * g.f_sbuf + ri.x] -= red[8 + s] * (float)ri.z;
+        }
+        __syncthreads();
+
+        for (int chunk = 0; chunk < g.f_nchunk; chunk++) {
+            const int rc_live = min(g.f_rc, nref - chunk * g.f_rc);
+            // ---- P2: contraction, units (16-bin group, reference pair) of this wave
+            {
+                const int blk = lane >> 2, irow = lane & 3, odd = lane & 1;
+                const float rs = red[12 + (irow >> 1)];
+                const float *abase = bufs + (irow >> 1) * g.f_sbuf + 2 * blk + (irow & 1);
+                const float *bchunk = Bf + (size_t)chunk * g.f_bchunk + lane;
+                const int u1 = g.f_uoff[wave + 1];
+#pragma unroll 1
+                for (int u = g.f_uoff[wave]; u < u1; u++) {
+                    const int4 ud = g.f_units[u];
+                    const int grp = ud.x, rp = ud.y;
+                    const int st0 = g.f_goff[grp], nst = g.f_goff[grp + 1] - st0;
+                    const float *bp = bchunk + ud.z;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    int st = 0;
+                    for (; st + 4 <= nst; st += 4) {
+                        const int o0 = aoff_s[st0 + st], o1 = aoff_s[st0 + st + 1], o2 = aoff_s[st0 + st + 2], o3 = aoff_s[st0 + st + 3];
+                        const float b0 = bp[(st) * 64], b1 = bp[(st + 1) * 64], b2 = bp[(st + 2) * 64], b3 = bp[(st + 3) * 64];
+                        const float a0 = abase[o0] * rs, a1 = abase[o1] * rs, a2 = abase[o2] * rs, a3 = abase[o3] * rs;
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, b2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, b3, acc, 0, 0, 0);
+                    }
+                    for (; st < nst; st++) {
+                        const float a0 = abase[aoff_s[st0 + st]] * rs, b0 = bp[st * 64];
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc, 0, 0, 0);
+                    }
+                    // acc[i], i = (offset slot, Re/Im D); lane = 4*bin + (ref in pair, Re/Im C).
+                    // 2x2 block exchange between the Re/Im column lanes of one reference:
+                    float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
+                    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
+                    float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
+                    float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                    const int k = 16 * grp + blk;
+                    const int pair = (2 * rp + ((lane & 3) >> 1)) * 2 + odd;     // (ref in chunk) * 2 + offset slot
+                    if (k <= N / 2) {
+                        *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
+                        *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- P3: inverse FFT + argmax; a wave takes 4 pairs {b, b+4, b+1, b+5} of an 8-block
+            {
+                const int j = lane & 15, sub = lane >> 4;
+                float2 twl[16];
+#pragma unroll
+                for (int n0 = 0; n0 < 16; n0++) {
+                    float2 t = tw_s[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
+                    twl[n0] = make_float2(t.x, -t.y);
+                }
+                const int nround = 2 * ((2 * rc_live + 7) / 8);
+                for (int r = wave; r < nround; r += nwave) {
+                    const int pair = 8 * (r >> 1) + 2 * (r & 1) + (sub >> 1) + 4 * (sub & 1);
+                    if (pair < 2 * rc_live) {      // uniform over the 16-lane group
+                        Cand c;
+                        ifft_argmax_core<ZL, N, 1>(Z, twl, pair, pair, j, c);
+                        if (j == 0) { c.refmir |= chunk * g.f_rc + (pair >> 1); pc[pair] = c; }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- P4: fold the pass into the running best (wave 0; key = (value, EMAN2 visiting order))
+            if (wave == 0) {
+                float v = -3.0e38f, tot = 0.f; int jt = 0, rm = 0, order = -1, sidx = 0;
+                if (lane < 2 * rc_live) {
+                    sidx = pass * 2 + (lane & 1);
+                    const int iy = sidx / nx1 - g.nky, ix = sidx % nx1 - g.nkx;
+                    const bool ok = sidx < g.nshift && ix >= -w.lkx && ix <= w.rkx && iy >= -w.lky && iy <= w.rky;
+                    if (ok) {
+                        const Cand c = pc[lane];
+                        v = c.val; tot = c.tot; jt = c.jtot; rm = c.refmir;
+                        order = sidx * nref + (rm & 0xffff);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(v, o), ot = __shfl_xor(tot, o);
+                    const int oj = __shfl_xor(jt, o), orm = __shfl_xor(rm, o), oo = __shfl_xor(order, o), os = __shfl_xor(sidx, o);
+                    if (oo >= 0 && (order < 0 || ov > v || (ov == v && oo > order))) { v = ov; tot = ot; jt = oj; rm = orm; order = oo; sidx = os; }
+                }
+                if (order >= 0 && (best_order < 0 || v > best.val || (v == best.val && order > best_order))) {
+                    best.val = v; best.tot = tot; best.jtot = jt; best.mirror = rm >> 16; best.ref = rm & 0xffff; best.sidx = sidx;
+                    best_order = order;
+                }
+            }
+        }
+    }
+    // ---- parameters (ang_n, ormq tail, combine_params2), as finalize_kernel
+    if (tid == 0) {
+        const float ang = fmodf(((best.tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
+        const float ixw = g.shift_x[best.sidx], iyw = g.shift_y[best.sidx];
+        const float sx = -ixw, sy = -iyw;
+        const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
+        const float sxs = sx * co - sy * so, sys = sx * so + sy * co;
+        const double a = (double)ang * M_PI / 180.0, c = cos(a), s = sin(a);
+        const double tx = c * (double)(-w.sxi) + s * (double)(-w.syi) + (double)sxs;
+        const double ty = -s * (double)(-w.sxi) + c * (double)(-w.syi) + (double)sys;
+        double alpha = atan2(s, c) * 180.0 / M_PI;
+        alpha = fmod(alpha, 360.0);
+        if (alpha < 0) alpha += 360.0;
+        if (alpha >= 360.0) alpha -= 360.0;
+        ra_result r;
+        r.alpha = (float)alpha; r.sx = (float)tx; r.sy = (float)ty;
+        r.mirror = best.mirror; r.ref_id = best.ref; r.peak = best.val; r.angle_bin = best.jtot; r.shift_idx = best.sidx;
+        res[p] = r;
+        state[2 * p] = w.sxi + ixw;
+        state[2 * p + 1] = w.syi + iyw;
+    }
+}
+
+// prepared references -> unit-major B stream of the fused kernel (Applyws weights and 1/maxrin folded in)
+__global__ void pack_refs_fused_kernel(DevGeom g, const float *__restrict__ refspec, int nref, float *__restrict__ Bf)
+{
+    const int total = g.f_nchunk * g.f_bchunk;
+    const float inv = 1.0f / (float)g.maxrin;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int ch = idx / g.f_bchunk, f = idx - ch * g.f_bchunk;
+        const int code = g.f_bsrc[f];
+        float v = 0.f;
+        if (code >= 0) {
+            const int e = code >> 5, ref = ch * g.f_rc + ((code >> 1) & 15);
+            if (((code >> 1) & 15) < g.f_rc && ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (code & 1)] * g.ent_wgt[e] * inv;
+        }
+        Bf[idx] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
