@@ -896,6 +896,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
     for (int i = tid; i < g.f_n_job; i += blockDim.x) jobs_s[i] = g.f_jobs[i];
     for (int i = tid; i < g.f_nstep; i += blockDim.x) aoff_s[i] = g.f_aoff[i];
     for (int i = tid; i < 2 * g.f_sbuf; i += blockDim.x) bufs[i] = 0.f;   // the slack behind the last ring stays zero
+    if (tid == 0) red[22] = 0.f;      // a runtime zero: per-phase lane arithmetic derived from it cannot be hoisted out of the pass loop
     const float sx0 = state[2 * p], sy0 = state[2 * p + 1];
     const Window w = particle_window(g, sx0, sy0);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
@@ -913,6 +914,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
         }
         __syncthreads();
         // ---- P1: polar sampling + ring FFT of the two offsets
+        if (!(g.dbg & 1024))
 #pragma unroll 1
         for (int job = wave; job < g.f_n_job; job += nwave) {
             const int4 jd = jobs_s[job];
@@ -951,11 +953,12 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
         for (int chunk = 0; chunk < g.f_nchunk; chunk++) {
             const int rc_live = min(g.f_rc, nref - chunk * g.f_rc);
             // ---- P2: contraction, units (16-bin group, reference pair) of this wave
-            {
-                const int blk = lane >> 2, irow = lane & 3, odd = lane & 1;
+            if (!(g.dbg & 2048)) {
+                const int ln = lane + __float_as_int(red[22]);
+                const int blk = ln >> 2, irow = ln & 3, odd = ln & 1;
                 const float rs = red[12 + (irow >> 1)];
                 const float *abase = bufs + (irow >> 1) * g.f_sbuf + 2 * blk + (irow & 1);
-                const float *bchunk = Bf + (size_t)chunk * g.f_bchunk + lane;
+                const float *bchunk = Bf + (size_t)chunk * g.f_bchunk + ln;
                 const int u1 = g.f_uoff[wave + 1];
 #pragma unroll 1
                 for (int u = g.f_uoff[wave]; u < u1; u++) {
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
                     float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
                     float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                     const int k = 16 * grp + blk;
-                    const int pair = (2 * rp + ((lane & 3) >> 1)) * 2 + odd;     // (ref in chunk) * 2 + offset slot
+                    const int pair = (2 * rp + ((ln & 3) >> 1)) * 2 + odd;     // (ref in chunk) * 2 + offset slot
                     if (k <= N / 2) {
                         *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
                         *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
@@ -995,8 +998,9 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
             }
             __syncthreads();
             // ---- P3: inverse FFT + argmax; a wave takes 4 pairs {b, b+4, b+1, b+5} of an 8-block
-            {
-                const int j = lane & 15, sub = lane >> 4;
+            if (!(g.dbg & 4096)) {
+                const int ln = lane + __float_as_int(red[22]);
+                const int j = ln & 15, sub = ln >> 4;
                 float2 twl[16];
 #pragma unroll
                 for (int n0 = 0; n0 < 16; n0++) {
