@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libralign_hip.so")
+LIB_PATH = os.environ.get("RALIGN_LIB") or os.path.join(_HERE, "libralign_hip.so")   # RALIGN_LIB: another build of the same library (kernel experiments)
 
 RA_MODE_MREF = 0
 RA_MODE_REFFREE = 1

@@ -41,11 +41,11 @@ struct ra_engine {
     int nrtile = 1;
     std::vector<void *> owned;          // device allocations freed at destroy
     float *d_A = nullptr;               // [chunk * ngroup + 2][a_blk]
-    Cand *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
+    CandT *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
     // second workspace + auxiliary stream: the polar kernel of chunk i+1 (VALU/LDS-bound) runs
     // beside the contraction kernel of chunk i (HBM-bound) instead of behind it
     float *d_A2 = nullptr;
-    Cand *d_cand2 = nullptr;
+    CandT *d_cand2 = nullptr;
     hipStream_t s_aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_polar_done[2] = {nullptr, nullptr}, ev_ccf_done[2] = {nullptr, nullptr};
     bool overlap = false;               // RALIGN_OVERLAP=1 (measured: no net gain on MI355X)
@@ -116,6 +116,28 @@ static int build_device_geometry(ra_engine *e)
         }
     }
     d.class_k0_end = g.nbins;
+    {   // start wave of every class: greedy choice that keeps the per-wave MFMA count level
+        const int NWV = RA_CCF_THREADS / 64;
+        std::vector<long> load(NWV, 0);
+        for (int c = 0; c < d.n_class; c++) {
+            const int nb = ((c + 1 < d.n_class) ? d.class_k0[c + 1] : g.nbins) - d.class_k0[c], w = d.class_ns[c] + 3;
+            int best_r = 0; long best_max = -1, best_sq = 0;
+            for (int r = 0; r < NWV; r++) {
+                long mx = 0, sq = 0;
+                for (int wv = 0; wv < NWV; wv++) {
+                    const int first = (wv - r + NWV) % NWV;                 // index of this wave's first bin in the class
+                    const long t = load[wv] + (first < nb ? (long)((nb - first + NWV - 1) / NWV) * w : 0);
+                    mx = std::max(mx, t); sq += t * t;
+                }
+                if (best_max < 0 || mx < best_max || (mx == best_max && sq < best_sq)) { best_max = mx; best_sq = sq; best_r = r; }
+            }
+            d.class_rot[c] = best_r;
+            for (int wv = 0; wv < NWV; wv++) {
+                const int first = (wv - best_r + NWV) % NWV;
+                if (first < nb) load[wv] += (long)((nb - first + NWV - 1) / NWV) * w;
+            }
+        }
+    }
     build_operand_tables(g, sbuf);
 
     // FFT work lists
@@ -346,7 +368,7 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
 
 extern "C" const char *ra_last_error(void) { return g_last_error.c_str(); }
 
-typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, Cand *);
+typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, CandT *);
 static ccf_fn select_ccf(int maxrin)
 {
     switch (maxrin) {
@@ -404,11 +426,13 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         delete e;
         return RA_ERR_ARG;
     }
+    e->nrtile = (cfg->nref + 7) / 8;
+    e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
+    if (getenv("RALIGN_RPT8")) e->dg.rpt = 8;
     int rc = build_device_geometry(e);
     if (rc) { ra_destroy(e); return rc; }
 
     e->shift_cap = e->geo.nshift; e->pad_cap = e->geo.nshift_pad;
-    e->nrtile = (cfg->nref + 7) / 8;
     const Geometry &g = e->geo;
     const int npix_pad = (g.nx * g.nx + 3) & ~3;
     e->lds_polar = (size_t)(((e->dg.pst * e->dg.pst + 3) & ~3) + 4 * e->dg.sbuf + 2 * g.maxrin + 2 * e->dg.n_qtab + 2 + 5 * e->dg.n_inst +
@@ -626,7 +650,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         const int cn = std::min(e->chunk, n - start);
         const int b = ov ? (ci & 1) : 0;
         float *Abuf = b ? e->d_A2 : e->d_A;
-        Cand *Cbuf = b ? e->d_cand2 : e->d_cand;
+        CandT *Cbuf = b ? e->d_cand2 : e->d_cand;
         const float *part = d_particles + (size_t)start * npix;
         float *st = d_state + (size_t)start * 2;
         std::pair<hipEvent_t, hipEvent_t> *evp = nullptr, *evc = nullptr;
@@ -806,7 +830,7 @@ size_t legacy_bytes(unsigned num_particles, const AlignConfig *c)
         return (size_t)-1;
     size_t npix = (size_t)c->img_dim * c->img_dim;
     size_t chunk = std::min<size_t>(8192, (c->sbj_num + 1) & ~1u);
-    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * ((size_t)g.LBP * 8 + 64) * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * 16;
+    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * ((size_t)g.LBP * 8 + 64) * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * sizeof(CandT);
     size_t imgs = ((size_t)c->sbj_num * 2 + c->ref_num * 3) * npix * 4;
     return ws + imgs + (size_t)num_particles * 64;
 }

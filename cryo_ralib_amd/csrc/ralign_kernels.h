@@ -39,9 +39,11 @@ struct DevGeom {
     int sbuf;                     // LDS stride of one ring buffer (floats)
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
+    int rpt;                      // references per tile of the contraction (<= 8, balanced over the tiles)
     int n_class;                  // bins with the same ring-slot count ns form contiguous classes
     int class_k0[8], class_ns[8]; // class c = bins [class_k0[c], class_k0[c+1]) ; class_k0[n_class] = nbins
     int class_k0_end;
+    int class_rot[8];             // wave that takes the first bin of the class (balances the contraction over the waves)
     const float *samp_dx, *samp_dy, *samp_w;
     const int *samp_dst;
     const int *bin_off, *bin_offp;
@@ -496,8 +498,8 @@ __global__ void pack_refs_kernel(DevGeom g, const float *__restrict__ refspec, i
         const int code = g.b_src[f];
         float v = 0.f;
         if (code >= 0) {
-            const int e = code >> 4, col = code & 15, ref = rt * 8 + (col >> 1);
-            if (ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
+            const int e = code >> 4, col = code & 15, ref = rt * g.rpt + (col >> 1);
+            if ((col >> 1) < g.rpt && ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (col & 1)] * g.ent_wgt[e] * inv;
         }
         B[idx] = v;
     }
@@ -558,6 +560,18 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
 // each MFMA lane owns KP/4 contiguous floats of its row, fetched as 16-B loads one bin ahead);
 // phase 2 transforms 4 pairs per wave and round, 16 lanes per transform.
 struct Cand { float val; float tot; int jtot; int refmir; };   // refmir = ref | mirror << 16
+// record of the two-kernel path: the 7-point neighbourhood of the maximum travels with the candidate
+// and Util::prb1d runs once per particle in finalize_kernel instead of once per pair
+struct CandT { float val; int jtot; int refmir; float t7[7]; };
+
+// Util::prb1d, npoint 7: sub-bin position of the maximum relative to the centre sample
+__device__ __forceinline__ float prb1d7(const float *t)
+{
+    const double t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6];
+    const double c2 = 49. * t0 + 6. * t1 - 21. * t2 - 32. * t3 - 27. * t4 - 6. * t5 + 31. * t6;
+    const double c3 = 5. * t0 - 3. * t2 - 4. * t3 - 3. * t4 + 5. * t6;
+    return (c3 != 0.0) ? (float)(c2 / (2.0 * c3) - 4) : 0.f;
+}
 
 template <int N> struct IfftPlan;
 template <> struct IfftPlan<256> { static constexpr int R1 = 16, R2 = 16; };
@@ -608,6 +622,7 @@ __device__ __forceinline__ void contract_bin(const Operands<NS> &o, float *Z, in
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[s], o.b[s], acc, 0, 0, 0);
+    // (one accumulation chain: the sum over rings stays the exact f32 fma chain the parity tests pin)
     // 2x2 block exchange between the Re/Im column lanes of one reference
     float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
     float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
@@ -624,6 +639,7 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
                                                int odd)
 {
     // panel of bin k in this class starts at (p0_class + (k - kbeg) * 4*NS) entries
+    // (`wave` arrives rotated by the class's start wave)
     int k = kbeg + wave;
     if (k >= kend) return;
     Operands<NS> cur, nxt;
@@ -647,8 +663,8 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
 // R1 x R2 through the LDS image laid out by ZL), argmax of real (q) and imaginary (t) parts with
 // the ">=" / last-index rule, prb1d on the 7-point neighbourhood of the winner.  Lanes j < NP
 // return the record of pair j in `out` (refmir holds the mirror bit only).
-template <class ZL, int N, int NP>
-__device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, int pairA, int pairB, int j, Cand &out)
+template <class ZL, int N, int NP, int TWS, class REC>
+__device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, int pairA, int pairB, int j, REC &out)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     const int pr[2] = {pairA, pairB};
@@ -662,7 +678,7 @@ __device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, in
         for (int q = 0; q < NP; q++) {
             Dft<1, R1>::run(v[q]);
 #pragma unroll
-            for (int n0 = 1; n0 < R1; n0++) v[q][n0] = cmul(v[q][n0], twl[n0]);
+            for (int n0 = 1; n0 < R1; n0++) v[q][n0] = cmul(v[q][n0], twl[n0 * TWS]);   // TWS = 1: registers, else an LDS table
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -717,75 +733,78 @@ __device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, in
         const int pair = (j == 0) ? pr[0] : pr[NP - 1];
         const bool mir = !(mq >= mt);
         const int jt = mir ? mit : miq;
-        double t7[7];
+        float t7[7];
 #pragma unroll
         for (int k = -3; k <= 3; k++) {
             float2 zz = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, (jt + k + N) & (N - 1)));
-            t7[k + 3] = mir ? (double)zz.y : (double)zz.x;
+            t7[k + 3] = mir ? zz.y : zz.x;
         }
-        // Util::prb1d, npoint 7
-        double c2 = 49. * t7[0] + 6. * t7[1] - 21. * t7[2] - 32. * t7[3] - 27. * t7[4] - 6. * t7[5] + 31. * t7[6];
-        double c3 = 5. * t7[0] - 3. * t7[2] - 4. * t7[3] - 3. * t7[4] + 5. * t7[6];
-        float pos = 0.f;
-        if (c3 != 0.0) pos = (float)(c2 / (2.0 * c3) - 4);
         out.val = mir ? mt : mq;
         out.jtot = jt + 1;
-        out.tot = (float)(jt + 1) + pos;
+        if constexpr (sizeof(REC) == sizeof(Cand)) {
+            out.tot = (float)(jt + 1) + prb1d7(t7);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; k++) out.t7[k] = t7[k];
+        }
         out.refmir = (mir ? 1 : 0) << 16;
     }
 }
 
 template <int N, int NP>
-__device__ __forceinline__ void ifft_argmax(float *Z, Cand *pc, const float2 *twl, int pairA, int pairB, int j, int rtile)
+__device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *twl, int pairA, int pairB, int j, int ref0)
 {
-    Cand c;
-    ifft_argmax_core<ZLayout<N>, N, NP>(Z, twl, pairA, pairB, j, c);
+    CandT c;
+    ifft_argmax_core<ZLayout<N>, N, NP, IfftPlan<N>::R2>(Z, twl, pairA, pairB, j, c);
     if (j < NP) {
         const int pair = (j == 0) ? pairA : pairB;
-        c.refmir |= rtile * 8 + (pair & 7);
+        c.refmir |= ref0 + (pair & 7);
         pc[pair] = c;
     }
 }
 
-#define RA_CCF_THREADS 512
+#ifndef RA_CCF_THREADS
+#define RA_CCF_THREADS 1024
+#endif
 #define RA_CCF_MAXNS 12     // KP_k / 4 <= 12 rings per MFMA lane (nring <= 48)
 
 template <int N>
-__global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const float *__restrict__ A,
+__global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) void ccf_kernel(DevGeom g, const float *__restrict__ A,
                                                              const float *__restrict__ B, int n_mtile, int nrtile,
-                                                             int nref, Cand *__restrict__ cand)
+                                                             int nref, CandT *__restrict__ cand)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     typedef ZLayout<N> ZL;
     extern __shared__ __align__(16) float Z[];
-    __shared__ Cand pc[64];
+    __shared__ CandT pc[64];
     const int mtile = blockIdx.x;
     if (mtile >= n_mtile) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = RA_CCF_THREADS / 64;
 
-    // twiddles e^{+2 pi i n0 j / N} of this lane for the first FFT pass (j = lane & 15)
-    float2 twl[16];
-    {
-        const int j = lane & 15;
-#pragma unroll
-        for (int n0 = 0; n0 < 16; n0++) {
-            float2 t = g.tw[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
-            twl[n0] = make_float2(t.x, -t.y);
-        }
+    // twiddles e^{+2 pi i n0 j / N} of the first FFT pass, [n0][j] in LDS (lane j reads column j)
+    __shared__ float2 tws[R1 * R2];
+    for (int i = tid; i < R1 * R2; i += RA_CCF_THREADS) {
+        const float2 t = g.tw[((i / R2) * (i % R2) * (g.maxrin / N)) & (g.maxrin - 1)];
+        tws[i] = make_float2(t.x, -t.y);
     }
+    const float2 *twl = tws + (lane & 15);
 
-    // the reference tiles are swept by the same workgroup so that the second and later sweeps
-    // find this tile's A panels in L2 / Infinity Cache instead of HBM
+    // the reference tiles are swept by the same workgroup: later sweeps find this tile's A panels
+    // in L2 / Infinity Cache instead of HBM
     for (int rtile = 0; rtile < nrtile; rtile++) {
+    const int ref0 = rtile * g.rpt;                       // references [ref0, ref0 + nvalid) of this tile
+    const int nvalid = min(g.rpt, nref - ref0);
     if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
-        Cand c; c.val = 0.f; c.tot = 1.f; c.jtot = 1; c.refmir = min(rtile * 8 + (tid & 7), nref - 1);
+        CandT c; c.val = 0.f; c.jtot = 1; c.refmir = min(ref0 + (tid & 7), nref - 1);
+        for (int k = 0; k < 7; k++) c.t7[k] = 0.f;
         pc[tid] = c;
     }
     // ---- phase 1: contraction, class by class (static shapes inside a class)
     if (!(g.dbg & 2)) {
         const int r16 = lane & 15, kk = lane >> 4;
-        const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
+        const int mt_eff = (g.dbg & 8192) ? (mtile & 63) : mtile;      // profiling: operands from an L2-resident subset
+        const float *Ablk = A + (size_t)(2 * mt_eff + (r16 >> 3)) * g.a_blk;
         const float *Bt = B + (size_t)rtile * g.LBP * 16;
         const int odd = lane & 1;
         const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);
@@ -794,7 +813,7 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
         for (int c = 0; c < g.n_class; c++) {
             const int kb = g.class_k0[c], ke = (c + 1 < g.n_class) ? g.class_k0[c + 1] : g.class_k0_end, ns = g.class_ns[c];
             switch (ns) {
-#define RA_CASE(NSV) case NSV: contract_class<N, NSV, NW>(Ablk, Bt, Z, kb, ke, p0, wave, la, lb, pair, odd); break;
+#define RA_CASE(NSV) case NSV: contract_class<N, NSV, NW>(Ablk, Bt, Z, kb, ke, p0, (wave - g.class_rot[c] + NW) % NW, la, lb, pair, odd); break;
                 RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6)
                 RA_CASE(7) RA_CASE(8) RA_CASE(9) RA_CASE(10) RA_CASE(11) RA_CASE(12)
 #undef RA_CASE
@@ -807,27 +826,26 @@ __global__ __launch_bounds__(RA_CCF_THREADS, 2) void ccf_kernel(DevGeom g, const
 
     // ---- phase 2: N-point inverse FFT of every live pair, 16 lanes per transform, then argmax.
     // pair = 16*sub + b, b = (ref slot, particle-offset parity): liveness depends on b only,
-    // so a wave is either wholly busy or wholly idle in a round.  A wave transforms two pairs
-    // per lane group at a time (independent register chains hide the DFT's dependent latency).
-    const int nvalid = min(8, nref - rtile * 8);
+    // so a wave is either wholly busy or wholly idle in a round.  With 8 waves a wave transforms two
+    // pairs per lane group at a time (independent register chains hide the DFT's dependent latency).
     if (!(g.dbg & 1)) {
         const int j = lane & 15, sub = lane >> 4;
         const int nlive = 2 * nvalid;                 // live b values: (b & 7) < nvalid
         for (int idx = wave; idx < nlive; idx += 2 * NW) {
             const int idx2 = idx + NW;
-            const bool two = idx2 < nlive;
+            const bool two = NW < 16 && idx2 < nlive;     // 16 waves cover all 16 live slots in one round
             const int bA = (idx / nvalid) * 8 + idx % nvalid;
             const int bB = two ? (idx2 / nvalid) * 8 + idx2 % nvalid : bA;
-            if (two) ifft_argmax<N, 2>(Z, pc, twl, 16 * sub + bA, 16 * sub + bB, j, rtile);
-            else ifft_argmax<N, 1>(Z, pc, twl, 16 * sub + bA, 16 * sub + bA, j, rtile);
+            if constexpr (NW < 16) { if (two) { ifft_argmax<N, 2>(Z, pc, twl, 16 * sub + bA, 16 * sub + bB, j, ref0); continue; } }
+            ifft_argmax<N, 1>(Z, pc, twl, 16 * sub + bA, 16 * sub + bA, j, ref0);
         }
     }
     __syncthreads();
     // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins)
     if (tid < 8) {
-        Cand best; best.val = -1.0e23f; best.tot = 0.f; best.jtot = 0; best.refmir = 0;
-        for (int rr = 0; rr < nvalid; rr++) {
-            Cand c = pc[tid * 8 + rr];
+        CandT best = pc[tid * 8];
+        for (int rr = 1; rr < nvalid; rr++) {
+            const CandT c = pc[tid * 8 + rr];
             if (c.val >= best.val) best = c;
         }
         cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
                     const int pair = 8 * (r >> 1) + 2 * (r & 1) + (sub >> 1) + 4 * (sub & 1);
                     if (pair < 2 * rc_live) {      // uniform over the 16-lane group
                         Cand c;
-                        ifft_argmax_core<ZL, N, 1>(Z, twl, pair, pair, j, c);
+                        ifft_argmax_core<ZL, N, 1, 1, Cand>(Z, twl, pair, pair, j, c);
                         if (j == 0) { c.refmir |= chunk * g.f_rc + (pair >> 1); pc[pair] = c; }
                     }
                 }
@@ -1088,7 +1106,7 @@ __global__ void pack_refs_fused_kernel(DevGeom g, const float *__restrict__ refs
 // K3: per-particle reduction over search offsets (y outer, x inner) and reference tiles with
 // the ">=" rule of Util::multiref_polar_ali_2d, ang_n, the ormq tail and combine_params2
 // (test_mref_gpu_align.py:1043-1049).
-__global__ void finalize_kernel(DevGeom g, const Cand *__restrict__ cand, int nrtile, int n,
+__global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
                                 float *__restrict__ state, ra_result *__restrict__ res,
                                 const float *__restrict__ cs)
 {
@@ -1096,20 +1114,23 @@ __global__ void finalize_kernel(DevGeom g, const Cand *__restrict__ cand, int nr
     if (p >= n) return;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     float peak = -1.0e23f;
-    Cand best; best.val = peak; best.tot = 1.f; best.jtot = 1; best.refmir = 0;
+    CandT best; best.val = peak; best.jtot = 1; best.refmir = 0;
+    for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
     int bs = 0;
     const int nx1 = 2 * g.nkx + 1;
     for (int s = 0; s < g.nshift; s++) {
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
         if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
         for (int rt = 0; rt < nrtile; rt++) {
-            Cand c = cand[((size_t)p * g.nshift_pad + s) * nrtile + rt];
-            if (c.val >= peak) { peak = c.val; best = c; bs = s; }
+            const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
+            const float v = c->val;
+            if (v >= peak) { peak = v; best = *c; bs = s; }
         }
     }
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
-    // Util::ang_n, mode F
-    const float ang = fmodf(((best.tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
+    // Util::prb1d on the winner's neighbourhood, then Util::ang_n, mode F
+    const float tot = (float)best.jtot + prb1d7(best.t7);
+    const float ang = fmodf(((tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
     const float ixw = g.shift_x[bs], iyw = g.shift_y[bs];
     const float sx = -ixw, sy = -iyw;
     const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
