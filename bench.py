@@ -170,13 +170,14 @@ def main():
         avg_ms = ms_ccf / max(n_ccf, 1)
         achieved = ccf_f * part_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
-            "metric": "particles/sec aligned, 90x90 nref=10 xr=yr=3 ou=36",
+            "metric": "particles/sec aligned, %dx%d nref=%d xr=yr=%g ou=%d" % (nx, nx, nref, xr, ou),
             "value": total / dt, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic %dx%d particles per GPU, nref=%d, xr=yr=%g, ts=1, "
+            "config": {"workload": "%s: %d synthetic %dx%d particles per GPU, nref=%d, xr=yr=%g, ts=1, "
                                    "ou=%d; step = one mref_ali2d iteration (search + rot_shift2D + class sums + "
-                                   "all-reduce + reference update)" % (n, nx, nx, nref, xr, ou),
+                                   "all-reduce + reference update)" % (
+                                       "BASELINE configs[1]" if (nx, ou, nref, xr) == (90, 36, 10, 3.0) else "custom", n, nx, nx, nref, xr, ou),
                        "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,

@@ -14,6 +14,7 @@
 
 #include "ralign_geom.h"
 #include "ralign_kernels.h"
+#include "ralign_generic.h"
 
 using namespace ralign;
 
@@ -59,6 +60,11 @@ struct ra_engine {
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0, lds_fused = 0;
     float *d_Bf = nullptr;              // [f_nchunk][f_bchunk] unit-major reference stream of the fused kernel
     bool fused = false;                 // RALIGN_FUSED=1: particle-resident single-kernel search
+    bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
+    bool xf_generic = false;            // image does not fit LDS in transform_kernel
+    float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
+    int g_nblk = 0, g_P = 0;
+    size_t lds_gpolar = 0, lds_gccf = 0;
     bool refs_ready = false;
     // kernel timing
     bool timing = false;
@@ -108,7 +114,7 @@ static int build_device_geometry(ra_engine *e)
     d.a_blk = g.LBP * 8 + 64;
     // classes of bins with equal ring-slot count
     d.n_class = 0;
-    for (int k = 0; k < g.nbins; k++) {
+    for (int k = 0; k < g.nbins && !e->generic; k++) {
         int ns = (g.bin_offp[k + 1] - g.bin_offp[k]) / 4;
         if (d.n_class == 0 || d.class_ns[d.n_class - 1] != ns) {
             if (d.n_class == 8) { g_last_error = "too many bin classes"; return RA_ERR_ARG; }
@@ -116,7 +122,7 @@ static int build_device_geometry(ra_engine *e)
         }
     }
     d.class_k0_end = g.nbins;
-    {   // start wave of every class: greedy choice that keeps the per-wave MFMA count level
+    if (!e->generic) {   // start wave of every class: greedy choice that keeps the per-wave MFMA count level
         const int NWV = RA_CCF_THREADS / 64;
         std::vector<long> load(NWV, 0);
         for (int c = 0; c < d.n_class; c++) {
@@ -144,7 +150,7 @@ static int build_device_geometry(ra_engine *e)
     std::vector<int4> A, B, C;
     struct RingPlan { int i, R1, R2; };
     std::vector<RingPlan> plans;
-    for (int i = 0; i < g.nring; i++) {
+    for (int i = 0; i < g.nring && !e->generic; i++) {
         int n = g.numr[3 * i + 2], R1, R2;
         if (!fft_plan(n / 2, R1, R2)) { g_last_error = "unsupported ring length"; return RA_ERR_ARG; }
         plans.push_back({i, R1, R2});
@@ -188,7 +194,7 @@ static int build_device_geometry(ra_engine *e)
             ringw[i] = (float)(g.numr[3 * i] * 2 * M_PI / (float)n);
         }
         auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
-        for (int i = 0; i < g.nring; i++)
+        for (int i = 0; i < g.nring && !e->generic; i++)
             if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
             const int lanes_of[6] = {16, 8, 8, 4, 4, 4};
@@ -210,8 +216,10 @@ static int build_device_geometry(ra_engine *e)
                 }
             }
         };
-        make_jobs(4, jobs, inst, instw);
-        make_jobs(2, f_jobs, f_inst, f_instw);
+        if (!e->generic) {
+            make_jobs(4, jobs, inst, instw);
+            make_jobs(2, f_jobs, f_inst, f_instw);
+        }
     }
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
@@ -220,7 +228,8 @@ static int build_device_geometry(ra_engine *e)
     // ---- fused (particle-resident) kernel plan
     std::vector<int> f_goff, f_aoff, f_uoff, f_bsrc;
     std::vector<int4> f_units;
-    {
+    d.f_on = 0;
+    if (!e->generic) {
         const int NWV = RA_POLAR_THREADS / 64;
         d.f_sbuf = (g.lring + 32 + 31) / 32 * 32 + 16;   // == 16 (mod 32): the two offset slots use disjoint banks; >= 32 floats of slack
         d.f_n_job = (int)f_jobs.size(); d.f_n_inst = (int)f_inst.size();
@@ -416,15 +425,26 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         delete e;
         return RA_ERR_ARG;
     }
-    if (e->geo.nring > 4 * RA_CCF_MAXNS) {
-        g_last_error = "more than 48 rings are not supported by the CCF kernel yet";
-        delete e;
-        return RA_ERR_ARG;
-    }
-    if (!select_ccf(e->geo.maxrin)) {
-        g_last_error = "maxrin not supported by the CCF kernel (32..256)";
-        delete e;
-        return RA_ERR_ARG;
+    {   // the LDS-resident kernels cover <= 48 rings of 8..256 samples and images whose padded copy
+        // plus four ring buffers fit one CU's LDS; everything else runs the size-generic kernels
+        const Geometry &g0 = e->geo;
+        bool fast = g0.nring <= 4 * RA_CCF_MAXNS && select_ccf(g0.maxrin) != nullptr && g0.numr[2] >= 8;
+        const int bd0 = (int)std::ceil(std::max(cfg->xrng, cfg->yrng)) + 2, pst0 = g0.nx + 2 * bd0;
+        const int sbuf0 = (g0.lring + 31) / 32 * 32 + 8;
+        if ((size_t)(pst0 * pst0 + 4 * sbuf0 + 2 * g0.maxrin + 4096) * sizeof(float) > 160 * 1024) fast = false;
+        int ncls = 0, prev = -1;
+        for (int k = 0; k < g0.nbins; k++) {
+            const int ns = (g0.bin_offp[k + 1] - g0.bin_offp[k]) / 4;
+            if (ns != prev) { ncls++; prev = ns; }
+        }
+        if (ncls > 8) fast = false;
+        if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) fast = false;
+        e->generic = !fast;
+        if (e->geo.maxrin > 4096) {
+            g_last_error = "rings longer than 4096 samples are not supported";
+            delete e;
+            return RA_ERR_ARG;
+        }
     }
     e->nrtile = (cfg->nref + 7) / 8;
     e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
@@ -441,25 +461,42 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->lds_ccf = (size_t)64 * (2 * (g.maxrin + g.maxrin / 16) + 2) * sizeof(float);
     e->lds_xf = (size_t)npix_pad * sizeof(float);
     const size_t lds_max = 160 * 1024;
-    if (e->lds_polar > lds_max || e->lds_ccf > lds_max) {
+    if (!e->generic && (e->lds_polar > lds_max || e->lds_ccf > lds_max)) {
         g_last_error = "image / ring geometry does not fit the 160 KB LDS of one CU";
         ra_destroy(e);
         return RA_ERR_ARG;
     }
-    hipError_t he;
-    he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
-    if (he == hipSuccess && e->dg.f_on) he = hipFuncSetAttribute((const void *)select_fused(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_fused);
+    e->xf_generic = e->lds_xf > lds_max;
+    // generic contraction: P pairs per inverse-FFT batch, two N-point buffers per pair
+    e->g_P = 64;
+    while (e->g_P > 1 && (size_t)e->g_P * (2 * g.maxrin + 1) * sizeof(float2) > 128 * 1024) e->g_P >>= 1;
+    e->lds_gccf = (size_t)e->g_P * (2 * g.maxrin + 1) * sizeof(float2);
+    e->lds_gpolar = (size_t)(RA_GEN_THREADS / 64) * g.maxrin * sizeof(float2);
+    hipError_t he = hipSuccess;
+    if (!e->generic) {
+        he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
+        if (he == hipSuccess && e->dg.f_on) he = hipFuncSetAttribute((const void *)select_fused(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_fused);
+    } else {
+        he = hipFuncSetAttribute((const void *)polar_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)polar_generic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
+    }
+    if (he == hipSuccess && !e->xf_generic) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
 
     // workspace: bin-major spectra of `chunk` particles + candidate records
     int chunk = cfg->chunk > 0 ? cfg->chunk : 8192;
     chunk = std::min((chunk + 1) & ~1, 32768);      // class_sum_kernel keeps a chunk's member list in LDS
-    e->chunk = chunk;
     const int ngroup = g.nshift_pad / 4;
+    {   // keep the spectra workspace of one chunk within ~12 GB (large boxes: tens of MB per particle)
+        const size_t per_particle = (size_t)ngroup * e->dg.a_blk * sizeof(float);
+        const size_t cap = std::max<size_t>(2, ((size_t)12 << 30) / per_particle);
+        if ((size_t)chunk > cap) chunk = (int)(cap & ~(size_t)1);
+    }
+    e->chunk = chunk;
     if ((rc = dev_alloc(e, &e->d_A, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
         (rc = dev_alloc(e, &e->d_cand, ((size_t)chunk * g.nshift_pad + 8) * e->nrtile, true)) ||
 
@@ -470,8 +507,12 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         ra_destroy(e);
         return rc;
     }
+    if (e->generic) {
+        e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
+        if ((rc = dev_alloc(e, &e->d_zscr, (size_t)e->g_nblk * 64 * g.maxrin, false))) { ra_destroy(e); return rc; }
+    }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
-    e->fused = e->dg.f_on && getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) != 0;
+    e->fused = !e->generic && e->dg.f_on && getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) != 0;
     if (e->dg.f_on && (rc = dev_alloc(e, &e->d_Bf, (size_t)e->dg.f_nchunk * e->dg.f_bchunk, true))) { ra_destroy(e); return rc; }
     e->overlap = getenv("RALIGN_OVERLAP") && atoi(getenv("RALIGN_OVERLAP")) != 0;
     if (e->overlap && ((rc = dev_alloc(e, &e->d_A2, ((size_t)chunk * ngroup + 2) * e->dg.a_blk, true)) ||
@@ -551,8 +592,12 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
 {
     if (!e || !d_refs) { g_last_error = "null argument"; return RA_ERR_ARG; }
     const Geometry &g = e->geo;
-    hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(e->cfg.nref), dim3(256), e->lds_ref, e->stream, e->dg, d_refs,
-                       e->cfg.nref, e->d_refspec);
+    if (e->generic)
+        hipLaunchKernelGGL(polar_generic_kernel<true>, dim3(e->cfg.nref), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
+                           d_refs, (const float *)nullptr, e->cfg.nref, e->d_refspec);
+    else
+        hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(e->cfg.nref), dim3(256), e->lds_ref, e->stream, e->dg, d_refs,
+                           e->cfg.nref, e->d_refspec);
     RA_HIP(hipGetLastError());
     int total = e->nrtile * g.LBP * 16;
     hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
@@ -617,7 +662,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
     const int ngroup = g.nshift_pad / 4;
-    ccf_fn ccf = select_ccf(g.maxrin);
+    ccf_fn ccf = e->generic ? nullptr : select_ccf(g.maxrin);
     if (cs && (cs[0] != 0.f || cs[1] != 0.f)) {
         RA_HIP(hipMemcpyAsync(e->d_cs, cs, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(apply_cs_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_cs, d_result, d_state);
@@ -661,7 +706,11 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // the polar kernel of this chunk may not overwrite a workspace the contraction of chunk ci-2 still reads
         if (ov && ci >= 2) RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[b], 0));
         if (evp) RA_HIP(hipEventRecord(evp->first, sp));
-        hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
+        if (e->generic)
+            hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
+                               part, (const float *)st, cn, Abuf);
+        else
+            hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
         if (ov) {
@@ -670,8 +719,12 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         }
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sc));
-        hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sc, e->dg, Abuf, e->d_B, n_mtile,
-                           e->nrtile, e->cfg.nref, Cbuf);
+        if (e->generic)
+            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sc, e->dg,
+                               Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P);
+        else
+            hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sc, e->dg, Abuf, e->d_B, n_mtile,
+                               e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
         if (evc) RA_HIP(hipEventRecord(evc->second, sc));
         hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sc, e->dg, Cbuf, e->nrtile,
@@ -691,7 +744,11 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
 {
     if (!e || !d_particles || !d_state || !h_out || n < 1 || n > e->chunk) { g_last_error = "bad argument"; return RA_ERR_ARG; }
     const Geometry &g = e->geo;
-    hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);
+    if (e->generic)
+        hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
+                           e->dg, d_particles, d_state, n, e->d_A);
+    else
+        hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);
     RA_HIP(hipGetLastError());
     float *d_out = nullptr;
     const size_t cnt = (size_t)n * g.nshift * g.lcirc;
@@ -712,8 +769,12 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
     if (!d_particles || !d_result) { g_last_error = "null argument"; return RA_ERR_ARG; }
     const int nx = e->geo.nx, npix = nx * nx;
     if (!d_sums || e->atomic_sums) {
-        hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, nx, d_particles, n, index0,
-                           d_result, d_aligned, d_sums, d_counts);
+        if (e->xf_generic)
+            hipLaunchKernelGGL(transform_generic_kernel, dim3(n, 8), dim3(256), 0, e->stream, nx, d_particles, n, index0,
+                               d_result, d_aligned, d_sums, d_counts);
+        else
+            hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, nx, d_particles, n, index0,
+                               d_result, d_aligned, d_sums, d_counts);
         RA_HIP(hipGetLastError());
         return RA_OK;
     }
@@ -721,8 +782,12 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *al = d_aligned ? d_aligned + (size_t)start * npix : e->d_alscratch;
-        hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(256), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
-                           cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
+        if (e->xf_generic)
+            hipLaunchKernelGGL(transform_generic_kernel, dim3(cn, 8), dim3(256), 0, e->stream, nx, d_particles + (size_t)start * npix,
+                               cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
+        else
+            hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(256), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
+                               cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
         RA_HIP(hipGetLastError());
         hipLaunchKernelGGL(class_sum_kernel, dim3(2 * e->cfg.nref, (npix + 255) / 256), dim3(256), (size_t)cn * sizeof(int), e->stream, npix, al,
                            d_result + start, cn, index0 + start, d_sums, d_counts);

@@ -1,0 +1,334 @@
+// Size-generic kernels of the alignment path for geometries the LDS-resident kernels of
+// ralign_kernels.h cannot hold: images larger than one CU's LDS (e.g. 256 x 256), more than 48
+// rings, rings longer than 256 samples (maxrin 512 ... 4096).  Same arithmetic and the same
+// operand layout (bin-major A panels, B tiles, CandT records) as the specialised kernels, so the
+// two paths are interchangeable stage by stage and are tested against each other.
+//
+//   polar_generic_kernel<false>  Polar2Dm + Normalize_ring + Frngs: one wave per search offset
+//                                (4 offsets = one A block per workgroup), image sampled from
+//                                global memory / L2, one ring at a time through a wave-private
+//                                LDS buffer, spectra scattered straight into the A panels.
+//   polar_generic_kernel<true>   the reference side (Polar2Dm + Frngs, natural layout).
+//   ccf_generic_kernel           Crosrng_ms: the same 16x16x4 f32 MFMA contraction per Fourier
+//                                bin; the CCF spectra of the 8 x 8 tile go through an L2-resident
+//                                scratch (they do not fit LDS at maxrin >= 512), are inverse
+//                                transformed in LDS a few pairs at a time and reduced by a
+//                                wavefront argmax.
+//   transform_generic_kernel     rot_shift2D reading the image from global memory.
+#pragma once
+
+#include "ralign_kernels.h"
+
+namespace ralign {
+
+#define RA_GEN_THREADS 256
+#define RA_GCCF_THREADS 512
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Wave-level Stockham FFT of h complex points (h a power of two >= 2) between two LDS buffers:
+// one radix-2 stage when log2 h is odd, radix-4 stages otherwise; natural-order output.
+// tw[m] = e^{-2 pi i m / T}, T a power of two >= h.  SIGN = -1 forward, +1 inverse (unscaled).
+// Returns the buffer that holds the result.
+template <int SIGN>
+__device__ __forceinline__ float2 *wave_fft(float2 *x, float2 *y, int h, const float2 *__restrict__ tw, int T, int lane)
+{
+    int Ns = 1;
+    const int lg = 31 - __clz(h);
+    if (lg & 1) {
+        const int q = h >> 1;
+        for (int j = lane; j < q; j += 64) {
+            const float2 a = x[j], b = x[j + q];
+            y[2 * j] = cadd(a, b);
+            y[2 * j + 1] = csub(a, b);
+        }
+        wave_lds_sync();
+        float2 *t = x; x = y; y = t;
+        Ns = 2;
+    }
+    for (; Ns < h; Ns <<= 2) {
+        const int q = h >> 2, tstep = T / (4 * Ns);
+        for (int j = lane; j < q; j += 64) {
+            const int k = j & (Ns - 1);
+            float2 v0 = x[j], v1 = x[j + q], v2 = x[j + 2 * q], v3 = x[j + 3 * q];
+            if (k) {
+                float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                if (SIGN > 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+            }
+            dft4<SIGN>(v0, v1, v2, v3);
+            const int j0 = ((j - k) << 2) + k;
+            y[j0] = v0; y[j0 + Ns] = v1; y[j0 + 2 * Ns] = v2; y[j0 + 3 * Ns] = v3;
+        }
+        wave_lds_sync();
+        float2 *t = x; x = y; y = t;
+    }
+    return x;
+}
+
+// real-FFT split step: bin k (0..h) of the n = 2h point real transform from the h-point complex
+// transform Z of the packed sequence z_m = x_2m + i x_2m+1
+__device__ __forceinline__ float2 split_bin(const float2 *Z, int k, int h, float2 w)
+{
+    const float2 zk = Z[k & (h - 1)], zm = Z[(h - k) & (h - 1)];
+    const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+    const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+    const float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+    if (k == 0 || k == h) return make_float2(er + tr, 0.f);
+    return make_float2(er + tr, ei + ti);
+}
+
+// Polar2Dm (bilinear) [+ Normalize_ring] + Frngs for images of any size.
+//   REFS = false: particles; workgroup = (particle, group of 4 search offsets), wave = offset slot;
+//                 output = the A block of that group (layout of ralign_geom.h: ent_apos).
+//   REFS = true : references; workgroup = reference, waves share the rings; output natural
+//                 padded ring layout [lring] (what ref_polar_fft_kernel writes).
+// (reference call sites: test_mref_gpu_align.py:1015-1016, 1043-1044)
+template <bool REFS>
+__global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g, const float *__restrict__ images,
+                                                                      const float *__restrict__ state, int n,
+                                                                      float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *bx = reinterpret_cast<float2 *>(lds) + (size_t)wave * g.maxrin;     // two buffers of maxrin/2 complex
+    float2 *by = bx + g.maxrin / 2;
+    const int npix = g.nx * g.nx;
+
+    if (REFS) {
+        const int r = blockIdx.x;
+        if (r >= n) return;
+        const float *img = images + (size_t)r * npix;
+        const float c = (float)g.cnx;
+        for (int i = wave; i < g.nring; i += RA_GEN_THREADS / 64) {
+            const int4 ri = g.ringinfo[i];
+            const int nlen = ri.z, h = nlen >> 1, kc = ri.x - 2 * i;
+            float *xr = reinterpret_cast<float *>(bx);
+            for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + c, g.samp_dy[kc + j] + c);
+            wave_lds_sync();
+            const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, g.tw, g.maxrin, lane) : bx;
+            float *dst = out + (size_t)r * g.lring + ri.x;
+            for (int k = lane; k <= h; k += 64) {
+                const float2 X = split_bin(Z, k, h, g.tw[k * (g.maxrin / nlen)]);
+                dst[2 * k] = X.x; dst[2 * k + 1] = X.y;
+            }
+            wave_lds_sync();
+        }
+        return;
+    }
+
+    const int ngroup = g.nshift_pad / 4;
+    const int p = blockIdx.x / ngroup, grp = blockIdx.x - p * ngroup;
+    if (p >= n) return;
+    const float *img = images + (size_t)p * npix;
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    const int slot = wave, si = min(grp * 4 + slot, g.nshift - 1);
+    const float cx = ((float)g.cnx + w.sxi) + g.shift_x[si], cy = ((float)g.cnx + w.syi) + g.shift_y[si];
+
+    // Normalize_ring statistics (multi-reference mode): one sampling pass, ring partials added in ring order
+    float avg = 0.f, rsg = 1.f;
+    if (g.mode == RA_MODE_MREF) {
+        float av = 0.f, sq = 0.f;
+        for (int i = 0; i < g.nring; i++) {
+            const int4 ri = g.ringinfo[i];
+            const int nlen = ri.z, kc = ri.x - 2 * i;
+            const float wt = g.ringw[i];
+            float a = 0.f, q = 0.f;
+            for (int j = lane; j < nlen; j += 64) {
+                const float s = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+                a += s * wt; q += s * s * wt;
+            }
+            av += wave_sum(a); sq += wave_sum(q);
+        }
+        const float nn = g.nn_weight;
+        avg = av / nn;
+        rsg = 1.0f / sqrtf((sq - av * av / nn) / nn);
+    }
+
+    float *blk = out + ((size_t)p * ngroup + grp) * g.a_blk;
+    for (int i = 0; i < g.nring; i++) {
+        const int4 ri = g.ringinfo[i];
+        const int nlen = ri.z, h = nlen >> 1, kc = ri.x - 2 * i;
+        float *xr = reinterpret_cast<float *>(bx);
+        for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+        wave_lds_sync();
+        const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, g.tw, g.maxrin, lane) : bx;
+        const float dc = avg * (float)nlen;
+        for (int k = lane; k <= h; k += 64) {
+            float2 X = split_bin(Z, k, h, g.tw[k * (g.maxrin / nlen)]);
+            // Normalize_ring after the (linear) FFT: X_0 -= avg * n, then the common scale 1/sigma
+            if (k == 0) X.x -= dc;
+            X.x *= rsg; X.y *= rsg;
+            const int2 ap = g.ent_apos[g.bin_off[k] + (i - g.bin_first[k])];
+            blk[ap.x + (2 * slot) * ap.y] = X.x;
+            blk[ap.x + (2 * slot + 1) * ap.y] = X.y;
+        }
+        wave_lds_sync();
+    }
+}
+
+// Crosrng_ms for an 8 (particle-offset) x 8 (reference) tile at any maxrin; persistent workgroups
+// walk the m-tiles.  zscr: [gridDim.x][N][64] complex scratch (stays in L2 / Infinity Cache);
+// P = pairs transformed per LDS batch (power of two, 2 * P * (N + 1) complex fit the dynamic LDS).
+__global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
+                                                                      const float *__restrict__ B, int n_mtile, int nrtile,
+                                                                      int nref, CandT *__restrict__ cand,
+                                                                      float2 *__restrict__ zscr, int P)
+{
+    extern __shared__ __align__(16) float lds[];
+    __shared__ CandT pc[64];
+    const int N = g.maxrin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = RA_GCCF_THREADS / 64;
+    float2 *zs = zscr + (size_t)blockIdx.x * 64 * N;
+    float2 *xb = reinterpret_cast<float2 *>(lds);
+    const int pstride = 2 * N + 1;          // complex slots per pair: two N-point buffers + 1 (bank skew)
+
+    for (int mtile = blockIdx.x; mtile < n_mtile; mtile += gridDim.x) {
+        for (int rtile = 0; rtile < nrtile; rtile++) {
+            const int ref0 = rtile * g.rpt;
+            const int nvalid = min(g.rpt, nref - ref0);
+            // ---- phase 1: contraction per Fourier bin (same operand layout as ccf_kernel)
+            {
+                const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
+                const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
+                const float *Bt = B + (size_t)rtile * g.LBP * 16;
+                const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);      // offset-in-tile * 8 + reference slot
+                const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
+                for (int k = wave; k < g.nbins; k += NW) {
+                    const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
+                    const float *pa = Ablk + (size_t)e0 * 8, *pb = Bt + (size_t)e0 * 16;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    int oa = 0, ob = 0;
+                    for (int q = 0; q < (ns >> 2); q++) {
+                        const float4 va = *reinterpret_cast<const float4 *>(pa + oa + la * 4);
+                        const float4 vb = *reinterpret_cast<const float4 *>(pb + ob + lb * 4);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc, 0, 0, 0);
+                        oa += 128; ob += 256;
+                    }
+                    if (ns & 2) {
+                        const float2 va = *reinterpret_cast<const float2 *>(pa + oa + la * 2);
+                        const float2 vb = *reinterpret_cast<const float2 *>(pb + ob + lb * 2);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
+                        oa += 64; ob += 128;
+                    }
+                    if (ns & 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[oa + la], pb[ob + lb], acc, 0, 0, 0);
+                    // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
+                    const float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
+                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    const float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
+                    const float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
+                    const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                    zs[(size_t)k * 64 + pair] = make_float2(apd + bpc, cmb + amd);
+                    zs[(size_t)((N - k) & (N - 1)) * 64 + pair] = make_float2(apd - bpc, amd - cmb);
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: inverse FFT + argmax, P pairs per batch, one wave per pair
+            for (int base = 0; base < 64; base += P) {
+                for (int idx = tid; idx < P * N; idx += RA_GCCF_THREADS) {
+                    const int k = idx / P, pp = idx - k * P;
+                    xb[(size_t)pp * pstride + k] = zs[(size_t)k * 64 + base + pp];
+                }
+                __syncthreads();
+                for (int pp = wave; pp < P; pp += NW) {
+                    const int pair = base + pp, slot = pair & 7;
+                    if (slot >= nvalid) continue;           // wave-uniform
+                    float2 *x = xb + (size_t)pp * pstride;
+                    const float2 *r = wave_fft<1>(x, x + N, N, g.tw, N, lane);
+                    float bq = -1.0e20f, bt = -1.0e20f;
+                    int iq = 0, it = 0;
+                    for (int j = lane; j < N; j += 64) {     // ascending: ">=" keeps the last maximum
+                        const float2 v = r[j];
+                        if (v.x >= bq) { bq = v.x; iq = j; }
+                        if (v.y >= bt) { bt = v.y; it = j; }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float oq = __shfl_xor(bq, o); const int oiq = __shfl_xor(iq, o);
+                        const float ot = __shfl_xor(bt, o); const int oit = __shfl_xor(it, o);
+                        if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
+                        if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
+                    }
+                    if (lane == 0) {
+                        const bool mir = !(bq >= bt);        // qn >= qm keeps the straight match
+                        const int jt = mir ? it : iq;
+                        CandT c;
+                        c.val = mir ? bt : bq; c.jtot = jt + 1; c.refmir = ((mir ? 1 : 0) << 16) | (ref0 + slot);
+#pragma unroll
+                        for (int k = -3; k <= 3; k++) {
+                            const float2 zz = r[(jt + k + N) & (N - 1)];
+                            c.t7[k + 3] = mir ? zz.y : zz.x;
+                        }
+                        pc[pair] = c;
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins)
+            if (tid < 8) {
+                CandT best = pc[tid * 8];
+                for (int rr = 1; rr < nvalid; rr++) {
+                    const CandT c = pc[tid * 8 + rr];
+                    if (c.val >= best.val) best = c;
+                }
+                cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// rot_shift2D for images that do not fit LDS: quadri_background reads global memory
+// (test_mref_gpu_align.py:1055; arithmetic of transform_kernel)
+__global__ __launch_bounds__(256) void transform_generic_kernel(int nx, const float *__restrict__ particles, int n,
+                                                                int index0, const ra_result *__restrict__ res,
+                                                                float *__restrict__ aligned, float *__restrict__ sums,
+                                                                int *__restrict__ counts)
+{
+#pragma clang fp contract(off)
+    const int p = blockIdx.x, tid = threadIdx.x, npix = nx * nx;
+    if (p >= n) return;
+    const float *img = particles + (size_t)p * npix;
+    const ra_result r = res[p];
+    const float ang = r.alpha * (float)M_PI / 180.0f;
+    float delx = r.sx, dely = r.sy;
+    while (delx >= (float)nx) delx -= nx;
+    while (delx <= -(float)nx) delx += nx;
+    while (dely >= (float)nx) dely -= nx;
+    while (dely <= -(float)nx) dely += nx;
+    const int xc = nx / 2, yc = nx / 2;
+    const float shiftxc = xc + delx, shiftyc = yc + dely;
+    const float cang = (float)cos((double)ang), sang = (float)sin((double)ang);
+    float *dsum = sums ? sums + ((size_t)r.ref_id * 2 + ((index0 + p) & 1)) * npix : nullptr;
+    float *dal = aligned ? aligned + (size_t)p * npix : nullptr;
+    const int mstart = 1 - nx % 2;
+    for (int i = blockIdx.y * blockDim.x + tid; i < npix; i += gridDim.y * blockDim.x) {
+        const int iy = i / nx, ix = i - iy * nx;
+        float y = (float)iy - shiftyc;
+        float ycang = y * cang + yc;
+        float ysang = -y * sang + xc;
+        float x = (float)ix - shiftxc;
+        float xold = x * cang + ysang;
+        float yold = x * sang + ycang;
+        float v = quadri_background_1b(img, nx, nx, xold + 1.0f, yold + 1.0f, ix + 1, iy + 1);
+        int ox = ix;
+        if (r.mirror && ix >= mstart) ox = mstart + (nx - 1) - ix;
+        const int o = iy * nx + ox;
+        if (dal) dal[o] = v;
+        if (dsum) atomicAdd(dsum + o, v);
+    }
+    if (counts && tid == 0 && blockIdx.y == 0) atomicAdd(counts + r.ref_id, 1);
+}
+
+}  // namespace ralign

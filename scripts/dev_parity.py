@@ -51,5 +51,9 @@ def main(nx=90, ou=36, nref=10, n=64, xr=3, sigma=0.25):
     print("newrefs finite", torch.isfinite(newrefs).all().item())
 
 if __name__ == "__main__":
-    main()
-    main(nx=32, ou=12, nref=3, n=16, xr=2)
+    if len(sys.argv) > 1:       # nx ou nref n xr [sigma]
+        a = sys.argv[1:]
+        main(nx=int(a[0]), ou=int(a[1]), nref=int(a[2]), n=int(a[3]), xr=int(a[4]), sigma=float(a[5]) if len(a) > 5 else 0.25)
+    else:
+        main()
+        main(nx=32, ou=12, nref=3, n=16, xr=2)
