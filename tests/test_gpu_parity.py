@@ -93,7 +93,10 @@ def test_prepared_references_match_applyws():
 def test_polar_ring_fft_stage_bin_for_bin(nx, ou, xr, mode):
     """first kernel alone: Polar2Dm -> (Normalize_ring) -> Frngs of every search offset, compared
     element by element with the oracle in EMAN2's packed ring layout."""
-    n = 3
+    polar_stage_check(nx, ou, xr, mode)
+
+
+def polar_stage_check(nx, ou, xr, mode, n=3, rtol=1e-5):
     refs = synth.make_references(2, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
     rg = orc.rings(1, ou, 1)
@@ -115,7 +118,7 @@ def test_polar_ring_fft_stage_bin_for_bin(nx, ou, xr, mode):
             if mode == api.RA_MODE_MREF:
                 c = orc.normalize_ring(c, rg)
             want = orc.frngs(c, rg)
-            assert np.abs(got[p, s] - want).max() < 1e-5 * np.abs(want).max(), (p, s)
+            assert np.abs(got[p, s] - want).max() < rtol * np.abs(want).max(), (p, s)
     assert mashi > 0
     eng.close()
 
@@ -508,3 +511,62 @@ def test_class_sums_are_bitwise_reproducible():
         want[r["ref_id"][i], (3 + i) % 2] += a[i]
     np.testing.assert_array_equal(outs[0][0], want)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# size-generic kernels (ralign_generic.h): large boxes, maxrin 512/1024, more than 48 rings
+
+@pytest.mark.parametrize("mode", [api.RA_MODE_MREF, api.RA_MODE_REFFREE])
+def test_generic_polar_stage_bin_for_bin_on_small_box(monkeypatch, mode):
+    """the generic polar / ring-FFT kernel forced onto a geometry the specialised kernel also covers"""
+    monkeypatch.setenv("RALIGN_GENERIC", "1")
+    polar_stage_check(64, 25, 3, mode)
+
+
+def test_generic_search_equals_specialised_search(monkeypatch):
+    """same inputs through both kernel families: identical integer assignments, peaks within f32 noise"""
+    nx, ou, nref, xr, n = 90, 36, 10, 3, 96
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    fast = api.Engine.result_to_numpy(res).copy()
+    eng.close()
+    monkeypatch.setenv("RALIGN_GENERIC", "1")
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    gen = api.Engine.result_to_numpy(res).copy()
+    eng.close()
+    for f in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+        assert (fast[f] == gen[f]).all(), f
+    assert (np.abs(fast["peak"] - gen["peak"]) / np.abs(fast["peak"])).max() < 1e-5
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    compare_search(gen, st.cpu().numpy(), params, infos, d)
+
+
+@pytest.mark.parametrize("nx,ou,xr,nref,n", [(256, 120, 5, 3, 6),      # BASELINE configs[4] geometry: maxrin 1024, 120 rings
+                                              (160, 70, 3, 9, 5),       # maxrin 512, two reference tiles (5 + 4)
+                                              (128, 50, 4, 2, 6)])      # maxrin 512, 50 rings
+def test_large_box_search_transform_and_sums(nx, ou, xr, nref, n):
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.25, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    assert rg.maxrin >= 512
+    d = np.zeros((n, 2), np.float32)
+    params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    got = eng.prepared_references()
+    assert np.abs(got - cref).max() < 1e-6 * np.abs(cref).max()
+    r = api.Engine.result_to_numpy(res)
+    compare_search(r, st.cpu().numpy(), params, infos, d, max_tie_frac=0.0)
+    gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
+    gc = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
+    eng.transform_accumulate(tp, res, 0, None, gs, gc)
+    eng.sync()
+    assert (gc.cpu().numpy() == counts).all()
+    assert_images_close(gs.cpu().numpy(), sums, mask, 2e-5 * np.abs(sums).max() + 1e-4)
+    eng.close()
+
+
+def test_large_box_polar_stage_bin_for_bin():
+    polar_stage_check(128, 50, 2, api.RA_MODE_MREF, n=2, rtol=2e-5)
