@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
+    "ra_fsc_len", "ra_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
 ]
 
 _lib = None
@@ -99,6 +100,12 @@ def load_library(path=None):
     L.ra_debug_spectra.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     L.ra_kernel_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    L.ra_fsc_len.argtypes = [vp]
+    L.ra_class_fsc.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, float_ptr]
+    L.ra_fit_tanh.argtypes = [float_ptr, float_ptr, ctypes.c_int, float_ptr, float_ptr]
+    L.ra_class_averages.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    L.ra_filter_references.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, float_ptr,
+                                       ctypes.c_int, float_ptr]
     # reference surface (test_mref_gpu_align.py:95-97 sets the pointer returns to c_ulonglong)
     L.pre_align_init.restype = ctypes.c_ulonglong
     L.pre_align_init.argtypes = [ctypes.c_uint, ctypes.POINTER(AlignConfig), ctypes.c_uint]
@@ -133,6 +140,18 @@ def get_c_ptr_array(images):
         assert img.flags["C_CONTIGUOUS"] and img.dtype == np.float32
         ptrs.append(img.ctypes.data_as(float_ptr))
     return (float_ptr * len(ptrs))(*ptrs)
+
+
+def fit_tanh(dres, low=0.1):
+    """sp_filter.fit_tanh on an fsc result [freq, fsc, n]; edits dres[1] in place like the original"""
+    assert low == 0.1
+    n = len(dres[0])
+    fr = (ctypes.c_float * n)(*dres[0])
+    fs = (ctypes.c_float * n)(*dres[1])
+    fl, aa = ctypes.c_float(), ctypes.c_float()
+    _check(load_library().ra_fit_tanh(fr, fs, n, ctypes.byref(fl), ctypes.byref(aa)), "ra_fit_tanh")
+    dres[1][:] = [float(v) for v in fs]
+    return fl.value, aa.value
 
 
 def _check(rc, what):
@@ -250,6 +269,32 @@ class Engine:
                                          self._ptr(state, self.torch.float32), out.ctypes.data_as(ctypes.c_void_p)),
                "ra_debug_spectra")
         return out
+
+    # -- reference update on the device (SURVEY.md section 8 row f-1)
+    def class_fsc(self, sums, counts, min_count=4, masked=False):
+        """[freq, fsc, npoints] lists like sp_statistics.fsc / fsc_mask, averaged over the live classes"""
+        n = self.lib.ra_fsc_len(self.handle)
+        out = np.zeros((3, n), np.float32)
+        _check(self.lib.ra_class_fsc(self.handle, self._ptr(sums, self.torch.float32), self._ptr(counts, self.torch.int32),
+                                     int(min_count), int(bool(masked)), out.ctypes.data_as(float_ptr)), "ra_class_fsc")
+        return [list(map(float, out[0])), list(map(float, out[1])), list(map(float, out[2]))]
+
+    def class_averages(self, sums, counts, refs, min_count=4):
+        _check(self.lib.ra_class_averages(self.handle, self._ptr(sums, self.torch.float32),
+                                          self._ptr(counts, self.torch.int32), int(min_count),
+                                          self._ptr(refs, self.torch.float32)), "ra_class_averages")
+
+    def filter_references(self, imgs, fl, aa, center=0, cs_in=None, normalize=True):
+        """in place on imgs [m][nx][nx]; returns the applied centres [m][2]"""
+        m = imgs.shape[0]
+        cin = None
+        if cs_in is not None:
+            cin = np.ascontiguousarray(cs_in, np.float32).reshape(m, 2)
+        cout = np.zeros((m, 2), np.float32)
+        _check(self.lib.ra_filter_references(self.handle, self._ptr(imgs, self.torch.float32), m, float(fl), float(aa),
+                                             int(center), cin.ctypes.data_as(float_ptr) if cin is not None else None,
+                                             int(bool(normalize)), cout.ctypes.data_as(float_ptr)), "ra_filter_references")
+        return cout
 
     def sync(self):
         _check(self.lib.ra_sync(self.handle), "ra_sync")

@@ -10,8 +10,9 @@ One process per GPU: run under `python -m torch.distributed.run --nproc-per-node
 reference's `mpirun -np N`; particles are sharded with MPI_start_end, class sums go through one
 RCCL all-reduce.  Outputs: per iteration `aqm%03d.<ext>` class averages (reference :519,564), at the end
 `params.txt` rows `idx angle_psi shift_x shift_y mirror class` / `initial2Dparams.txt` rows
-`alpha sx sy mirror`.  Flags the engine does not implement yet (--CTF, --function filtering/centring,
-a mask file, --MPI CPU path) are accepted and reported, not silently ignored.
+`alpha sx sy mirror`.  --function=ref_ali2d (the default) runs the FSC-fitted tangent filter and the
+centring on the device; any other name is rejected.  Flags the engine does not implement (--CTF, a
+mask file, the --MPI CPU path) are accepted and reported, not silently ignored.
 """
 import argparse
 import os
@@ -40,6 +41,13 @@ def _common(p):
 def _first(v):
     """the reference uses only stage 0 of "4 2 1 1"-style lists (test_reffree_gpu_align.py:355-357)"""
     return float(str(v).split()[0])
+
+
+def _user_func(name):
+    """--function: the reference resolves the name in sp_user_functions; the engine implements ref_ali2d"""
+    if name in ("ref_ali2d", "none", "None", ""):
+        return "ref_ali2d" if name == "ref_ali2d" else None
+    raise SystemExit("--function=%s is not implemented by the MI355X engine (ref_ali2d | none)" % name)
 
 
 def _setup(args):
@@ -86,9 +94,11 @@ def main_mref(argv=None):
         os.makedirs(args.outdir, exist_ok=True)
     maxit = int(args.maxit) if int(args.maxit) > 0 else 10
     for it in range(maxit):
-        counts = al.iterate()
+        counts = al.iterate(_user_func(args.function), int(args.center))
         if rank == 0:
             stackio.write_stack(os.path.join(args.outdir, "aqm%03d.%s" % (it, args.ext)), al.refs.cpu().numpy())
+            if al.filter_params:
+                print("Tangent filter:  cut-off frequency = %10.3f        fall-off = %10.3f" % al.filter_params[-1])
             print("ITERATION #%3d" % (it + 1))
             for j, c in enumerate(counts):
                 print("   group #%3d   number of particles = %7d" % (j, c))
@@ -130,7 +140,7 @@ def main_reffree(argv=None):
                         total_nima=total)
     maxit = int(args.maxit) if int(args.maxit) > 0 else 10
     for it in range(maxit):
-        a1 = al.iterate(int(args.center))
+        a1 = al.iterate(int(args.center), _user_func(args.function))
         if rank == 0:
             print("Iteration #%4d   Criterion = %15.8e" % (it + 1, a1))
     r = al.params()

@@ -15,6 +15,7 @@
 #include "ralign_geom.h"
 #include "ralign_kernels.h"
 #include "ralign_generic.h"
+#include "ralign_refine.h"
 
 using namespace ralign;
 
@@ -65,6 +66,10 @@ struct ra_engine {
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
     int g_nblk = 0, g_P = 0;
     size_t lds_gpolar = 0, lds_gccf = 0;
+    // reference-update workspace (ralign_refine.h), allocated on first use
+    int rf_cap = 0;                     // images the workspace holds
+    double2 *d_rfT = nullptr, *d_rfF = nullptr, *d_rftw = nullptr;
+    float *d_rfmean = nullptr, *d_rffsc = nullptr, *d_rfcs = nullptr;
     bool refs_ready = false;
     // kernel timing
     bool timing = false;
@@ -846,6 +851,190 @@ extern "C" int ra_kernel_time(ra_engine *e, int enable, double *ms_ccf, int *lau
     if (launches_polar) *launches_polar = (int)e->ev_used_polar;
     e->ev_used_ccf = e->ev_used_polar = 0;
     e->timing = enable != 0;
+    return RA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference update on the device (kernels in ralign_refine.h)
+
+static int ensure_refine_ws(ra_engine *e, int nimg)
+{
+    if (nimg <= e->rf_cap) return RA_OK;
+    const int nx = e->geo.nx, nxh = nx / 2 + 1;
+    const int cap = std::max(nimg, 2 * e->cfg.nref);
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_rfT, (size_t)cap * nx * nxh, false)) || (rc = dev_alloc(e, &e->d_rfF, (size_t)cap * nx * nxh, false)) ||
+        (rc = dev_alloc(e, &e->d_rfmean, (size_t)cap, true)) || (rc = dev_alloc(e, &e->d_rffsc, (size_t)cap * (nx / 2 + 1), true)) ||
+        (rc = dev_alloc(e, &e->d_rfcs, (size_t)cap * 2, true)))
+        return rc;
+    if (!e->d_rftw) {
+        std::vector<double2> tw(nx);
+        for (int t = 0; t < nx; t++) { const double a = 2.0 * M_PI * t / nx; tw[t] = make_double2(cos(a), sin(a)); }
+        const double2 *p = nullptr;
+        if ((rc = upload(e, tw, &p))) return rc;
+        e->d_rftw = (double2 *)p;
+    }
+    e->rf_cap = cap;
+    return RA_OK;
+}
+
+static int forward_dft(ra_engine *e, const float *d_imgs, int nimg, const float *d_mask, const float *d_mean)
+{
+    const int nx = e->geo.nx;
+    hipLaunchKernelGGL(dft_rows_kernel, dim3(nimg, nx), dim3(64), 0, e->stream, nx, d_imgs, d_mask, d_mean, e->d_rftw, e->d_rfT);
+    RA_HIP(hipGetLastError());
+    hipLaunchKernelGGL(dft_cols_kernel<-1>, dim3(nimg, nx), dim3(64), 0, e->stream, nx, e->d_rfT, e->d_rftw, e->d_rfF);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_fsc_len(const ra_engine *e) { return e ? e->geo.nx / 2 + 1 : RA_ERR_ARG; }
+
+extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked, float *h_fsc)
+{
+    if (!e || !d_sums || !d_counts || !h_fsc) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    const int R = e->cfg.nref, nx = e->geo.nx, len = nx / 2 + 1;
+    int rc = ensure_refine_ws(e, 2 * R);
+    if (rc) return rc;
+    if (masked) {
+        hipLaunchKernelGGL(masked_mean_kernel, dim3(2 * R), dim3(256), 0, e->stream, nx * nx, d_sums, e->dg.mask, e->d_rfmean);
+        RA_HIP(hipGetLastError());
+    }
+    if ((rc = forward_dft(e, d_sums, 2 * R, masked ? e->dg.mask : nullptr, masked ? e->d_rfmean : nullptr))) return rc;
+    hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(64), 0, e->stream, nx, e->d_rfF, e->d_rffsc);
+    RA_HIP(hipGetLastError());
+    std::vector<float> all((size_t)R * 2 * len);
+    std::vector<int> counts(R);
+    RA_HIP(hipMemcpyAsync(all.data(), e->d_rffsc, all.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    RA_HIP(hipMemcpyAsync(counts.data(), d_counts, R * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    RA_HIP(hipStreamSynchronize(e->stream));
+    // average over the live classes as the reference does (ave_fsc / c_fsc; kept only if its sum is not 0)
+    std::vector<double> ave(len, 0.0);
+    int live = 0, last = -1;
+    for (int j = 0; j < R; j++) {
+        if (counts[j] < min_count) continue;
+        for (int i = 0; i < len; i++) ave[i] += all[((size_t)j * 2) * len + i];
+        live++; last = j;
+    }
+    if (live == 0) { g_last_error = "ra_class_fsc: every class is below min_count"; return RA_ERR_STATE; }
+    double tot = 0;
+    for (int i = 0; i < len; i++) tot += ave[i];
+    for (int i = 0; i < len; i++) {
+        h_fsc[i] = (float)((double)i / (2.0 * (nx / 2)));
+        h_fsc[len + i] = (tot != 0.0) ? (float)(ave[i] / live) : all[((size_t)last * 2) * len + i];
+        h_fsc[2 * len + i] = all[((size_t)last * 2 + 1) * len + i];
+    }
+    return RA_OK;
+}
+
+// sp_filter.fit_tanh(dres, low = 0.1) with sp_utilities.amoeba (simplex maximisation); host arithmetic in
+// double like the Python original.  fsc is edited in place (zeroed after its first drop below `low`).
+namespace {
+struct TanhFit {
+    const float *freq; float *fsc; int n;
+    double operator()(const double *a) const
+    {
+        double v = 0.0;
+        if (fsc[0] < 0.0f) fsc[0] *= -1.0f;
+        for (int i = 0; i < n; i++) {
+            const double r = fsc[i], f = 2 * r / (1.0 + r);
+            double qt = 0;
+            if (a[0] != 0 && a[1] != 0)
+                qt = f - 0.5 * (tanh(M_PI * (freq[i] + a[0]) / 2.0 / a[1] / a[0]) - tanh(M_PI * (freq[i] - a[0]) / 2.0 / a[1] / a[0]));
+            v -= qt * qt;
+        }
+        return v;
+    }
+};
+}  // namespace
+
+extern "C" int ra_fit_tanh(const float *freq, float *fsc, int n, float *fl, float *aa)
+{
+    if (!freq || !fsc || !fl || !aa || n < 3) { g_last_error = "bad argument"; return RA_ERR_ARG; }
+    const double low = 0.1;
+    bool setzero = false;
+    for (int i = 1; i < n; i++) {
+        if (!setzero && 2 * (double)fsc[i] / (1.0 + fsc[i]) < low) setzero = true;
+        if (setzero) fsc[i] = 0.0f;
+    }
+    double f0 = -1.0;
+    for (int i = 1; i < n - 1; i++)
+        if (2 * (double)fsc[i] / (1.0 + fsc[i]) < 0.5) { f0 = freq[i - 1]; break; }
+    if (f0 < 0.0) {
+        if (fsc[n - 1] < 0.5f) { *fl = 0.5f; *aa = 0.2f; } else { *fl = 0.49f; *aa = 0.1f; }
+        return RA_OK;
+    }
+    TanhFit func{freq, fsc, n};
+    const double scale[2] = {0.05, 0.05}, ftol = 1.e-4, xtol = 1.e-4;
+    double sx[3][2] = {{f0, 0.1}, {f0 + scale[0], 0.1}, {f0, 0.1 + scale[1]}}, fv[3];
+    for (int i = 0; i < 3; i++) fv[i] = func(sx[i]);
+    int iteration = 0, best = 0;
+    while (true) {
+        int worst = 0; best = 0;
+        for (int i = 0; i < 3; i++) { if (fv[i] > fv[best]) best = i; if (fv[i] < fv[worst]) worst = i; }
+        double pavg[2] = {0, 0};
+        for (int i = 0; i < 3; i++) if (i != worst) { pavg[0] += sx[i][0]; pavg[1] += sx[i][1]; }
+        pavg[0] /= 2; pavg[1] /= 2;
+        const double simscale = (fabs(pavg[0] - sx[worst][0]) / scale[0] + fabs(pavg[1] - sx[worst][1]) / scale[1]) / 2;
+        const double fscale = (fabs(fv[best]) + fabs(fv[worst])) / 2.0;
+        const double frange = fscale != 0.0 ? fabs(fv[best] - fv[worst]) / fscale : 0.0;
+        if ((frange < ftol && simscale < xtol) || iteration >= 500) break;
+        double pnew[2] = {2.0 * pavg[0] - sx[worst][0], 2.0 * pavg[1] - sx[worst][1]};
+        double fnew = func(pnew);
+        if (fnew <= fv[worst]) {           // worse than the worst: shrink towards the best
+            for (int i = 0; i < 3; i++)
+                if (i != best && i != worst) {
+                    sx[i][0] = 0.5 * sx[best][0] + 0.5 * sx[i][0]; sx[i][1] = 0.5 * sx[best][1] + 0.5 * sx[i][1];
+                    fv[i] = func(sx[i]);
+                }
+            pnew[0] = 0.5 * sx[best][0] + 0.5 * sx[worst][0]; pnew[1] = 0.5 * sx[best][1] + 0.5 * sx[worst][1];
+            fnew = func(pnew);
+        } else if (fnew >= fv[best]) {     // better than the best: try to expand
+            double p2[2] = {3.0 * pavg[0] - 2.0 * sx[worst][0], 3.0 * pavg[1] - 2.0 * sx[worst][1]};
+            const double f2 = func(p2);
+            if (f2 > fnew) { pnew[0] = p2[0]; pnew[1] = p2[1]; fnew = f2; }
+        }
+        sx[worst][0] = pnew[0]; sx[worst][1] = pnew[1]; fv[worst] = fnew;
+        iteration++;
+    }
+    *fl = (float)sx[best][0]; *aa = (float)sx[best][1];
+    return RA_OK;
+}
+
+extern "C" int ra_class_averages(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, float *d_refs)
+{
+    if (!e || !d_sums || !d_counts || !d_refs) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    hipLaunchKernelGGL(class_average_kernel, dim3(e->cfg.nref), dim3(256), 0, e->stream, e->geo.nx * e->geo.nx, d_sums, d_counts,
+                       min_count, d_refs);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
+                                    const float *h_cs_in, int normalize, float *h_cs_out)
+{
+    if (!e || !d_imgs || nimg < 1) { g_last_error = "bad argument"; return RA_ERR_ARG; }
+    if (center == -1 && !h_cs_in) { g_last_error = "center = -1 needs the shift list"; return RA_ERR_ARG; }
+    const int nx = e->geo.nx;
+    int rc = ensure_refine_ws(e, nimg);
+    if (rc) return rc;
+    if (center == -1) RA_HIP(hipMemcpyAsync(e->d_rfcs, h_cs_in, (size_t)nimg * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if ((rc = forward_dft(e, d_imgs, nimg, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(filter_center_kernel, dim3(nimg), dim3(256), 0, e->stream, nx, e->d_rfF, fl, aa, center,
+                       center == -1 ? e->d_rfcs : (const float *)nullptr, e->d_rfcs);
+    RA_HIP(hipGetLastError());
+    hipLaunchKernelGGL(dft_cols_kernel<1>, dim3(nimg, nx), dim3(64), 0, e->stream, nx, e->d_rfF, e->d_rftw, e->d_rfT);
+    RA_HIP(hipGetLastError());
+    hipLaunchKernelGGL(idft_rows_kernel, dim3(nimg, nx), dim3(128), 0, e->stream, nx, e->d_rfT, e->d_rftw, d_imgs);
+    RA_HIP(hipGetLastError());
+    if (normalize) {
+        hipLaunchKernelGGL(normalize_mask_kernel, dim3(nimg), dim3(256), 0, e->stream, nx * nx, e->dg.mask, d_imgs);
+        RA_HIP(hipGetLastError());
+    }
+    if (h_cs_out) {
+        RA_HIP(hipMemcpyAsync(h_cs_out, e->d_rfcs, (size_t)nimg * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        RA_HIP(hipStreamSynchronize(e->stream));
+    }
     return RA_OK;
 }
 

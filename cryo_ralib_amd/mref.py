@@ -8,9 +8,9 @@ AlignParam -> xform.align2d conversion (:578-588).  `RefFreeAligner` / `ali2d_ba
 mirror `ali2d_base_gpu_isac_CLEAN` (test_reffree_gpu_align.py:153-577).
 
 All heavy work is in the HIP engine (api.Engine); torch supplies device memory, the stream
-and the RCCL collective.  The FSC-driven low-pass filter and centring of the reference's
-`user_func` (:555) are not on the measured hot path and not built yet (SURVEY.md §8 f-1);
-`user_func=None` reproduces the reference run with an identity user function.
+and the RCCL collective.  `user_func="ref_ali2d"` runs the reference's default user function
+(--function=ref_ali2d, :1153: FSC-fitted tangent low-pass + centring, :531-563) on the device
+(SURVEY.md §8 f-1); `user_func=None` is an identity user function (what bench.py times).
 """
 import random
 
@@ -45,6 +45,7 @@ class MrefAligner:
         self.iteration = 0
         self.rng = random.Random(rand_seed)       # seed(rand_seed) on the main node (:352)
         self.class_sizes = []
+        self.filter_params, self.fsc_curves, self.centres = [], [], []     # per iteration, user_func="ref_ali2d"
         if preprocess:
             self._normalize_refs_all()
             self.engine.normalize_particles(self.particles)    # :342
@@ -79,13 +80,23 @@ class MrefAligner:
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
                                          self.buf.counts_i)
 
-    def reduce_and_update(self, user_func=None):
-        """cross-rank sum (:495-499) then the reference update every rank repeats (:517-575)."""
-        self.buf.all_reduce()
-        counts = self.buf.counts_i.cpu().numpy()
-        self.class_sizes.append(counts.copy())
-        vanished = [j for j in range(self.nref) if counts[j] < 4]
-        self.engine.update_references(self.buf.sums, self.buf.counts_i, self.refs, 4)
+    def _ref_ali2d(self, counts, vanished, center):
+        """the default user function on the device: fsc per class (:531), averaged (:537-548),
+        sp_user_functions.ref_ali2d = fit_tanh + clamps + filt_tanl + center_2D(center), normalize.mask (:563)"""
+        if len(vanished) == self.nref:
+            raise api.EngineError("every class vanished: no FSC to fit the filter to")
+        frsc = self.engine.class_fsc(self.buf.sums, self.buf.counts_i, 4, masked=False)
+        self.engine.class_averages(self.buf.sums, self.buf.counts_i, self.refs, 4)
+        self._reseed(vanished)
+        fl, aa = api.fit_tanh(frsc)
+        aa = min(aa, 0.2)
+        fl = max(min(0.4, fl), 0.12)
+        self.filter_params.append((fl, aa))
+        self.fsc_curves.append(frsc)
+        cs = self.engine.filter_references(self.refs, fl, aa, center=1 if center == 1 else 0, normalize=True)
+        self.centres.append(cs)
+
+    def _reseed(self, vanished):
         for j in vanished:
             # "if vanished, put a random image (only from main node!) there" (:523-528)
             k = self.rng.randint(0, self.n - 1)
@@ -93,6 +104,19 @@ class MrefAligner:
             if dist.dist.is_initialized() and dist.dist.get_world_size() > 1:
                 dist.dist.broadcast(img, src=self.main_node)
             self.refs[j].copy_(img)
+
+    def reduce_and_update(self, user_func=None, center=1):
+        """cross-rank sum (:495-499) then the reference update every rank repeats (:517-575)."""
+        self.buf.all_reduce()
+        counts = self.buf.counts_i.cpu().numpy()
+        self.class_sizes.append(counts.copy())
+        vanished = [j for j in range(self.nref) if counts[j] < 4]
+        if user_func == "ref_ali2d":
+            self._ref_ali2d(counts, vanished, center)
+            self.iteration += 1
+            return counts
+        self.engine.update_references(self.buf.sums, self.buf.counts_i, self.refs, 4)
+        self._reseed(vanished)
         if user_func is not None:
             self.refs = user_func(self.refs, self.buf, counts)
         if user_func is not None:
@@ -102,9 +126,9 @@ class MrefAligner:
         self.iteration += 1
         return counts
 
-    def iterate(self, user_func=None):
+    def iterate(self, user_func=None, center=1):
         self.search()
-        return self.reduce_and_update(user_func)
+        return self.reduce_and_update(user_func, center)
 
     def params(self):
         """per-particle (alpha, sx, sy, mirror, ref_id, peak) of the last search."""
@@ -123,14 +147,14 @@ class MrefAligner:
 
 
 def mref_ali2d_gpu(stack, refim, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, rand_seed=1000, device=0,
-                   index0=0, total_nima=None, user_func=None, chunk=0, on_iteration=None):
+                   index0=0, total_nima=None, user_func=None, chunk=0, on_iteration=None, center=1):
     """Multi-reference alignment of this rank's shard `stack` against `refim`
     (mirror of mref_ali2d_gpu, test_mref_gpu_align.py:222).  Returns
     (params records, class averages [R][nx][nx] numpy, list of class-size arrays)."""
     al = MrefAligner(stack, refim, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, rand_seed, True, chunk)
     max_iter = int(maxit) if int(maxit) > 0 else 10
     for it in range(max_iter):
-        counts = al.iterate(user_func)
+        counts = al.iterate(user_func, center)
         if on_iteration is not None:
             on_iteration(it, al, counts)
     al.engine.sync()
@@ -166,6 +190,7 @@ class RefFreeAligner:
         self.cs = [0.0, 0.0]
         self.iteration = 0
         self.criteria = []
+        self.filter_params = []
 
     def _sum_oe_raw(self):
         # iteration 0: plain even/odd sums of the raw particles (sum_oe, :365)
@@ -175,7 +200,10 @@ class RefFreeAligner:
         self.buf.sums[0, 1] = self.particles[par == 1].sum(0)
         self.buf.counts_i[0] = self.n
 
-    def iterate(self, center=0):
+    def iterate(self, center=0, user_func=None):
+        """one iteration of ali2d_base_gpu_isac_CLEAN (:361-540).  user_func="ref_ali2d": fsc_mask (:384),
+        the tangent filter, and the centring of the average (fshift by the average centre for center=-1,
+        :403-410; center_2D method for center > 0) on the device; None keeps the raw average."""
         if self.iteration == 0:
             self._sum_oe_raw()
         self.buf.all_reduce()
@@ -185,9 +213,20 @@ class RefFreeAligner:
         self.criteria.append(a1)
         cs = [0.0, 0.0]
         if center == -1 and self.iteration > 0:
-            # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410); the fshift of tavg by -cs
-            # belongs to the reference-update row f-1 and is not built yet
+            # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410); with user_func the average is
+            # shifted by -cs on the device (fshift), the particle parameters are corrected inside ra_align
             cs = [float(self.buf.extra_f[0].item()) / self.total_nima, float(self.buf.extra_f[1].item()) / self.total_nima]
+        if user_func == "ref_ali2d":
+            frsc = self.engine.class_fsc(self.buf.sums, self.buf.counts_i, 1, masked=True)
+            fl, aa = api.fit_tanh(frsc)
+            aa = min(aa, 0.2)
+            fl = max(min(0.4, fl), 0.12)
+            self.filter_params.append((fl, aa))
+            if center == -1:
+                self.engine.filter_references(self.tavg, fl, aa, center=-1, cs_in=[cs], normalize=False)
+            else:
+                got = self.engine.filter_references(self.tavg, fl, aa, center=1 if center == 1 else 0, normalize=False)
+                cs = [float(got[0, 0]), float(got[0, 1])]
         self.cs = cs
         self.engine.set_references(self.tavg)
         self.engine.align(self.particles, self.state, self.result, cs if (cs[0] or cs[1]) else None)
@@ -210,12 +249,12 @@ class RefFreeAligner:
 
 
 def ali2d_base_gpu(stack, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, device=0, index0=0, total_nima=None,
-                   center=0, chunk=0):
+                   center=0, chunk=0, user_func=None):
     """mirror of ali2d_base_gpu_isac_CLEAN; returns (params records, final average, criteria).
     Rows of initial2Dparams.txt are (alpha, sx, sy, mirror) (test_reffree_gpu_align.py:561-569)."""
     al = RefFreeAligner(stack, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, False, chunk)
     for _ in range(int(maxit)):
-        al.iterate(center)
+        al.iterate(center, user_func)
     al.engine.sync()
     out = al.params().copy(), al.tavg[0].cpu().numpy(), al.criteria
     al.close()

@@ -162,6 +162,27 @@ int  ra_normalize_particles(ra_engine *e, float *d_particles, int n);
  * spectra of every search offset in EMAN2 packing, h_out [n][num_shifts][lcirc] (what
  * Polar2Dm -> Normalize_ring -> Frngs leave in `cimage` inside Util.multiref_polar_ali_2d) */
 int  ra_debug_spectra(ra_engine *e, const float *d_particles, int n, const float *d_state, float *h_out);
+/* ---- reference update of one iteration on the device (what the reference's main node does on the
+ * CPU, test_mref_gpu_align.py:517-564 / test_reffree_gpu_align.py:374-429, default user function) */
+/* length of an FSC curve: nx/2 + 1 */
+int  ra_fsc_len(const ra_engine *e);
+/* sp_statistics.fsc (masked = 0, :531) or fsc_mask (masked = 1, test_reffree_gpu_align.py:384) between
+ * the even and odd sums of every class with count >= min_count, averaged over those classes (:537-548).
+ * h_fsc [3][ra_fsc_len]: frequencies, fsc, points per shell (host). */
+int  ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked,
+                  float *h_fsc);
+/* sp_filter.fit_tanh(dres, low=0.1): host arithmetic; fsc is edited in place like the original. */
+int  ra_fit_tanh(const float *freq, float *fsc, int n, float *fl, float *aa);
+/* (even + odd) / count without normalisation (:534-535); classes below min_count untouched */
+int  ra_class_averages(ra_engine *e, const float *d_sums, const int *d_counts, int min_count,
+                       float *d_refs);
+/* sp_user_functions.ref_ali2d body on nimg device images, in place: filt_tanl(fl, aa) (fl <= 0: no
+ * filter), center_2D: center = 1 phase_cog + fshift, center = -1 fshift by -h_cs_in[i] (average-centre
+ * rule, test_reffree_gpu_align.py:403-410), center = 0 none; then normalize.mask(no_sigma=1) under
+ * model_circle(last_ring) if normalize != 0 (:563).  h_cs_out [nimg][2] (may be NULL) = applied centres. */
+int  ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
+                          const float *h_cs_in, int normalize, float *h_cs_out);
+
 /* block until the engine's stream is idle */
 int  ra_sync(ra_engine *e);
 

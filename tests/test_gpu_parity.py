@@ -472,10 +472,21 @@ def test_command_line_entry_points(tmp_path):
     stackio.write_stack(str(tmp_path / "refs.mrcs"), refs)
     out = tmp_path / "out"
     assert cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out), "--ou=12", "--xr=2",
-                          "--yr=2", "--maxit=3"]) == 0
+                          "--yr=2", "--maxit=3", "--function=none"]) == 0
     rows = np.loadtxt(out / "params.txt")
     assert rows.shape == (n, 6) and (rows[:, 5].astype(int) == truth["cls"]).mean() > 0.98
     assert stackio.read_stack(str(out / "aqm002.mrcs")).shape == (nref, nx, nx)
+    # default --function=ref_ali2d --center=1: FSC-fitted tangent filter + centring of every average on the device
+    out1 = tmp_path / "out1"
+    assert cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out1), "--ou=12", "--xr=2",
+                          "--yr=2", "--maxit=3"]) == 0
+    rows1 = np.loadtxt(out1 / "params.txt")
+    acc = (rows1[:, 5].astype(int) == truth["cls"]).mean()
+    print("class recovery with ref_ali2d:", acc)
+    assert rows1.shape == (n, 6) and acc > 0.8
+    assert np.isfinite(stackio.read_stack(str(out1 / "aqm002.mrcs"))).all()
+    with pytest.raises(SystemExit):
+        cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out1), "--function=my_func"])
     out2 = tmp_path / "out2"
     assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
                              "--center=0"]) == 0
@@ -570,3 +581,95 @@ def test_large_box_search_transform_and_sums(nx, ou, xr, nref, n):
 
 def test_large_box_polar_stage_bin_for_bin():
     polar_stage_check(128, 50, 2, api.RA_MODE_MREF, n=2, rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference update on the device against oracle/refine_oracle.py
+
+def _searched_aligner(nx=90, ou=36, nref=5, xr=3, n=400, sigma=1.0):
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
+    al = MrefAligner(parts, refs, ou, xr, xr, 1.0, preprocess=True)
+    al.search()
+    al.buf.all_reduce()
+    return al
+
+
+def test_class_fsc_and_tangent_filter_against_oracle():
+    from oracle import refine_oracle as ro
+    al = _searched_aligner()
+    sums = al.buf.sums.cpu().numpy()
+    counts = al.buf.counts_i.cpu().numpy()
+    mask = geometry.model_circle(al.ou, al.nx, al.nx)
+    assert (counts >= 4).all()
+    # fsc per class, averaged over the classes (test_mref_gpu_align.py:531-548)
+    got = al.engine.class_fsc(al.buf.sums, al.buf.counts_i, 4, masked=False)
+    per = [ro.fsc(sums[j, 0], sums[j, 1]) for j in range(al.nref)]
+    want = np.mean([p[1] for p in per], axis=0)
+    np.testing.assert_allclose(got[0], per[0][0], atol=1e-7)
+    np.testing.assert_allclose(got[1], want, atol=2e-5)
+    np.testing.assert_allclose(got[2], per[-1][2], atol=0)
+    # fsc_mask (test_reffree_gpu_align.py:384)
+    gotm = al.engine.class_fsc(al.buf.sums, al.buf.counts_i, 4, masked=True)
+    wantm = np.mean([ro.fsc_mask(sums[j, 0], sums[j, 1], mask)[1] for j in range(al.nref)], axis=0)
+    np.testing.assert_allclose(gotm[1], wantm, atol=2e-5)
+    # class averages, tangent filter, phase_cog centring, normalize.mask
+    avg = torch.zeros_like(al.refs)
+    al.engine.class_averages(al.buf.sums, al.buf.counts_i, avg, 4)
+    a = avg.cpu().numpy()
+    for j in range(al.nref):
+        np.testing.assert_allclose(a[j], (sums[j, 0] + sums[j, 1]) * np.float32(1.0 / counts[j]), rtol=0, atol=1e-6)
+    for center in (0, 1):
+        x = avg.clone()
+        cs = al.engine.filter_references(x, 0.17, 0.15, center=center, normalize=True)
+        x = x.cpu().numpy()
+        for j in range(al.nref):
+            t = ro.filt_tanl(a[j], 0.17, 0.15)
+            c = (0.0, 0.0)
+            if center:
+                c = ro.phase_cog(t)
+                t = ro.fshift(t, -c[0], -c[1])
+            t = ro.normalize_mask(t, mask)
+            assert abs(cs[j, 0] - c[0]) < 1e-3 and abs(cs[j, 1] - c[1]) < 1e-3
+            assert np.abs(x[j] - t).max() < 2e-4 * np.abs(t).max()
+    # fshift by a given centre (the reference-free average-centre rule), no filter, no normalisation
+    x = avg[:1].clone()
+    al.engine.filter_references(x, 0.0, 0.0, center=-1, cs_in=[[1.25, -0.5]], normalize=False)
+    t = ro.fshift(a[0], -1.25, 0.5)
+    assert np.abs(x[0].cpu().numpy() - t).max() < 2e-5 * np.abs(t).max()
+    al.close()
+
+
+def test_mref_iteration_with_default_user_function():
+    """MrefAligner.iterate(user_func="ref_ali2d") = the reference's per-iteration update (:517-564)"""
+    from oracle import refine_oracle as ro
+    al = _searched_aligner(n=600)
+    sums = al.buf.sums.cpu().numpy()
+    counts = al.buf.counts_i.cpu().numpy()
+    mask = geometry.model_circle(al.ou, al.nx, al.nx)
+    want, curve, (fl, aa), css = ro.mref_reference_update(sums, counts, mask, center=1)
+    al.reduce_and_update("ref_ali2d", center=1)
+    got = al.refs.cpu().numpy()
+    gfl, gaa = al.filter_params[-1]
+    assert abs(gfl - fl) < 5e-5 and abs(gaa - aa) < 5e-5, (gfl, gaa, fl, aa)
+    assert 0.12 <= gfl <= 0.4 and gaa <= 0.2
+    np.testing.assert_allclose(al.centres[-1], css, atol=2e-3)
+    for j in range(al.nref):
+        assert np.abs(got[j] - want[j]).max() < 5e-4 * np.abs(want[j]).max(), j
+    # the filtered, centred references are what the next search uses
+    al.iterate("ref_ali2d", center=1)
+    assert np.isfinite(al.refs.cpu().numpy()).all()
+    al.close()
+
+
+def test_reffree_driver_with_user_function_and_average_centring():
+    nx, ou, xr, n = 64, 25, 2, 300
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    al = RefFreeAligner(parts, ou, xr, xr, 1.0)
+    for it in range(4):
+        al.iterate(center=-1, user_func="ref_ali2d")
+    assert len(al.filter_params) == 4 and all(0.12 <= f <= 0.4 and a <= 0.2 for f, a in al.filter_params)
+    assert np.isfinite(al.tavg.cpu().numpy()).all()
+    assert al.criteria[-1] > al.criteria[0]
+    al.close()

@@ -135,3 +135,62 @@ def test_cli_flags_match_reference():
                  "--mode", "--random_method"):
         assert '"%s"' % flag in src, flag
     assert cli._first("4 2 1 1") == 4.0 and cli._first(3) == 3.0
+
+
+def test_fit_tanh_matches_the_python_restatement():
+    """ra_fit_tanh (C++, in the product library; pure host arithmetic) against oracle/refine_oracle.fit_tanh
+    on FSC curves of different shapes, including the early-exit branches"""
+    import math
+    from cryo_ralib_amd import api
+    from oracle import refine_oracle as ro
+    n = 46
+    freq = [i / (2.0 * (n - 1)) for i in range(n)]
+
+    def halfset(full):      # the fit converts half-set fsc r to 2r/(1+r): invert so that the fitted curve is `full`
+        return [f / (2.0 - f) for f in full]
+
+    curves = []
+    for fl, aa in ((0.15, 0.1), (0.25, 0.3), (0.08, 0.2), (0.35, 0.05)):
+        full = [0.5 * (math.tanh(math.pi * (f + fl) / 2.0 / aa / fl) - math.tanh(math.pi * (f - fl) / 2.0 / aa / fl)) for f in freq]
+        curves.append(halfset(full))
+    curves.append([1.0] * n)                              # never falls: (0.49, 0.1)
+    curves.append([0.9] * (n - 1) + [0.2])                # falls only at the last point: (0.5, 0.2)
+    rng = __import__("numpy").random.default_rng(3)
+    noisy = [max(-0.2, min(1.0, c + 0.05 * rng.standard_normal())) for c in curves[0]]
+    noisy[0] = -0.3                                       # the sign flip of the first point
+    curves.append(noisy)
+    for c in curves:
+        a = [list(freq), [float(__import__("numpy").float32(v)) for v in c], [2.0] * n]
+        b = [list(a[0]), list(a[1]), list(a[2])]
+        want = ro.fit_tanh(a)
+        got = api.fit_tanh(b)
+        assert abs(got[0] - want[0]) < 2e-5 and abs(got[1] - want[1]) < 2e-5, (got, want)
+        assert max(abs(x - y) for x, y in zip(a[1], b[1])) < 1e-7      # same in-place edit of the curve
+
+
+def test_refine_oracle_known_properties():
+    """the numpy restatement of fsc / filt_tanl / phase_cog / fshift behaves as the definitions say"""
+    import numpy as np
+    from oracle import refine_oracle as ro
+    rng = np.random.default_rng(5)
+    nx = 32
+    a = rng.standard_normal((nx, nx)).astype(np.float32)
+    f = ro.fsc(a, a)
+    assert len(f[0]) == nx // 2 + 1 and abs(f[0][-1] - 0.5) < 1e-12
+    assert all(abs(v - 1.0) < 1e-6 for v in f[1])                      # identical halves correlate perfectly
+    b = rng.standard_normal((nx, nx)).astype(np.float32)
+    assert max(abs(v) for v in ro.fsc(a, b)[1][3:]) < 0.6              # independent noise does not
+    # tangent filter: DC passes, Nyquist is suppressed; pinned formula of cuda/gpu_aln_noref.cu:799-814
+    h = ro.tanl_filter_values(nx, 0.12, 0.2)
+    assert abs(h[0, 0] - 1.0) < 1e-3 and h[0, nx // 2] < 1e-3
+    # a blob displaced from the centre by (+3, -2): phase_cog finds it, fshift(-cs) puts it back
+    yy, xx = np.mgrid[0:nx, 0:nx]
+    blob = np.exp(-((xx - nx // 2 - 3) ** 2 + (yy - nx // 2 + 2) ** 2) / 18.0).astype(np.float32)
+    cs = ro.phase_cog(blob)
+    assert abs(cs[0] - 3) < 0.05 and abs(cs[1] + 2) < 0.05
+    back = ro.fshift(blob, -cs[0], -cs[1])
+    c2 = ro.phase_cog(back)
+    assert abs(c2[0]) < 1e-3 and abs(c2[1]) < 1e-3
+    # amoeba maximises
+    best, val, _ = ro.amoeba([0.0, 0.0], [0.5, 0.5], lambda p, d: -((p[0] - 1) ** 2 + (p[1] + 2) ** 2))
+    assert abs(best[0] - 1) < 1e-2 and abs(best[1] + 2) < 1e-2
