@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--xr", type=float, default=3.0)
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--function", default="ref_ali2d", help="reference preparation per iteration: ref_ali2d (the "
+                    "reference's default --function: FSC-fitted tangent filter + centring, on the device) | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -138,13 +140,14 @@ def main():
     # the run starts from the generating references; every step re-estimates them from the data
     al = MrefAligner(particles, refs_np, ou, xr, xr, 1.0, device=local, index0=rank * n, total_nima=n * world,
                      preprocess=True, chunk=args.chunk)
+    user_func = None if args.function in ("none", "None", "") else args.function
     for _ in range(args.warmup):
-        al.iterate()
+        al.iterate(user_func, 1)
     al.engine.kernel_time(True)          # arm HIP-event timing of the hot kernels on the engine's stream
     rdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        al.iterate()
+        al.iterate(user_func, 1)
     rdist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = rdist.max_over_ranks(dt, dev)
@@ -174,9 +177,9 @@ def main():
             "value": total / dt, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d synthetic %dx%d particles per GPU, nref=%d, xr=yr=%g, ts=1, "
-                                   "ou=%d; step = one mref_ali2d iteration (search + rot_shift2D + class sums + "
-                                   "all-reduce + reference update)" % (
+            "config": {"workload": ("%s: %d synthetic %dx%d particles per GPU, nref=%d, xr=yr=%g, ts=1, "
+                                    "ou=%d; step = one mref_ali2d iteration (search + rot_shift2D + class sums + "
+                                    "all-reduce + reference update with --function=" + str(args.function) + ")") % (
                                        "BASELINE configs[1]" if (nx, ou, nref, xr) == (90, 36, 10, 3.0) else "custom", n, nx, nx, nref, xr, ou),
                        "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
