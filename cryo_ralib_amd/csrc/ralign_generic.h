@@ -96,7 +96,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
                                                                       float *__restrict__ out)
 {
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *bx = reinterpret_cast<float2 *>(lds) + (size_t)wave * g.maxrin;     // two buffers of maxrin/2 complex
     float2 *by = bx + g.maxrin / 2;
     const int npix = g.nx * g.nx;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
     extern __shared__ __align__(16) float lds[];
     __shared__ CandT pc[64];
     const int N = g.maxrin;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_GCCF_THREADS / 64;
     float2 *zs = zscr + (size_t)blockIdx.x * 64 * N;
     float2 *xb = reinterpret_cast<float2 *>(lds);

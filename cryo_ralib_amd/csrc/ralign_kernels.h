@@ -380,7 +380,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
     float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);      // [n_inst]
     float *red = instw_s + g.n_inst;    // [8] -, [8] avg / rsigma, [8] centres, [4*nring*2] ring partials
     const int p = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwave = blockDim.x >> 6;
     if (p >= n) return;
 
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
     __shared__ CandT pc[64];
     const int mtile = blockIdx.x;
     if (mtile >= n_mtile) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_CCF_THREADS / 64;
 
     // twiddles e^{+2 pi i n0 j / N} of the first FFT pass, [n0][j] in LDS (lane j reads column j)
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
     int *aoff_s = reinterpret_cast<int *>(instw_s + g.f_n_inst);        // [f_nstep]
     float *red = reinterpret_cast<float *>(aoff_s + g.f_nstep);         // as in polar_fft_kernel
     const int p = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwave = blockDim.x >> 6;
     if (p >= n) return;
 
