@@ -201,10 +201,15 @@ static int build_device_geometry(ra_engine *e)
         auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
         for (int i = 0; i < g.nring && !e->generic; i++)
             if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
+        // job code 6: 256-sample rings with 8 lanes per ring (16 sample pairs per lane, two 8-point rows per lane in
+        // the second FFT pass) instead of 16 lanes with half of them idle there (RALIGN_POLAR_R16=0: the old split)
+        const bool r16 = !(getenv("RALIGN_POLAR_R16") && atoi(getenv("RALIGN_POLAR_R16")) == 0);
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
-            const int lanes_of[6] = {16, 8, 8, 4, 4, 4};
+            const int lanes_of[8] = {16, 8, 8, 4, 4, 4, 8, 4};
+            const bool r8 = !(getenv("RALIGN_POLAR_R8") && atoi(getenv("RALIGN_POLAR_R8")) == 0);   // 64-sample rings: 4 lanes x 8 pairs
             for (int lg = 8; lg >= 3; lg--) {
-                const int n = 1 << lg, code = code_of(n);
+                const int n = 1 << lg;
+                const int code = (n == 256 && r16 && nslot == 4) ? 6 : ((n == 64 && r8 && nslot == 4) ? 7 : code_of(n));
                 std::vector<int4> cls;
                 std::vector<float> clsw;
                 for (int sft = 0; sft < nslot; sft++)

@@ -110,8 +110,10 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
 __device__ __forceinline__ float bilinear_pad(const float *base, int st, float xold, float yold)
 {
 #pragma clang fp contract(off)
+    // coordinates are >= 1 inside the padded image: x - floor(x) (v_fract_f32, exact) equals the oracle's
+    // xold - (float)(int)xold bit for bit and saves the int -> float round trip
     const int ix = (int)xold, iy = (int)yold;
-    const float ydif = yold - iy, xdif = xold - ix;
+    const float ydif = __builtin_amdgcn_fractf(yold), xdif = __builtin_amdgcn_fractf(xold);
     const float *p = base + (__mul24(iy, st) + ix);     // 24-bit multiply: full-rate VALU
     const float f00 = p[0], f10 = p[1], f01 = p[st], f11 = p[st + 1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
@@ -331,16 +333,27 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         *reinterpret_cast<float2 *>(buf + 2 * (LR * c + ((t + c) & (LR - 1)))) = o;
     }
     RA_WAVE_SYNC();
-    float2 z[LR];
-    if (t < R1) {
+    // second pass: the R1 rows of the LR-point transforms are dealt to the LR lanes of the ring
+    // (one row per lane when R1 <= LR, R1/LR rows per lane otherwise: no idle half-groups)
+    constexpr int NROW = (R1 + LR - 1) / LR;
+    float2 z[NROW][LR];
 #pragma unroll
-        for (int b = 0; b < LR; b++) z[b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * t + ((b + t) & (LR - 1))));
-        Dft<-1, LR>::run(z);
+    for (int m = 0; m < NROW; m++) {
+        const int row = t + LR * m;
+        if (row < R1) {
+#pragma unroll
+            for (int b = 0; b < LR; b++) z[m][b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * row + ((b + row) & (LR - 1))));
+            Dft<-1, LR>::run(z[m]);
+        }
     }
     RA_WAVE_SYNC();
-    if (t < R1) {
 #pragma unroll
-        for (int e = 0; e < LR; e++) *reinterpret_cast<float2 *>(buf + 2 * (t + R1 * e)) = z[e];
+    for (int m = 0; m < NROW; m++) {
+        const int row = t + LR * m;
+        if (row < R1) {
+#pragma unroll
+            for (int e = 0; e < LR; e++) *reinterpret_cast<float2 *>(buf + 2 * (row + R1 * e)) = z[m][e];
+        }
     }
     RA_WAVE_SYNC();
     // split step X_k <- (Z_k, Z_{H-k}), k = 0..H/2, in place; X_0 and X_H are real
@@ -415,6 +428,8 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
                 case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 6: ring_job<16, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 7: ring_job<8, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 }
             }
