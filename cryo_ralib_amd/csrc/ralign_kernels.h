@@ -115,7 +115,7 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
 __device__ __forceinline__ float bilinear_pad(const float *base, int st, float xold, float yold)
 {
 #pragma clang fp contract(off)
-    // coordinates are >= 1 inside the padded image: x - floor(x) (v_fract_f32, exact) equals the oracle's
+    // coordinates are >= 1 inside the padded image: x - floor(x) (v_fract_f32, exact) equals the CPU path's
     // xold - (float)(int)xold bit for bit and saves the int -> float round trip
     const int ix = (int)xold, iy = (int)yold;
     const float ydif = __builtin_amdgcn_fractf(yold), xdif = __builtin_amdgcn_fractf(xold);
