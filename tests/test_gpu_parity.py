@@ -696,3 +696,39 @@ def test_row_tile_contraction_path(monkeypatch):
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
     compare_search(got, st.cpu().numpy(), params, infos, d)
     polar_stage_check(90, 36, 3, api.RA_MODE_MREF)
+
+
+@pytest.mark.parametrize("cfg", [
+    # nx, ou, ir, rs, xr, yr, ts, nref, n, mode
+    dict(nx=91, ou=36, ir=1, rs=1, xr=3, yr=3, ts=1.0, nref=3, n=24, mode=api.RA_MODE_MREF),      # odd box
+    dict(nx=90, ou=36, ir=3, rs=1, xr=2, yr=2, ts=1.0, nref=2, n=24, mode=api.RA_MODE_MREF),      # inner radius > 1
+    dict(nx=90, ou=36, ir=1, rs=2, xr=2, yr=1, ts=1.0, nref=2, n=24, mode=api.RA_MODE_MREF),      # every second ring
+    dict(nx=64, ou=28, ir=1, rs=1, xr=1, yr=1, ts=0.5, nref=17, n=20, mode=api.RA_MODE_MREF),     # 17 references: 3 tiles of 6, half-pixel steps
+    dict(nx=48, ou=20, ir=1, rs=1, xr=0, yr=0, ts=1.0, nref=9, n=20, mode=api.RA_MODE_MREF),      # rotation-only search
+    dict(nx=90, ou=40, ir=1, rs=1, xr=3, yr=3, ts=1.0, nref=1, n=24, mode=api.RA_MODE_REFFREE),   # single reference, ormq rules
+    dict(nx=128, ou=60, ir=5, rs=1, xr=2, yr=2, ts=1.0, nref=2, n=6, mode=api.RA_MODE_MREF),      # generic kernels, ir > 1
+], ids=lambda c: "nx%d_ou%d_ir%d_rs%d_R%d" % (c["nx"], c["ou"], c["ir"], c["rs"], c["nref"]))
+def test_geometry_sweep_against_oracle(cfg):
+    """ring ranges, odd boxes, ring skips, fractional steps, reference counts around the tile sizes"""
+    nx, ou, nref, n = cfg["nx"], cfg["ou"], cfg["nref"], cfg["n"]
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, int(cfg["xr"]), int(cfg["yr"]), 0.25, ou=ou)
+    rg = orc.rings(cfg["ir"], ou, cfg["rs"])
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask, rg)
+    d = np.zeros((n, 2), np.float32)
+    if cfg["mode"] == api.RA_MODE_MREF:
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, cfg["xr"], cfg["yr"], cfg["ts"], d, nthreads=8)
+    else:
+        params = np.zeros((n, 6), np.float32)
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, cfg["xr"], cfg["yr"], cfg["ts"], (0, 0), d, params, nthreads=8)
+    eng = api.Engine(nx, ou, cfg["xr"], cfg["yr"], cfg["ts"], nref, cfg["mode"], first_ring=cfg["ir"], ring_skip=cfg["rs"])
+    eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    got = eng.prepared_references()
+    assert np.abs(got - cref).max() < 1e-6 * np.abs(cref).max()
+    tp = torch.from_numpy(parts).to(eng.dev)
+    st, res = eng.new_state(n), eng.new_result(n)
+    eng.align(tp, st, res)
+    eng.sync()
+    compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    eng.close()
