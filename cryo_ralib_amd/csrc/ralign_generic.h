@@ -195,7 +195,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
             const int ref0 = rtile * g.rpt;
             const int nvalid = min(g.rpt, nref - ref0);
             // ---- phase 1: contraction per Fourier bin (same operand layout as ccf_kernel)
-            {
+            if (!(g.dbg & 2)) {
                 const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
                 const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
                 const float *Bt = B + (size_t)rtile * g.LBP * 16;
@@ -206,14 +206,23 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                     const float *pa = Ablk + (size_t)e0 * 8, *pb = Bt + (size_t)e0 * 16;
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     int oa = 0, ob = 0;
-                    for (int q = 0; q < (ns >> 2); q++) {
-                        const float4 va = *reinterpret_cast<const float4 *>(pa + oa + la * 4);
-                        const float4 vb = *reinterpret_cast<const float4 *>(pb + ob + lb * 4);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc, 0, 0, 0);
-                        oa += 128; ob += 256;
+                    const int nq = ns >> 2;
+                    if (nq > 0) {      // chunks of 4 ring steps, the next chunk's operands in flight while this one multiplies
+                        float4 va = *reinterpret_cast<const float4 *>(pa + la * 4);
+                        float4 vb = *reinterpret_cast<const float4 *>(pb + lb * 4);
+                        for (int q = 0; q < nq; q++) {
+                            float4 na = va, nb = vb;
+                            if (q + 1 < nq) {
+                                na = *reinterpret_cast<const float4 *>(pa + oa + 128 + la * 4);
+                                nb = *reinterpret_cast<const float4 *>(pb + ob + 256 + lb * 4);
+                            }
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc, 0, 0, 0);
+                            va = na; vb = nb;
+                            oa += 128; ob += 256;
+                        }
                     }
                     if (ns & 2) {
                         const float2 va = *reinterpret_cast<const float2 *>(pa + oa + la * 2);
@@ -235,10 +244,26 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
             }
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax, P pairs per batch, one wave per pair
+            if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
+                CandT c; c.val = 0.f; c.jtot = 1; c.refmir = min(ref0 + (tid & 7), nref - 1);
+                for (int k = 0; k < 7; k++) c.t7[k] = 0.f;
+                pc[tid] = c;
+            }
+            if (!(g.dbg & 1))
             for (int base = 0; base < 64; base += P) {
-                for (int idx = tid; idx < P * N; idx += RA_GCCF_THREADS) {
-                    const int k = idx / P, pp = idx - k * P;
-                    xb[(size_t)pp * pstride + k] = zs[(size_t)k * 64 + base + pp];
+                // scratch [k][64 pairs] -> LDS [pair][k]: 8 independent loads per thread in flight
+                for (int idx0 = tid; idx0 < P * N; idx0 += 8 * RA_GCCF_THREADS) {
+                    float2 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int idx = idx0 + u * RA_GCCF_THREADS;
+                        if (idx < P * N) { const int k = idx / P, pp = idx - k * P; t[u] = zs[(size_t)k * 64 + base + pp]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int idx = idx0 + u * RA_GCCF_THREADS;
+                        if (idx < P * N) { const int k = idx / P, pp = idx - k * P; xb[(size_t)pp * pstride + k] = t[u]; }
+                    }
                 }
                 __syncthreads();
                 for (int pp = wave; pp < P; pp += NW) {
