@@ -158,13 +158,13 @@ def main():
         # gfx950 + WRITE_SIZE, per particle), scaled to this run's particles per launch
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_v6_pmc_summary.json")) as f:
                 pm = json.load(f)
             if (nx, ou, nref) == (90, 36, 10):
-                per_particle = pm["kernels"]["ralign::ccf_kernel<256>"]["hbm_bytes_per_dispatch_corrected"] / \
-                    pm["particles_per_dispatch"]
+                key = [k for k in pm["kernels"] if "ccf_kernel<256>" in k][0]
+                per_particle = pm["kernels"][key]["hbm_bytes_per_dispatch_corrected"] / pm["particles_per_dispatch"]
                 traffic = per_particle * (n * args.steps / max(n_ccf, 1))
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         total = n * world * args.steps
         polar_f, ccf_f, S, L, M = algorithmic_flops(nx, ou, xr, xr, 1.0, nref)
