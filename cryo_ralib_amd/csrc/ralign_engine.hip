@@ -16,7 +16,6 @@
 #include "ralign_kernels.h"
 #include "ralign_generic.h"
 #include "ralign_refine.h"
-#include "ralign_rowtile.h"
 
 using namespace ralign;
 
@@ -62,8 +61,6 @@ struct ra_engine {
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0, lds_fused = 0;
     float *d_Bf = nullptr;              // [f_nchunk][f_bchunk] unit-major reference stream of the fused kernel
     bool fused = false;                 // RALIGN_FUSED=1: particle-resident single-kernel search
-    bool rowtile = false;               // row-tile contraction (ralign_rowtile.h): one sweep over the spectra for 9..~14 references
-    size_t lds_row = 0;
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
@@ -153,7 +150,6 @@ static int build_device_geometry(ra_engine *e)
         }
     }
     build_operand_tables(g, sbuf);
-    build_row_tables(g);
 
     // FFT work lists
     std::vector<int4> A, B, C;
@@ -349,15 +345,6 @@ static int build_device_geometry(ra_engine *e)
         d.ent_apos = reinterpret_cast<const int2 *>(tmp_p);
     }
     if ((rc = upload(e, g.bin_first, &d.bin_first))) return rc;
-    {
-        const int *t1, *t2, *t3;
-        if ((rc = upload(e, g.rt_went, &t1)) || (rc = upload(e, g.rt_wmeta, &t2)) || (rc = upload(e, g.rt_apos, &t3))) return rc;
-        d.rt_went = reinterpret_cast<const int4 *>(t1);
-        d.rt_wmeta = reinterpret_cast<const int2 *>(t2);
-        d.rt_apos = reinterpret_cast<const int2 *>(t3);
-        d.rt_nwent = (int)(g.rt_wmeta.size() / 2);
-        d.rt_ablk = g.LBP * 16 + 64;
-    }
     // shift tables are sized for the create-time window; ra_reset_shifts rewrites them
     std::vector<float> sx(g.shift_x), sy(g.shift_y);
     if ((rc = upload(e, sx, &d.shift_x))) return rc;
@@ -408,18 +395,6 @@ static ccf_fn select_ccf(int maxrin)
     case 128: return ccf_kernel<128>;
     case 64: return ccf_kernel<64>;
     case 32: return ccf_kernel<32>;
-    default: return nullptr;
-    }
-}
-
-typedef void (*ccf_row_fn)(DevGeom, const float *, const float *, int, int, int, CandT *);
-static ccf_row_fn select_ccf_row(int maxrin)
-{
-    switch (maxrin) {
-    case 256: return ccf_row_kernel<256>;
-    case 128: return ccf_row_kernel<128>;
-    case 64: return ccf_row_kernel<64>;
-    case 32: return ccf_row_kernel<32>;
     default: return nullptr;
     }
 }
@@ -484,17 +459,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->nrtile = (cfg->nref + 7) / 8;
     e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
     if (getenv("RALIGN_RPT8")) e->dg.rpt = 8;
-    {   // row-tile path: a whole grid row (<= 8 offsets) x two reference tiles must fit the LDS image of the CCF
-        // spectra, and it must save a sweep over the particle spectra compared with the 8 x 8 tiles
-        const int OB = 2 * e->geo.nkx + 1;
-        e->dg.rt_on = 0;
-        e->dg.rt_ob = OB; e->dg.rt_nblk = 2 * e->geo.nky + 1; e->dg.rt_nsweep = (e->nrtile + 1) / 2;
-        // measured on MI355X (H config): contraction 4.59 -> 4.31 ms per launch, but the polar stage pays 0.5 ms for
-        // the row-aligned passes (4 + 3 offsets) and the 16-row write-out, so the path is opt-in (RALIGN_ROWTILE=1)
-        const bool want = getenv("RALIGN_ROWTILE") && atoi(getenv("RALIGN_ROWTILE")) != 0;
-        if (!e->generic && want && OB <= 8 && e->nrtile == 2 && OB * 2 * e->dg.rpt <= RA_ROW_MAXPAIRS - 2) e->dg.rt_on = 1;
-        e->rowtile = e->dg.rt_on != 0;
-    }
     int rc = build_device_geometry(e);
     if (rc) { ra_destroy(e); return rc; }
 
@@ -512,7 +476,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         ra_destroy(e);
         return RA_ERR_ARG;
     }
-    e->lds_row = (size_t)e->dg.rt_ob * 2 * e->dg.rpt * (2 * (g.maxrin + g.maxrin / 16) + 2) * sizeof(float);
     e->xf_generic = e->lds_xf > lds_max;
     // generic contraction: P pairs per inverse-FFT batch, two N-point buffers per pair
     e->g_P = 64;
@@ -524,7 +487,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
-        if (he == hipSuccess && e->rowtile) he = hipFuncSetAttribute((const void *)select_ccf_row(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_row);
         if (he == hipSuccess && e->dg.f_on) he = hipFuncSetAttribute((const void *)select_fused(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_fused);
     } else {
         he = hipFuncSetAttribute((const void *)polar_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
@@ -545,8 +507,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if ((size_t)chunk > cap) chunk = (int)(cap & ~(size_t)1);
     }
     e->chunk = chunk;
-    const size_t a_floats = std::max(((size_t)chunk * ngroup + 2) * e->dg.a_blk, ((size_t)chunk * e->dg.rt_nblk + 1) * e->dg.rt_ablk);
-    const size_t cand_recs = std::max(((size_t)chunk * g.nshift_pad + 8) * e->nrtile, ((size_t)chunk * e->dg.rt_nblk + 1) * 8 * e->dg.rt_nsweep);
+    const size_t a_floats = ((size_t)chunk * ngroup + 2) * e->dg.a_blk;
+    const size_t cand_recs = ((size_t)chunk * g.nshift_pad + 8) * e->nrtile;
     if ((rc = dev_alloc(e, &e->d_A, a_floats, true)) ||
         (rc = dev_alloc(e, &e->d_cand, cand_recs, true)) ||
 
@@ -635,7 +597,6 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
     e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad;
     e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
-    e->dg.rt_ob = 2 * g2.nkx + 1; e->dg.rt_nblk = 2 * g2.nky + 1;      // the row layout follows the window (it can only shrink)
     return RA_OK;
 }
 
@@ -773,16 +734,13 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (e->generic)
             hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sc, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P);
-        else if (e->rowtile)
-            hipLaunchKernelGGL(select_ccf_row(g.maxrin), dim3(cn * e->dg.rt_nblk), dim3(RA_CCF_THREADS), e->lds_row, sc, e->dg, Abuf,
-                               e->d_B, cn * e->dg.rt_nblk, e->nrtile, e->cfg.nref, Cbuf);
         else
             hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sc, e->dg, Abuf, e->d_B, n_mtile,
                                e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
         if (evc) RA_HIP(hipEventRecord(evc->second, sc));
-        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sc, e->dg, Cbuf,
-                           e->rowtile ? e->dg.rt_nsweep : e->nrtile, cn, st, d_result + start, e->d_cs);
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sc, e->dg, Cbuf, e->nrtile,
+                           cn, st, d_result + start, e->d_cs);
         RA_HIP(hipGetLastError());
         if (ov) RA_HIP(hipEventRecord(e->ev_ccf_done[b], sc));
     }

@@ -34,10 +34,6 @@ struct Geometry {
     std::vector<int> a_src;        // [LBP*8]  see build_operand_tables
     std::vector<int> b_src;        // [LBP*16]
     std::vector<int> ent_apos;     // [LB*2] {A-block float offset of entry e at row 0, chunk width}
-    // row layout (16 operand rows per block, ralign_rowtile.h)
-    std::vector<int> rt_went;      // [n*4] ring-buffer offsets of the rings of every (bin, kk, chunk) entry, -1 = padding
-    std::vector<int> rt_wmeta;     // [n*2] {float offset of row 0 in the block, chunk width}
-    std::vector<int> rt_apos;      // [LB*2] as ent_apos for the 16-row block
     // search offsets
     int nkx = 0, nky = 0, nshift = 0, nshift_pad = 0;
     float step = 1.f;
@@ -169,47 +165,6 @@ inline void build_operand_tables(Geometry &g, int sbuf)
                 g.b_src[(size_t)g.bin_offp[k] * 16 + panel_pos(ns, 16, kk, col, s)] = (e << 4) | col;
         }
     }
-}
-
-// write-out table of the row layout: one entry per (bin k, MFMA k-slot kk, chunk of <= 4 ring steps)
-inline void build_row_tables(Geometry &g)
-{
-    g.rt_went.clear(); g.rt_wmeta.clear();
-    g.rt_apos.assign((size_t)g.LB * 2, 0);
-    for (int k = 0; k < g.nbins; k++) {
-        const int cnt = g.bin_off[k + 1] - g.bin_off[k], ns = (g.bin_offp[k + 1] - g.bin_offp[k]) / 4;
-        for (int kk = 0; kk < 4; kk++) {
-            int s0 = 0;
-            while (s0 < ns) {
-                const int w = (ns - s0 >= 4) ? 4 : ((ns - s0 >= 2) ? 2 : 1);
-                int src[4] = {-1, -1, -1, -1};
-                for (int j = 0; j < w; j++) {
-                    const int ring_j = kk * ns + s0 + j;      // index of the ring among those that hold bin k
-                    if (ring_j < cnt) src[j] = g.ent_src[g.bin_off[k] + ring_j];
-                }
-                for (int j = 0; j < 4; j++) g.rt_went.push_back(src[j]);
-                g.rt_wmeta.push_back(g.bin_offp[k] * 16 + panel_pos(ns, 16, kk, 0, s0));
-                g.rt_wmeta.push_back(w);
-                s0 += w;
-            }
-        }
-        for (int j = 0; j < cnt; j++) {
-            const int kk = j / ns, s = j % ns, e = g.bin_off[k] + j;
-            g.rt_apos[2 * e] = g.bin_offp[k] * 16 + panel_pos(ns, 16, kk, 0, s);
-            g.rt_apos[2 * e + 1] = panel_pos(ns, 16, kk, 1, s) - panel_pos(ns, 16, kk, 0, s);
-        }
-    }
-    // widest chunks first: the threads of a wave then take the same store width
-    const size_t n = g.rt_wmeta.size() / 2;
-    std::vector<size_t> order(n);
-    for (size_t i = 0; i < n; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return g.rt_wmeta[2 * a + 1] > g.rt_wmeta[2 * b + 1]; });
-    std::vector<int> we(n * 4), wm(n * 2);
-    for (size_t i = 0; i < n; i++) {
-        for (int j = 0; j < 4; j++) we[i * 4 + j] = g.rt_went[order[i] * 4 + j];
-        wm[i * 2] = g.rt_wmeta[order[i] * 2]; wm[i * 2 + 1] = g.rt_wmeta[order[i] * 2 + 1];
-    }
-    g.rt_went.swap(we); g.rt_wmeta.swap(wm);
 }
 
 // search offsets in Util::multiref_polar_ali_2d order (y outer, x inner), full window

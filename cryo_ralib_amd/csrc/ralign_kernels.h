@@ -40,11 +40,6 @@ struct DevGeom {
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
     int rpt;                      // references per tile of the contraction (<= 8, balanced over the tiles)
-    // row-tile path (ralign_rowtile.h): A blocks hold one row of the search grid, two reference tiles per sweep
-    int rt_on, rt_ob, rt_nblk, rt_ablk, rt_nsweep, rt_nwent;
-    const int4 *rt_went;          // [rt_nwent] ring-buffer offsets of the <= 4 rings of a (bin, kk, chunk) entry, -1 = padding
-    const int2 *rt_wmeta;         // [rt_nwent] {float offset of row 0 in the 16-row block, chunk width}
-    const int2 *rt_apos;          // [LB] {offset of entry e at row 0 in the 16-row block, row stride}
     int n_class;                  // bins with the same ring-slot count ns form contiguous classes
     int class_k0[8], class_ns[8]; // class c = bins [class_k0[c], class_k0[c+1]) ; class_k0[n_class] = nbins
     int class_k0_end;
@@ -290,7 +285,6 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (sub >= count) return;
     const int4 in = inst_s[inst0 + sub];
     const int slot = in.x & 255, ring = in.x >> 8;
-    if (slot >= __float_as_int(red[0])) return;      // offsets beyond the live ones of this pass
     float *buf = bufs + slot * sbuf + in.y;
     const float rad = (float)in.w, wt = instw_s[inst0 + sub];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
@@ -384,9 +378,6 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (t == 0) { red[24 + 2 * (slot * g.nring + ring)] = av; red[25 + 2 * (slot * g.nring + ring)] = sq; }
 }
 
-__device__ __forceinline__ void write_rows(const DevGeom &g, const float *bufs, const float *rsg, float *__restrict__ Ablk,
-                                           int row0, int nlive, int tid, int nthreads);     // ralign_rowtile.h
-
 __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
                                                                      const float *__restrict__ state, int n,
                                                                      float *__restrict__ A)
@@ -419,19 +410,12 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
 
-    // passes of 4 search offsets.  Row layout (ralign_rowtile.h): a pass never straddles two rows of the search
-    // grid -- a row of OB <= 8 offsets is done as offsets 0..3 then 4..OB-1 -- so that every pass writes whole
-    // 128-byte lines of its A block.
-    const int ngroup = g.rt_on ? 2 * g.rt_nblk : g.nshift_pad / 4;
+    const int ngroup = g.nshift_pad / 4;
     for (int grp = 0; grp < ngroup; grp++) {
-        const int o0 = g.rt_on ? (grp >> 1) * g.rt_ob + 4 * (grp & 1) : grp * 4;         // first offset of the pass
-        const int nlive = g.rt_on ? min(4, g.rt_ob - 4 * (grp & 1)) : min(4, g.nshift - o0);
-        if (nlive <= 0) continue;
         if (tid < 4) {
-            int si = min(o0 + min(tid, nlive - 1), g.nshift - 1);
+            int si = min(grp * 4 + tid, g.nshift - 1);
             red[16 + 2 * tid] = cxf + g.shift_x[si];
             red[17 + 2 * tid] = cyf + g.shift_y[si];
-            if (tid == 0) red[0] = __int_as_float(g.rt_on ? nlive : 4);
         }
         __syncthreads();
         if (!(g.dbg & 16)) {
@@ -476,10 +460,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
         __syncthreads();
         // write-out through the gather table: 4 consecutive ring slots of one (bin, row) per thread
         float4 *dstA = reinterpret_cast<float4 *>(A + ((size_t)p * ngroup + grp) * g.a_blk);
-        if (g.rt_on) {
-            if (!(g.dbg & 64))
-                write_rows(g, bufs, red + 12, A + ((size_t)p * g.rt_nblk + (grp >> 1)) * g.rt_ablk, 8 * (grp & 1), nlive, tid, blockDim.x);
-        } else if (!(g.dbg & 64))
+        if (!(g.dbg & 64))
         for (int q = tid; q < g.LBP * 2; q += blockDim.x) {
             const int4 sidx = g.a_src4[q];
             auto fetch = [&](int idx) -> float {
@@ -568,17 +549,16 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
     const int m = blockIdx.x;                  // particle * nshift + shift
     const int p = m / g.nshift, sft = m - p * g.nshift;
     if (p >= n) return;
-    const float *blk = g.rt_on ? A + ((size_t)p * g.rt_nblk + sft / g.rt_ob) * g.rt_ablk
-                               : A + ((size_t)p * (g.nshift_pad / 4) + (sft >> 2)) * g.a_blk;
+    const float *blk = A + ((size_t)p * (g.nshift_pad / 4) + (sft >> 2)) * g.a_blk;
     float *dst = out + (size_t)m * g.lcirc;
-    const int row0 = g.rt_on ? (sft % g.rt_ob) * 2 : (sft & 3) * 2;
+    const int row0 = (sft & 3) * 2;
     for (int i = 0; i < g.nring; i++) {
         const int nlen = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
         for (int j = threadIdx.x; j < nlen; j += blockDim.x) {
             // packed slot j: 0 -> Re X0, 1 -> Re X(n/2), 2k -> Re Xk, 2k+1 -> Im Xk
             const int k = (j == 0) ? 0 : (j == 1 ? nlen / 2 : j >> 1), comp = (j < 2) ? 0 : (j & 1);
             const int e = g.bin_off[k] + (i - g.bin_first[k]);
-            const int2 ap = g.rt_on ? g.rt_apos[e] : g.ent_apos[e];
+            const int2 ap = g.ent_apos[e];
             dst[o + j] = blk[ap.x + (row0 + comp) * ap.y];
         }
     }
@@ -949,7 +929,6 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
     for (int i = tid; i < g.f_n_job; i += blockDim.x) jobs_s[i] = g.f_jobs[i];
     for (int i = tid; i < g.f_nstep; i += blockDim.x) aoff_s[i] = g.f_aoff[i];
     for (int i = tid; i < 2 * g.f_sbuf; i += blockDim.x) bufs[i] = 0.f;   // the slack behind the last ring stays zero
-    if (tid == 0) red[0] = __int_as_float(4);      // ring_job: all offset slots of a pass are live
     if (tid == 0) red[22] = 0.f;      // a runtime zero: per-phase lane arithmetic derived from it cannot be hoisted out of the pass loop
     const float sx0 = state[2 * p], sy0 = state[2 * p + 1];
     const Window w = particle_window(g, sx0, sy0);
@@ -1158,8 +1137,7 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
         if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
         for (int rt = 0; rt < nrtile; rt++) {
-            const CandT *c = g.rt_on ? cand + (((size_t)p * g.rt_nblk + s / g.rt_ob) * 8 + s % g.rt_ob) * nrtile + rt
-                                     : cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
+            const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
             const float v = c->val;
             if (v >= peak) { peak = v; best = *c; bs = s; }
         }

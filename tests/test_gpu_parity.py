@@ -675,29 +675,6 @@ def test_reffree_driver_with_user_function_and_average_centring():
     al.close()
 
 
-def test_row_tile_contraction_path(monkeypatch):
-    """opt-in row-tile path (ralign_rowtile.h: one sweep over the particle spectra for 10 references, A blocks hold a
-    row of the search grid): same answers as the default path, and as the oracle, including the polar stage"""
-    nx, ou, nref, xr, n = 90, 36, 10, 3, 128
-    refs = synth.make_references(nref, nx, ou)
-    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
-    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
-    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
-    base = api.Engine.result_to_numpy(res).copy()
-    eng.close()
-    monkeypatch.setenv("RALIGN_ROWTILE", "1")
-    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, chunk=50)
-    got = api.Engine.result_to_numpy(res).copy()
-    eng.close()
-    for f in ("ref_id", "mirror", "angle_bin", "shift_idx"):
-        assert (base[f] == got[f]).all(), f
-    assert (np.abs(base["peak"] - got["peak"]) / np.abs(base["peak"])).max() < 1e-5
-    d = np.zeros((n, 2), np.float32)
-    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
-    compare_search(got, st.cpu().numpy(), params, infos, d)
-    polar_stage_check(90, 36, 3, api.RA_MODE_MREF)
-
-
 @pytest.mark.parametrize("cfg", [
     # nx, ou, ir, rs, xr, yr, ts, nref, n, mode
     dict(nx=91, ou=36, ir=1, rs=1, xr=3, yr=3, ts=1.0, nref=3, n=24, mode=api.RA_MODE_MREF),      # odd box
