@@ -35,7 +35,7 @@ def _common(p):
     p.add_argument("--gpu_info", action="store_true")
     p.add_argument("--MPI", action="store_true")
     p.add_argument("--EQ", action="store_true")
-    p.add_argument("--ext", default="mrcs", help="format of the written stacks: mrcs | npy | hdf")
+    p.add_argument("--ext", default="hdf", help="format of the written stacks: hdf (EMAN2 MDF, as the reference) | mrcs | npy")
 
 
 def _first(v):

@@ -5,8 +5,8 @@ test_mref_gpu_align.py:1358-1375) and writes class averages with `write_image`
 (:564).  Without EMAN2 the engine accepts:
   * `.npy`            float32 [n][ny][nx]
   * `.mrc` / `.mrcs`  MRC2014 mode-2 stacks (EMAN2 / RELION read and write these)
-  * `.hdf`            EMAN2 MDF layout `/MDF/images/<i>/image` -- only when `h5py` is
-                      importable (it is not in the build image)
+  * `.hdf` / `.h5`    EMAN2 MDF layout `/MDF/images/<i>/image`, read and written by the dependency-free
+                      HDF5 subset implementation in `mdfio.py`
 Parameter rows follow the reference's text outputs: `idx angle_psi shift_x shift_y mirror class`
 (notebook/03 cell 6) and `alpha sx sy mirror` for initial2Dparams.txt
 (test_reffree_gpu_align.py:561-569).
@@ -52,29 +52,13 @@ def _write_mrc(path, arr):
 
 
 def _read_hdf(path):
-    try:
-        import h5py
-    except ImportError as e:
-        raise RuntimeError("%s: reading EMAN2 HDF stacks needs h5py, which is not installed; convert the stack "
-                           "to .mrcs (e2proc2d.py in.hdf out.mrcs) or .npy" % path) from e
-    with h5py.File(path, "r") as f:
-        imgs = f["MDF"]["images"]
-        n = len([k for k in imgs.keys() if k.isdigit()])
-        return np.stack([np.asarray(imgs[str(i)]["image"], np.float32) for i in range(n)])
+    from . import mdfio
+    return mdfio.read_mdf_stack(path)
 
 
 def _write_hdf(path, arr):
-    try:
-        import h5py
-    except ImportError as e:
-        raise RuntimeError("%s: writing EMAN2 HDF stacks needs h5py; use .mrcs or .npy" % path) from e
-    with h5py.File(path, "w") as f:
-        g = f.create_group("MDF").create_group("images")
-        g.attrs["imageid_max"] = arr.shape[0] - 1
-        for i, img in enumerate(arr):
-            gi = g.create_group(str(i))
-            gi.create_dataset("image", data=np.asarray(img, np.float32))
-            gi.attrs["EMAN.nx"], gi.attrs["EMAN.ny"], gi.attrs["EMAN.nz"] = img.shape[-1], img.shape[-2], 1
+    from . import mdfio
+    mdfio.write_mdf_stack(path, arr)
 
 
 def read_stack(path):

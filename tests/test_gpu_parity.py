@@ -463,7 +463,8 @@ def test_full_size_properties():
 
 
 def test_command_line_entry_points(tmp_path):
-    """the named entry points end to end on .mrcs stacks: outputs exist, classes are recovered"""
+    """the named entry points end to end (.mrcs inputs, EMAN2-MDF .hdf outputs like the reference): outputs exist,
+    classes are recovered"""
     from cryo_ralib_amd import cli, stackio
     nx, ou, nref, xr, n = 32, 12, 3, 2, 120
     refs = synth.make_references(nref, nx, ou)
@@ -475,7 +476,7 @@ def test_command_line_entry_points(tmp_path):
                           "--yr=2", "--maxit=3", "--function=none"]) == 0
     rows = np.loadtxt(out / "params.txt")
     assert rows.shape == (n, 6) and (rows[:, 5].astype(int) == truth["cls"]).mean() > 0.98
-    assert stackio.read_stack(str(out / "aqm002.mrcs")).shape == (nref, nx, nx)
+    assert stackio.read_stack(str(out / "aqm002.hdf")).shape == (nref, nx, nx)
     # default --function=ref_ali2d --center=1: FSC-fitted tangent filter + centring of every average on the device
     out1 = tmp_path / "out1"
     assert cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out1), "--ou=12", "--xr=2",
@@ -484,7 +485,7 @@ def test_command_line_entry_points(tmp_path):
     acc = (rows1[:, 5].astype(int) == truth["cls"]).mean()
     print("class recovery with ref_ali2d:", acc)
     assert rows1.shape == (n, 6) and acc > 0.8
-    assert np.isfinite(stackio.read_stack(str(out1 / "aqm002.mrcs"))).all()
+    assert np.isfinite(stackio.read_stack(str(out1 / "aqm002.hdf"))).all()
     with pytest.raises(SystemExit):
         cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out1), "--function=my_func"])
     out2 = tmp_path / "out2"

@@ -114,11 +114,11 @@ def test_stack_io_round_trip(tmp_path):
     from cryo_ralib_amd import stackio
     rng = np.random.default_rng(0)
     a = rng.normal(size=(5, 12, 12)).astype(np.float32)
-    for ext in ("npy", "mrcs"):
+    for ext in ("npy", "mrcs", "hdf"):
         p = str(tmp_path / ("s." + ext))
         stackio.write_stack(p, a)
         np.testing.assert_array_equal(stackio.read_stack(p), a)
-    with pytest.raises((RuntimeError, ValueError)):
+    with pytest.raises((RuntimeError, ValueError, OSError)):
         stackio.read_stack(str(tmp_path / "missing.hdf"))
     stackio.write_text_rows(str(tmp_path / "p.txt"), [(0, 1.968414, 1.102456, 2.963881, 0, 0)])
     row = open(tmp_path / "p.txt").read().split()
@@ -194,3 +194,51 @@ def test_refine_oracle_known_properties():
     # amoeba maximises
     best, val, _ = ro.amoeba([0.0, 0.0], [0.5, 0.5], lambda p, d: -((p[0] - 1) ** 2 + (p[1] + 2) ** 2))
     assert abs(best[0] - 1) < 1e-2 and abs(best[1] + 2) < 1e-2
+
+
+def test_mdf_hdf5_reader_on_a_file_written_by_libhdf5(golden_dir):
+    """tests/golden/eman2_mdf_sample.hdf was produced with the HDF5 C library (make_hdf_fixture.c): 37 images in the
+    EMAN2 MDF layout (more than one symbol-table node per group), value(i, y, x) = 1000 i + 16 y + x + 0.25"""
+    import os
+    import numpy as np
+    from cryo_ralib_amd import mdfio, stackio
+    path = os.path.join(golden_dir, "eman2_mdf_sample.hdf")
+    a, attrs = mdfio.read_mdf_stack(path, with_attrs=True)
+    assert a.shape == (37, 10, 12) and a.dtype == np.float32
+    i, y, x = np.mgrid[0:37, 0:10, 0:12]
+    assert np.array_equal(a, (1000 * i + 16 * y + x + 0.25).astype(np.float32))
+    assert attrs[5]["EMAN.nx"] == 12 and attrs[5]["EMAN.ny"] == 10 and attrs[5]["EMAN.ptcl_repr"] == 2
+    assert abs(float(attrs[36]["EMAN.apix_x"]) - 1.25) < 1e-7
+    assert np.array_equal(stackio.read_stack(path), a)
+
+
+def test_mdf_hdf5_writer_round_trip_and_libhdf5_check(tmp_path):
+    """the writer's files read back bit for bit; where the HDF5 command line tools exist (the build container's
+    /opt/conda) the real library must list every object and print the same pixels"""
+    import shutil
+    import subprocess
+    import numpy as np
+    from cryo_ralib_amd import mdfio, stackio
+    rng = np.random.default_rng(11)
+    for n in (1, 9, 70, 1300):                      # 1 .. several B-tree levels at the library's default node sizes
+        arr = rng.standard_normal((n, 6, 5)).astype(np.float32)
+        path = str(tmp_path / ("s%d.hdf" % n))
+        stackio.write_stack(path, arr)
+        assert np.array_equal(stackio.read_stack(path), arr)
+        h5ls = shutil.which("h5ls") or "/opt/conda/bin/h5ls"
+        h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+        if not (shutil.os.path.exists(h5ls) and shutil.os.path.exists(h5dump)):
+            continue
+        out = subprocess.run([h5ls, path + "/MDF/images"], capture_output=True, text=True)
+        assert out.returncode == 0 and len(out.stdout.strip().splitlines()) == n, out.stderr
+        out = subprocess.run([h5dump, "-d", "/MDF/images/%d/image" % (n - 1), "-y", "-w", "0", path], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        body = out.stdout.split("DATA {")[1].split("}")[0].replace("\\n", " ")
+        vals = np.array([float(v) for v in body.replace(",", " ").split()], np.float32)
+        np.testing.assert_allclose(vals, arr[n - 1].ravel(), rtol=1e-5, atol=1e-6)
+        out = subprocess.run([h5dump, "-a", "/MDF/images/imageid_max", path], capture_output=True, text=True)
+        assert out.returncode == 0 and ("(0): %d" % (n - 1)) in out.stdout
+    with __import__("pytest").raises(mdfio.HDF5FormatError):
+        p = tmp_path / "bad.hdf"
+        p.write_bytes(b"not hdf5" * 100)
+        mdfio.read_mdf_stack(str(p))
