@@ -44,13 +44,6 @@ struct ra_engine {
     std::vector<void *> owned;          // device allocations freed at destroy
     float *d_A = nullptr;               // [chunk * ngroup + 2][a_blk]
     CandT *d_cand = nullptr;             // [(chunk * nshift_pad + 8)][nrtile]
-    // second workspace + auxiliary stream: the polar kernel of chunk i+1 (VALU/LDS-bound) runs
-    // beside the contraction kernel of chunk i (HBM-bound) instead of behind it
-    float *d_A2 = nullptr;
-    CandT *d_cand2 = nullptr;
-    hipStream_t s_aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_polar_done[2] = {nullptr, nullptr}, ev_ccf_done[2] = {nullptr, nullptr};
-    bool overlap = false;               // RALIGN_OVERLAP=1 (measured: no net gain on MI355X)
     float *d_refspec = nullptr;         // [nref][lring]
     float *d_B = nullptr;               // [nrtile][LBP][16]
     float *d_cs = nullptr;              // [2]
@@ -202,14 +195,13 @@ static int build_device_geometry(ra_engine *e)
         for (int i = 0; i < g.nring && !e->generic; i++)
             if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
         // job code 6: 256-sample rings with 8 lanes per ring (16 sample pairs per lane, two 8-point rows per lane in
-        // the second FFT pass) instead of 16 lanes with half of them idle there (RALIGN_POLAR_R16=0: the old split)
-        const bool r16 = !(getenv("RALIGN_POLAR_R16") && atoi(getenv("RALIGN_POLAR_R16")) == 0);
+        // the second FFT pass) instead of 16 lanes with half of them idle there; code 7 does the same for 64-sample rings
+        // (4 lanes x 8 pairs).  Measured: polar stage 5.64 -> 5.2 ms per 7143 particles.
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
             const int lanes_of[8] = {16, 8, 8, 4, 4, 4, 8, 4};
-            const bool r8 = !(getenv("RALIGN_POLAR_R8") && atoi(getenv("RALIGN_POLAR_R8")) == 0);   // 64-sample rings: 4 lanes x 8 pairs
             for (int lg = 8; lg >= 3; lg--) {
                 const int n = 1 << lg;
-                const int code = (n == 256 && r16 && nslot == 4) ? 6 : ((n == 64 && r8 && nslot == 4) ? 7 : code_of(n));
+                const int code = (n == 256 && nslot == 4) ? 6 : ((n == 64 && nslot == 4) ? 7 : code_of(n));
                 std::vector<int4> cls;
                 std::vector<float> clsw;
                 for (int sft = 0; sft < nslot; sft++)
@@ -458,7 +450,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     }
     e->nrtile = (cfg->nref + 7) / 8;
     e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
-    if (getenv("RALIGN_RPT8")) e->dg.rpt = 8;
     int rc = build_device_geometry(e);
     if (rc) { ra_destroy(e); return rc; }
 
@@ -526,21 +517,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     e->fused = !e->generic && e->dg.f_on && getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) != 0;
     if (e->dg.f_on && (rc = dev_alloc(e, &e->d_Bf, (size_t)e->dg.f_nchunk * e->dg.f_bchunk, true))) { ra_destroy(e); return rc; }
-    e->overlap = getenv("RALIGN_OVERLAP") && atoi(getenv("RALIGN_OVERLAP")) != 0;
-    if (e->overlap && ((rc = dev_alloc(e, &e->d_A2, a_floats, true)) ||
-                       (rc = dev_alloc(e, &e->d_cand2, cand_recs, true)))) {
-        ra_destroy(e);
-        return rc;
-    }
-    {
-        hipError_t he2 = hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking);
-        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-        for (int i = 0; i < 2 && he2 == hipSuccess; i++) {
-            he2 = hipEventCreateWithFlags(&e->ev_polar_done[i], hipEventDisableTiming);
-            if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&e->ev_ccf_done[i], hipEventDisableTiming);
-        }
-        if (he2 != hipSuccess) { g_last_error = std::string("stream/event creation: ") + hipGetErrorString(he2); ra_destroy(e); return RA_ERR_HIP; }
-    }
     *out = e;
     return RA_OK;
 }
@@ -551,12 +527,6 @@ extern "C" void ra_destroy(ra_engine *e)
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     for (void *p : e->owned) (void)hipFree(p);
-    if (e->s_aux) (void)hipStreamDestroy(e->s_aux);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    for (int i = 0; i < 2; i++) {
-        if (e->ev_polar_done[i]) (void)hipEventDestroy(e->ev_polar_done[i]);
-        if (e->ev_ccf_done[i]) (void)hipEventDestroy(e->ev_ccf_done[i]);
-    }
     for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -696,18 +666,11 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         }
         return RA_OK;
     }
-    const bool ov = e->overlap && n > e->chunk;
-    hipStream_t sp = e->stream, sc = ov ? e->s_aux : e->stream;
-    if (ov) {
-        RA_HIP(hipEventRecord(e->ev_fork, sp));
-        RA_HIP(hipStreamWaitEvent(sc, e->ev_fork, 0));
-    }
-    int ci = 0;
-    for (int start = 0; start < n; start += e->chunk, ci++) {
+    hipStream_t sp = e->stream;
+    for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
-        const int b = ov ? (ci & 1) : 0;
-        float *Abuf = b ? e->d_A2 : e->d_A;
-        CandT *Cbuf = b ? e->d_cand2 : e->d_cand;
+        float *Abuf = e->d_A;
+        CandT *Cbuf = e->d_cand;
         const float *part = d_particles + (size_t)start * npix;
         float *st = d_state + (size_t)start * 2;
         std::pair<hipEvent_t, hipEvent_t> *evp = nullptr, *evc = nullptr;
@@ -715,8 +678,6 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             evp = next_events(e->ev_polar, e->ev_used_polar);
             evc = next_events(e->ev_ccf, e->ev_used_ccf);
         }
-        // the polar kernel of this chunk may not overwrite a workspace the contraction of chunk ci-2 still reads
-        if (ov && ci >= 2) RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[b], 0));
         if (evp) RA_HIP(hipEventRecord(evp->first, sp));
         if (e->generic)
             hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
@@ -725,28 +686,19 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
-        if (ov) {
-            RA_HIP(hipEventRecord(e->ev_polar_done[b], sp));
-            RA_HIP(hipStreamWaitEvent(sc, e->ev_polar_done[b], 0));
-        }
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
-        if (evc) RA_HIP(hipEventRecord(evc->first, sc));
+        if (evc) RA_HIP(hipEventRecord(evc->first, sp));
         if (e->generic)
-            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sc, e->dg,
+            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P);
         else
-            hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sc, e->dg, Abuf, e->d_B, n_mtile,
+            hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sp, e->dg, Abuf, e->d_B, n_mtile,
                                e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
-        if (evc) RA_HIP(hipEventRecord(evc->second, sc));
-        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sc, e->dg, Cbuf, e->nrtile,
+        if (evc) RA_HIP(hipEventRecord(evc->second, sp));
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, Cbuf, e->nrtile,
                            cn, st, d_result + start, e->d_cs);
         RA_HIP(hipGetLastError());
-        if (ov) RA_HIP(hipEventRecord(e->ev_ccf_done[b], sc));
-    }
-    if (ov) {   // join: later work on the engine's stream sees every chunk finished
-        RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[0], 0));
-        if (ci >= 2) RA_HIP(hipStreamWaitEvent(sp, e->ev_ccf_done[1], 0));
     }
     (void)ngroup;
     return RA_OK;
