@@ -471,8 +471,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     // generic contraction: P pairs per inverse-FFT batch, two N-point buffers per pair
     e->g_P = 64;
     while (e->g_P > 1 && (size_t)e->g_P * (2 * g.maxrin + 1) * sizeof(float2) > 128 * 1024) e->g_P >>= 1;
-    e->lds_gccf = (size_t)e->g_P * (2 * g.maxrin + 1) * sizeof(float2);
-    e->lds_gpolar = (size_t)(RA_GEN_THREADS / 64) * g.maxrin * sizeof(float2);
+    e->lds_gccf = ((size_t)e->g_P * (2 * g.maxrin + 1) + g.maxrin) * sizeof(float2);      // pair buffers + twiddle table
+    e->lds_gpolar = (size_t)(RA_GEN_THREADS / 64 + 1) * g.maxrin * sizeof(float2);      // per-wave ring buffers + twiddle table
     hipError_t he = hipSuccess;
     if (!e->generic) {
         he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);

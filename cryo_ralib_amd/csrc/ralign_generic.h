@@ -99,6 +99,9 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *bx = reinterpret_cast<float2 *>(lds) + (size_t)wave * g.maxrin;     // two buffers of maxrin/2 complex
     float2 *by = bx + g.maxrin / 2;
+    float2 *tw_s = reinterpret_cast<float2 *>(lds) + (size_t)(RA_GEN_THREADS / 64) * g.maxrin;      // twiddle table in LDS
+    for (int i = tid; i < g.maxrin; i += RA_GEN_THREADS) tw_s[i] = g.tw[i];
+    __syncthreads();
     const int npix = g.nx * g.nx;
 
     if (REFS) {
@@ -112,10 +115,10 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
             float *xr = reinterpret_cast<float *>(bx);
             for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + c, g.samp_dy[kc + j] + c);
             wave_lds_sync();
-            const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, g.tw, g.maxrin, lane) : bx;
+            const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
             float *dst = out + (size_t)r * g.lring + ri.x;
             for (int k = lane; k <= h; k += 64) {
-                const float2 X = split_bin(Z, k, h, g.tw[k * (g.maxrin / nlen)]);
+                const float2 X = split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]);
                 dst[2 * k] = X.x; dst[2 * k + 1] = X.y;
             }
             wave_lds_sync();
@@ -158,10 +161,10 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
         float *xr = reinterpret_cast<float *>(bx);
         for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
         wave_lds_sync();
-        const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, g.tw, g.maxrin, lane) : bx;
+        const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
         const float dc = avg * (float)nlen;
         for (int k = lane; k <= h; k += 64) {
-            float2 X = split_bin(Z, k, h, g.tw[k * (g.maxrin / nlen)]);
+            float2 X = split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]);
             // Normalize_ring after the (linear) FFT: X_0 -= avg * n, then the common scale 1/sigma
             if (k == 0) X.x -= dc;
             X.x *= rsg; X.y *= rsg;
@@ -189,6 +192,9 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
     float2 *zs = zscr + (size_t)blockIdx.x * 64 * N;
     float2 *xb = reinterpret_cast<float2 *>(lds);
     const int pstride = 2 * N + 1;          // complex slots per pair: two N-point buffers + 1 (bank skew)
+    float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
+    for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
+    __syncthreads();
 
     for (int mtile = blockIdx.x; mtile < n_mtile; mtile += gridDim.x) {
         for (int rtile = 0; rtile < nrtile; rtile++) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                     const int pair = base + pp, slot = pair & 7;
                     if (slot >= nvalid) continue;           // wave-uniform
                     float2 *x = xb + (size_t)pp * pstride;
-                    const float2 *r = wave_fft<1>(x, x + N, N, g.tw, N, lane);
+                    const float2 *r = wave_fft<1>(x, x + N, N, tw_s, N, lane);
                     float bq = -1.0e20f, bt = -1.0e20f;
                     int iq = 0, it = 0;
                     for (int j = lane; j < N; j += 64) {     // ascending: ">=" keeps the last maximum
