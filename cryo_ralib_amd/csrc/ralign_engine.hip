@@ -226,6 +226,12 @@ static int build_device_geometry(ra_engine *e)
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
+    // row stride of the padded LDS image: the lanes of a ring job sit along an arc and across consecutive radii, so
+    // bilinear taps step through the image by +-1 column, +-1 row (= pst words) or a diagonal (pst +- 1).  A stride
+    // that is a multiple of 32 (96 at nx = 90) puts every vertical neighbour into the same LDS bank; pick the next
+    // stride whose residues pst, pst - 1, pst + 1 share at most a factor 4 with the 32 banks.
+    if (!(getenv("RALIGN_PST_RAW") && atoi(getenv("RALIGN_PST_RAW")) != 0))
+        while (!((d.pst & 1) && ((d.pst - 1) & 7) && ((d.pst + 1) & 7))) d.pst++;
 
     // ---- fused (particle-resident) kernel plan
     std::vector<int> f_goff, f_aoff, f_uoff, f_bsrc;

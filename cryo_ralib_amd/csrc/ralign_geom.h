@@ -144,7 +144,7 @@ inline int panel_pos(int ns, int rows, int kk, int row, int s)
     return off + (kk * rows + row);
 }
 
-// a_src: per A-block float, the source offset inside the 4 LDS ring buffers (stride sbuf), -1 = 0
+// a_src: per A-block float, the source offset inside the 4 LDS ring buffers (stride sbuf) | offset slot << 24, -1 = 0
 // b_src: per B-tile float, (entry e << 4 | col), -1 = 0
 inline void build_operand_tables(Geometry &g, int sbuf)
 {
@@ -160,7 +160,7 @@ inline void build_operand_tables(Geometry &g, int sbuf)
             g.ent_apos[2 * e + 1] = panel_pos(ns, 8, kk, 1, s) - panel_pos(ns, 8, kk, 0, s);
             for (int row = 0; row < 8; row++)
                 g.a_src[(size_t)g.bin_offp[k] * 8 + panel_pos(ns, 8, kk, row, s)] =
-                    (row >> 1) * sbuf + g.ent_src[e] + (row & 1);
+                    ((row >> 1) * sbuf + g.ent_src[e] + (row & 1)) | ((row >> 1) << 24);
             for (int col = 0; col < 16; col++)
                 g.b_src[(size_t)g.bin_offp[k] * 16 + panel_pos(ns, 16, kk, col, s)] = (e << 4) | col;
         }

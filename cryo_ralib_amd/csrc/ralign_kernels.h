@@ -398,9 +398,13 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
     if (p >= n) return;
 
     const float *src = particles + (size_t)p * g.nx * g.nx;
-    for (int i = tid; i < npad; i += blockDim.x) {
-        const int y = i / g.pst - g.bd, x = i % g.pst - g.bd;
-        img[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.nx) ? src[y * g.nx + x] : 0.f;
+    for (int row = wave; row < g.pst; row += nwave) {        // a wave per padded row: no per-pixel division
+        const int y = row - g.bd;
+        const bool yin = y >= 0 && y < g.nx;
+        for (int c = lane; c < g.pst; c += 64) {
+            const int x = c - g.bd;
+            img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
+        }
     }
     const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
     for (int i = tid; i < g.maxrin; i += blockDim.x) tw_s[i] = g.tw[i];
@@ -463,10 +467,10 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
         if (!(g.dbg & 64))
         for (int q = tid; q < g.LBP * 2; q += blockDim.x) {
             const int4 sidx = g.a_src4[q];
-            auto fetch = [&](int idx) -> float {
-                if (idx < 0) return 0.f;
-                const int m4 = (idx >= g.sbuf) + (idx >= 2 * g.sbuf) + (idx >= 3 * g.sbuf);
-                return bufs[idx] * red[12 + m4];
+            // table element = LDS float index | offset slot << 24 (the slot picks 1/sigma); -1 = padding
+            auto fetch = [&](int code) -> float {
+                if (code < 0) return 0.f;
+                return bufs[code & 0xffffff] * red[12 + (code >> 24)];
             };
             float4 v;
             v.x = fetch(sidx.x); v.y = fetch(sidx.y); v.z = fetch(sidx.z); v.w = fetch(sidx.w);
