@@ -240,7 +240,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                     if (ns & 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[oa + la], pb[ob + lb], acc, 0, 0, 0);
                     // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
                     const float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
                     const float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
                     const float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
                     const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;

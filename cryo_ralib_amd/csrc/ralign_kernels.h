@@ -81,6 +81,13 @@ struct DevGeom {
 // ------------------------------------------------------------------------------------------
 // helpers
 
+// exchange with the neighbouring lane (lane ^ 1) through the DPP quad permute [1,0,3,2]: a VALU move modifier, no
+// trip through the LDS crossbar (what __shfl_xor(v, 1) compiles to: ds_bpermute_b32 + s_waitcnt)
+__device__ __forceinline__ float swap_lane_pair(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -644,7 +651,7 @@ __device__ __forceinline__ void contract_bin(const Operands<NS> &o, float *Z, in
     // (one accumulation chain: the sum over rings stays the exact f32 fma chain the parity tests pin)
     // 2x2 block exchange between the Re/Im column lanes of one reference
     float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
     float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
     float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
     float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
@@ -734,14 +741,20 @@ __device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, in
                 if (v[q][n1].y >= bt[q]) { bt[q] = v[q][n1].y; it[q] = ix; }
             }
         }
-        // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=)
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            float oq = __shfl_xor(bq[q], o); int oiq = __shfl_xor(iq[q], o);
-            float ot = __shfl_xor(bt[q], o); int oit = __shfl_xor(it[q], o);
-            if (oq > bq[q] || (oq == bq[q] && oiq > iq[q])) { bq[q] = oq; iq[q] = oiq; }
-            if (ot > bt[q] || (ot == bt[q] && oit > it[q])) { bt[q] = ot; it[q] = oit; }
+        // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=).  The partners of the four
+        // steps are DPP row permutes (mirror 15-i, half mirror 7-i, quad [2,3,0,1], quad [1,0,3,2]): together they
+        // reach all 16 lanes of the row without a trip through the LDS crossbar; the tie rule is order-free.
+#define RA_DPP_STEP(CTRL)                                                                                              \
+        {                                                                                                              \
+            const float oq = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bq[q]), CTRL, 0xF, 0xF, true)); \
+            const int oiq = __builtin_amdgcn_update_dpp(0, iq[q], CTRL, 0xF, 0xF, true);                               \
+            const float ot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bt[q]), CTRL, 0xF, 0xF, true)); \
+            const int oit = __builtin_amdgcn_update_dpp(0, it[q], CTRL, 0xF, 0xF, true);                               \
+            if (oq > bq[q] || (oq == bq[q] && oiq > iq[q])) { bq[q] = oq; iq[q] = oiq; }                               \
+            if (ot > bt[q] || (ot == bt[q] && oit > it[q])) { bt[q] = ot; it[q] = oit; }                               \
         }
+        RA_DPP_STEP(0x140) RA_DPP_STEP(0x141) RA_DPP_STEP(0x4E) RA_DPP_STEP(0xB1)
+#undef RA_DPP_STEP
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -770,15 +783,94 @@ __device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, in
     }
 }
 
+// two-kernel path: the same transform, but the 7-point neighbourhood of the maximum is picked out of the REGISTERS
+// (lane j holds the outputs with index = j mod R1; every one of the 7 neighbours sits in a different lane, which
+// selects it with a compare chain and stores it straight into the candidate record) -- the transformed sequence is
+// never written back to LDS.  Records: pc[pair] = {val, jtot, refmir = mirror << 16 | ref0 + (pair & 7), t7[7]}.
 template <int N, int NP>
 __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *twl, int pairA, int pairB, int j, int ref0)
 {
-    CandT c;
-    ifft_argmax_core<ZLayout<N>, N, NP, IfftPlan<N>::R2>(Z, twl, pairA, pairB, j, c);
-    if (j < NP) {
-        const int pair = (j == 0) ? pairA : pairB;
-        c.refmir |= ref0 + (pair & 7);
-        pc[pair] = c;
+    typedef ZLayout<N> ZL;
+    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2, TWS = IfftPlan<N>::R2;
+    const int pr[2] = {pairA, pairB};
+    float2 v[NP][16];
+    if (j < R2) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int k1 = 0; k1 < R1; k1++) v[q][k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], R2 * k1 + j));
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            Dft<1, R1>::run(v[q]);
+#pragma unroll
+            for (int n0 = 1; n0 < R1; n0++) v[q][n0] = cmul(v[q][n0], twl[n0 * TWS]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (j < R2) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pr[q], n0 * R2 + j)) = v[q][n0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (j < R1) {
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int k0 = 0; k0 < R2; k0++) v[q][k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], j * R2 + k0));
+#pragma unroll
+        for (int q = 0; q < NP; q++) Dft<1, R2>::run(v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        float bq = -1.0e20f, bt = -1.0e20f;
+        int iq = 0, it = 0;
+        if (j < R1) {
+#pragma unroll
+            for (int n1 = 0; n1 < R2; n1++) {
+                const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
+                if (v[q][n1].x >= bq) { bq = v[q][n1].x; iq = ix; }
+                if (v[q][n1].y >= bt) { bt = v[q][n1].y; it = ix; }
+            }
+        }
+        // 16-lane argmax, ties -> larger index; DPP row permutes (mirror 15-i, half mirror 7-i, quad [2,3,0,1], quad
+        // [1,0,3,2]) reach all 16 lanes of the row, and every lane ends up with the row's winner
+#define RA_DPP_STEP(CTRL)                                                                                              \
+        {                                                                                                              \
+            const float oq = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bq), CTRL, 0xF, 0xF, true));  \
+            const int oiq = __builtin_amdgcn_update_dpp(0, iq, CTRL, 0xF, 0xF, true);                                  \
+            const float ot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bt), CTRL, 0xF, 0xF, true));  \
+            const int oit = __builtin_amdgcn_update_dpp(0, it, CTRL, 0xF, 0xF, true);                                  \
+            if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }                                              \
+            if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }                                              \
+        }
+        RA_DPP_STEP(0x140) RA_DPP_STEP(0x141) RA_DPP_STEP(0x4E) RA_DPP_STEP(0xB1)
+#undef RA_DPP_STEP
+        // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
+        const bool mir = !(bq >= bt);
+        const int jt = mir ? it : iq;
+        CandT *dst = pc + pr[q];
+        // neighbour jt + k (k = -3..3) lives in lane (jt + k) mod R1 at register (jt + k) / R1
+        const int d = (j - jt) & (R1 - 1);
+        const int k = d <= 3 ? d : d - R1;
+        if (j < R1 && k >= -3) {
+            const int n1 = ((jt + k + N) & (N - 1)) / R1;
+            float val = 0.f;
+#pragma unroll
+            for (int r = 0; r < R2; r++) {
+                const float c = mir ? v[q][r].y : v[q][r].x;
+                val = (r == n1) ? c : val;
+            }
+            dst->t7[k + 3] = val;
+        }
+        if (j == 0) {
+            dst->val = mir ? bt : bq;
+            dst->jtot = jt + 1;
+            dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + (pr[q] & 7));
+        }
     }
 }
 
@@ -1021,7 +1113,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g
                     // acc[i], i = (offset slot, Re/Im D); lane = 4*bin + (ref in pair, Re/Im C).
                     // 2x2 block exchange between the Re/Im column lanes of one reference:
                     float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-                    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
                     float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
                     float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
                     float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
