@@ -251,9 +251,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax, P pairs per batch, one wave per pair
             if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
-                CandT c; c.val = 0.f; c.jtot = 1; c.refmir = min(ref0 + (tid & 7), nref - 1);
-                for (int k = 0; k < 7; k++) c.t7[k] = 0.f;
-                pc[tid] = c;
+                pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
+                for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
             }
             if (!(g.dbg & 1))
             for (int base = 0; base < 64; base += P) {
@@ -291,29 +290,31 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                         if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
                         if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
                     }
-                    if (lane == 0) {
+                    {
                         const bool mir = !(bq >= bt);        // qn >= qm keeps the straight match
                         const int jt = mir ? it : iq;
-                        CandT c;
-                        c.val = mir ? bt : bq; c.jtot = jt + 1; c.refmir = ((mir ? 1 : 0) << 16) | (ref0 + slot);
-#pragma unroll
-                        for (int k = -3; k <= 3; k++) {
-                            const float2 zz = r[(jt + k + N) & (N - 1)];
-                            c.t7[k + 3] = mir ? zz.y : zz.x;
+                        CandT *dst = pc + pair;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
+                        if (lane < 7) {
+                            const float2 zz = r[(jt + lane - 3 + N) & (N - 1)];
+                            dst->t7[lane] = mir ? zz.y : zz.x;
                         }
-                        pc[pair] = c;
+                        if (lane == 0) {
+                            dst->val = mir ? bt : bq; dst->jtot = jt + 1; dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + slot);
+                        }
                     }
                 }
                 __syncthreads();
             }
-            // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins)
-            if (tid < 8) {
-                CandT best = pc[tid * 8];
+            // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins), dword-wise copy
+            if (tid < 8 * (int)(sizeof(CandT) / 4)) {
+                constexpr int W = sizeof(CandT) / 4;
+                const int o = tid / W, wd = tid - o * W;
+                float bv = pc[o * 8].val; int br = 0;
                 for (int rr = 1; rr < nvalid; rr++) {
-                    const CandT c = pc[tid * 8 + rr];
-                    if (c.val >= best.val) best = c;
+                    const float v = pc[o * 8 + rr].val;
+                    if (v >= bv) { bv = v; br = rr; }
                 }
-                cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
+                reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
             }
             __syncthreads();
         }

@@ -907,9 +907,8 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
     const int ref0 = rtile * g.rpt;                       // references [ref0, ref0 + nvalid) of this tile
     const int nvalid = min(g.rpt, nref - ref0);
     if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
-        CandT c; c.val = 0.f; c.jtot = 1; c.refmir = min(ref0 + (tid & 7), nref - 1);
-        for (int k = 0; k < 7; k++) c.t7[k] = 0.f;
-        pc[tid] = c;
+        pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
+        for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
     }
     // ---- phase 1: contraction, class by class (static shapes inside a class)
     if (!(g.dbg & 2)) {
@@ -952,14 +951,17 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
         }
     }
     __syncthreads();
-    // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins)
-    if (tid < 8) {
-        CandT best = pc[tid * 8];
+    // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins); the 8 winning records are
+    // copied dword by dword (no private copy of the struct)
+    if (tid < 8 * (int)(sizeof(CandT) / 4)) {
+        constexpr int W = sizeof(CandT) / 4;
+        const int o = tid / W, wd = tid - o * W;
+        float bv = pc[o * 8].val; int br = 0;
         for (int rr = 1; rr < nvalid; rr++) {
-            const CandT c = pc[tid * 8 + rr];
-            if (c.val >= best.val) best = c;
+            const float v = pc[o * 8 + rr].val;
+            if (v >= bv) { bv = v; br = rr; }
         }
-        cand[((size_t)mtile * 8 + tid) * nrtile + rtile] = best;
+        reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
     }
     __syncthreads();
     }   // rtile
