@@ -88,6 +88,17 @@ __device__ __forceinline__ float swap_lane_pair(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
 
+// sum over the LR (4 | 8 | 16) lanes of a ring group with DPP row permutes; every lane ends up with the total.
+// Fixed pairing order, hence reproducible run to run.
+template <int LR> __device__ __forceinline__ float group_sum_dpp(float v)
+{
+    if constexpr (LR >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // 15 - i
+    if constexpr (LR >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // 7 - i
+    if constexpr (LR >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // i ^ 2
+    if constexpr (LR >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // i ^ 1
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -380,8 +391,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         }
     }
     // Normalize_ring partial sums of this ring -> its own slot (summed in ring order later)
-#pragma unroll
-    for (int o = LR / 2; o > 0; o >>= 1) { av += __shfl_xor(av, o); sq += __shfl_xor(sq, o); }
+    av = group_sum_dpp<LR>(av); sq = group_sum_dpp<LR>(sq);
     if (t == 0) { red[24 + 2 * (slot * g.nring + ring)] = av; red[25 + 2 * (slot * g.nring + ring)] = sq; }
 }
 
