@@ -111,7 +111,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
         const float c = (float)g.cnx;
         for (int i = wave; i < g.nring; i += RA_GEN_THREADS / 64) {
             const int4 ri = g.ringinfo[i];
-            const int nlen = ri.z, h = nlen >> 1, kc = ri.x - 2 * i;
+            const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
             float *xr = reinterpret_cast<float *>(bx);
             for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + c, g.samp_dy[kc + j] + c);
             wave_lds_sync();
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
         float av = 0.f, sq = 0.f;
         for (int i = 0; i < g.nring; i++) {
             const int4 ri = g.ringinfo[i];
-            const int nlen = ri.z, kc = ri.x - 2 * i;
+            const int nlen = ri.z, kc = ri.x - kRingPad * i;
             const float wt = g.ringw[i];
             float a = 0.f, q = 0.f;
             for (int j = lane; j < nlen; j += 64) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     float *blk = out + ((size_t)p * ngroup + grp) * g.a_blk;
     for (int i = 0; i < g.nring; i++) {
         const int4 ri = g.ringinfo[i];
-        const int nlen = ri.z, h = nlen >> 1, kc = ri.x - 2 * i;
+        const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
         float *xr = reinterpret_cast<float *>(bx);
         for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
         wave_lds_sync();

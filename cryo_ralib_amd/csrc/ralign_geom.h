@@ -11,6 +11,12 @@
 
 namespace ralign {
 
+// floats between consecutive rings in the padded ring buffer, beyond the ring's n samples: 2 would do for the
+// in-place real FFT (slot of X_{n/2}); 16 makes every ring stride (24, 32, 48, 80, 144, 272 floats) an odd multiple of 8
+// or 16 dwords, so that the 2 ... 4 rings a wave-instruction touches at once sit in different LDS bank windows
+// instead of on top of each other (256 + 2 = 258 = 2 mod 64 put 8 rings within 14 banks of each other)
+constexpr int kRingPad = 16;
+
 struct Geometry {
     int nx = 0;
     int first_ring = 1, last_ring = 0, skip = 1;
@@ -18,7 +24,7 @@ struct Geometry {
     int nbins = 0;                 // maxrin/2 + 1 complex bins of the CCF spectrum
     int LB = 0;                    // sum over rings of (n/2+1): complex entries per particle-shift
     int LBP = 0;                   // same with every bin's ring count padded to a multiple of 4
-    int lring = 0;                 // lcirc + 2*nring floats: ring buffers padded for in-place R2C
+    int lring = 0;                 // lcirc + kRingPad*nring floats: ring buffers padded for in-place R2C
     float nn_weight = 0.f;         // Normalize_ring's float-accumulated sum of weights
     std::vector<int> numr;         // (radius, 1-based offset, length) per ring
     std::vector<float> wr;         // ringwe
@@ -80,7 +86,7 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
     float nn = 0.f;
     for (int it = 0; it < g.nring; it++) {
         int inr = g.numr[3 * it], kc = g.numr[3 * it + 1] - 1, l = g.numr[3 * it + 2];
-        g.ring_off[it] = kc + 2 * it;
+        g.ring_off[it] = kc + kRingPad * it;
         int lt = l / 4, nsim = lt - 1;
         double dfi = qpi / (nsim + 1);
         float w = (float)(inr * 2 * M_PI / (float)l);
@@ -98,7 +104,7 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
         for (int j = 0; j < l; j++) nn += w;   // Normalize_ring: float accumulation in ring order
     }
     g.nn_weight = nn;
-    g.lring = g.lcirc + 2 * g.nring;
+    g.lring = g.lcirc + kRingPad * g.nring;
 
     // bin-major contraction layout
     g.bin_first.assign(g.nbins, 0);
