@@ -158,7 +158,7 @@ def main():
         # gfx950 + WRITE_SIZE, per particle), scaled to this run's particles per launch
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v7_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_v8_pmc_summary.json")) as f:
                 pm = json.load(f)
             if (nx, ou, nref) == (90, 36, 10):
                 key = [k for k in pm["kernels"] if "ccf_kernel<256>" in k][0]
