@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; root=$(pwd); cd /tmp
-for d in 0 16 64; do
+for d in ${DBGS:-0 16 64}; do
   RALIGN_DEBUG=$d rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d /tmp/lds_$d -o run -- python3 $root/bench.py --steps 1 --warmup 0 --particles 14000 --no-cpu-baseline --function none > /tmp/lds_$d.log 2>&1
   python3 - <<PY
 import csv,glob,collections
