@@ -55,6 +55,8 @@ aln_param_ptr = ctypes.POINTER(AlignParam)
 EXPORTED_SYMBOLS = [
     "print_gpu_info", "gpu_clear", "pre_align_init", "pre_align_size_check", "pre_align_fetch",
     "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
+    "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
+    "ref_free_alignment_2D_filter_references", "ra_isac_get_references",
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
@@ -128,6 +130,16 @@ def load_library(path=None):
     L.print_gpu_info.argtypes = [ctypes.c_uint]
     L.print_gpu_info.restype = None
     L.gpu_clear.restype = None
+    L.ref_free_alignment_2D_init.restype = ctypes.c_ulonglong
+    L.ref_free_alignment_2D_init.argtypes = [ctypes.POINTER(AlignConfig), ctypes.POINTER(float_ptr), ctypes.POINTER(float_ptr),
+                                             ctypes.POINTER(ctypes.c_int), ctypes.c_uint]
+    L.ref_free_alignment_2D_size_check.restype = ctypes.c_bool
+    L.ref_free_alignment_2D_size_check.argtypes = [ctypes.POINTER(AlignConfig), ctypes.c_uint, ctypes.c_float, ctypes.c_bool]
+    L.ref_free_alignment_2D.restype = None
+    L.ref_free_alignment_2D.argtypes = []
+    L.ref_free_alignment_2D_filter_references.restype = None
+    L.ref_free_alignment_2D_filter_references.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.ra_isac_get_references.argtypes = [float_ptr]
     if path is None:
         _lib = L
     return L

@@ -51,9 +51,7 @@ struct ra_engine {
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
-    size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0, lds_fused = 0;
-    float *d_Bf = nullptr;              // [f_nchunk][f_bchunk] unit-major reference stream of the fused kernel
-    bool fused = false;                 // RALIGN_FUSED=1: particle-resident single-kernel search
+    size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
@@ -106,7 +104,11 @@ static int build_device_geometry(ra_engine *e)
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
     d.nn_weight = g.nn_weight; d.mode = e->cfg.mode;
+#ifdef RALIGN_PROFILE_SWITCHES
     d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
+#else
+    d.dbg = 0;
+#endif
     int sbuf = (g.lring + 31) / 32 * 32 + 8;    // == 8 (mod 32): the 4 offsets of an entry hit disjoint banks
     d.sbuf = sbuf;
     d.a_blk = g.LBP * 8 + 64;
@@ -172,8 +174,7 @@ static int build_device_geometry(ra_engine *e)
     std::vector<float> ringw(g.nring);
     std::vector<int4> inst;
     std::vector<float> instw;
-    std::vector<int4> jobs, f_jobs, f_inst;
-    std::vector<float> f_instw;
+    std::vector<int4> jobs;
     {
         std::vector<int> qoff(32, -1);
         const double qpi = 2 * atan(1.0);
@@ -218,10 +219,7 @@ static int build_device_geometry(ra_engine *e)
                 }
             }
         };
-        if (!e->generic) {
-            make_jobs(4, jobs, inst, instw);
-            make_jobs(2, f_jobs, f_inst, f_instw);
-        }
+        if (!e->generic) make_jobs(4, jobs, inst, instw);
     }
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
@@ -232,80 +230,6 @@ static int build_device_geometry(ra_engine *e)
     // stride whose residues pst, pst - 1, pst + 1 share at most a factor 4 with the 32 banks.
     if (!(getenv("RALIGN_PST_RAW") && atoi(getenv("RALIGN_PST_RAW")) != 0))
         while (!((d.pst & 1) && ((d.pst - 1) & 7) && ((d.pst + 1) & 7))) d.pst++;
-
-    // ---- fused (particle-resident) kernel plan
-    std::vector<int> f_goff, f_aoff, f_uoff, f_bsrc;
-    std::vector<int4> f_units;
-    d.f_on = 0;
-    if (!e->generic) {
-        const int NWV = RA_POLAR_THREADS / 64;
-        d.f_sbuf = (g.lring + 32 + 31) / 32 * 32 + 16;   // == 16 (mod 32): the two offset slots use disjoint banks; >= 32 floats of slack
-        d.f_n_job = (int)f_jobs.size(); d.f_n_inst = (int)f_inst.size();
-        d.f_ng = (g.nbins + 15) / 16;
-        f_goff.assign(d.f_ng + 1, 0);
-        std::vector<int> gfirst(d.f_ng);
-        for (int gi = 0; gi < d.f_ng; gi++) {
-            int i0 = 0;
-            while (i0 < g.nring && g.numr[3 * i0 + 2] / 2 < 16 * gi) i0++;
-            gfirst[gi] = i0;
-            f_goff[gi + 1] = f_goff[gi] + (g.nring - i0);
-        }
-        d.f_nstep = f_goff[d.f_ng];
-        f_aoff.resize(d.f_nstep);
-        for (int gi = 0; gi < d.f_ng; gi++)
-            for (int st = 0; st < f_goff[gi + 1] - f_goff[gi]; st++) f_aoff[f_goff[gi] + st] = g.ring_off[gfirst[gi] + st] + 32 * gi;
-        const int base = 2 * (g.maxrin + g.maxrin / 16);
-        d.f_ps = base + ((8 - base % 64) + 64) % 64;
-        // references per chunk: the CCF spectra of 2 offsets x rc references must fit beside image and ring buffers
-        auto lds_floats = [&](int rc) {
-            return ((d.pst * d.pst + 3) & ~3) + 2 * d.f_sbuf + 2 * rc * d.f_ps + 2 * g.maxrin + 2 * (int)qtab.size() + 2 +
-                   4 * d.f_n_inst + 4 * d.f_n_job + 8 * rc + d.f_n_inst + d.f_nstep + 32 + 8 * g.nring;
-        };
-        int rc = std::min(16, (e->cfg.nref + 1) & ~1);
-        while (rc > 2 && (size_t)lds_floats(rc) * 4 > 160 * 1024) rc -= 2;
-        d.f_on = ((size_t)lds_floats(rc) * 4 <= 160 * 1024) ? 1 : 0;
-        d.f_nchunk = (e->cfg.nref + rc - 1) / rc;
-        rc = std::min(rc, (((e->cfg.nref + d.f_nchunk - 1) / d.f_nchunk) + 1) & ~1);
-        d.f_rc = rc;
-        e->lds_fused = (size_t)lds_floats(rc) * 4;
-        // units (16-bin group, reference pair), longest first onto the least loaded wave
-        const int nrp = rc / 2;
-        struct U { int gi, rp, w, bbase; };
-        std::vector<U> us;
-        int bb = 0;
-        for (int gi = 0; gi < d.f_ng; gi++)
-            for (int rp = 0; rp < nrp; rp++) {
-                const int wgt = f_goff[gi + 1] - f_goff[gi];
-                us.push_back({gi, rp, wgt, bb});
-                bb += wgt * 64;
-            }
-        d.f_bchunk = bb; d.f_nunit = (int)us.size();
-        std::vector<U> sorted(us);
-        std::stable_sort(sorted.begin(), sorted.end(), [](const U &a, const U &b) { return a.w > b.w; });
-        std::vector<std::vector<U>> per(NWV);
-        std::vector<int> load(NWV, 0);
-        for (auto &u : sorted) {
-            int wv = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            per[wv].push_back(u); load[wv] += u.w + 6;      // + ~6 steps of epilogue per unit
-        }
-        f_uoff.assign(NWV + 1, 0);
-        for (int wv = 0; wv < NWV; wv++) {
-            for (auto &u : per[wv]) f_units.push_back(make_int4(u.gi, u.rp, u.bbase, 0));
-            f_uoff[wv + 1] = (int)f_units.size();
-        }
-        // B stream source table
-        f_bsrc.assign(d.f_bchunk, -1);
-        for (auto &u : us)
-            for (int st = 0; st < u.w; st++) {
-                const int ring = gfirst[u.gi] + st, nlen = g.numr[3 * ring + 2];
-                for (int ln = 0; ln < 64; ln++) {
-                    const int k = 16 * u.gi + (ln >> 2), j = ln & 3;
-                    if (k > nlen / 2 || k >= g.nbins) continue;
-                    const int en = g.bin_off[k] + (ring - g.bin_first[k]);
-                    f_bsrc[u.bbase + st * 64 + ln] = (en << 5) | ((2 * u.rp + (j >> 1)) << 1) | (j & 1);
-                }
-            }
-    }
 
     std::vector<float2> tw(g.maxrin);
     for (int k = 0; k < g.maxrin; k++) {
@@ -355,14 +279,6 @@ static int build_device_geometry(ra_engine *e)
     if ((rc = upload(e, jobs, &d.jobs))) return rc;
     if ((rc = upload(e, inst, &d.inst))) return rc;
     if ((rc = upload(e, instw, &d.instw))) return rc;
-    if ((rc = upload(e, f_jobs, &d.f_jobs))) return rc;
-    if ((rc = upload(e, f_inst, &d.f_inst))) return rc;
-    if ((rc = upload(e, f_instw, &d.f_instw))) return rc;
-    if ((rc = upload(e, f_goff, &d.f_goff))) return rc;
-    if ((rc = upload(e, f_aoff, &d.f_aoff))) return rc;
-    if ((rc = upload(e, f_units, &d.f_units))) return rc;
-    if ((rc = upload(e, f_uoff, &d.f_uoff))) return rc;
-    if ((rc = upload(e, f_bsrc, &d.f_bsrc))) return rc;
     if ((rc = upload(e, qtab, &d.qtab))) return rc;
     if ((rc = upload(e, ringinfo, &d.ringinfo))) return rc;
     if ((rc = upload(e, ringw, &d.ringw))) return rc;
@@ -393,18 +309,6 @@ static ccf_fn select_ccf(int maxrin)
     case 128: return ccf_kernel<128>;
     case 64: return ccf_kernel<64>;
     case 32: return ccf_kernel<32>;
-    default: return nullptr;
-    }
-}
-
-typedef void (*fused_fn)(DevGeom, const float *, float *, int, const float *, ra_result *, int);
-static fused_fn select_fused(int maxrin)
-{
-    switch (maxrin) {
-    case 256: return align_fused_kernel<256>;
-    case 128: return align_fused_kernel<128>;
-    case 64: return align_fused_kernel<64>;
-    case 32: return align_fused_kernel<32>;
     default: return nullptr;
     }
 }
@@ -484,7 +388,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
-        if (he == hipSuccess && e->dg.f_on) he = hipFuncSetAttribute((const void *)select_fused(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_fused);
     } else {
         he = hipFuncSetAttribute((const void *)polar_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)polar_generic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
@@ -521,8 +424,6 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if ((rc = dev_alloc(e, &e->d_zscr, (size_t)e->g_nblk * 64 * g.maxrin, false))) { ra_destroy(e); return rc; }
     }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
-    e->fused = !e->generic && e->dg.f_on && getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) != 0;
-    if (e->dg.f_on && (rc = dev_alloc(e, &e->d_Bf, (size_t)e->dg.f_nchunk * e->dg.f_bchunk, true))) { ra_destroy(e); return rc; }
     *out = e;
     return RA_OK;
 }
@@ -564,6 +465,12 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
         g_last_error = "shift or radius too large: particle crosses image boundary";
         return RA_ERR_ARG;
     }
+    // the padded LDS image of the polar stage was sized at ra_create for a border of ceil(max range) + 2 pixels;
+    // a wider window (possible at a constant offset count, e.g. xr=1,ts=0.5 -> xr=4,ts=2) would let taps leave it
+    if (!e->generic && (int)std::ceil(std::max(xrng, yrng)) + 2 > e->dg.bd) {
+        g_last_error = "reset_shifts: search range exceeds the image border the engine was created with";
+        return RA_ERR_ARG;
+    }
     RA_HIP(hipStreamSynchronize(e->stream));
     RA_HIP(hipMemcpy((void *)e->dg.shift_x, g2.shift_x.data(), g2.nshift * sizeof(float), hipMemcpyHostToDevice));
     RA_HIP(hipMemcpy((void *)e->dg.shift_y, g2.shift_y.data(), g2.nshift * sizeof(float), hipMemcpyHostToDevice));
@@ -591,12 +498,6 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
                        e->cfg.nref, e->nrtile, e->d_B);
     RA_HIP(hipGetLastError());
-    if (e->dg.f_on) {
-        const int totalf = e->dg.f_nchunk * e->dg.f_bchunk;
-        hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(4096, (totalf + 255) / 256)), dim3(256), 0, e->stream, e->dg,
-                           e->d_refspec, e->cfg.nref, e->d_Bf);
-        RA_HIP(hipGetLastError());
-    }
     e->refs_ready = true;
     return RA_OK;
 }
@@ -655,22 +556,6 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipMemcpyAsync(e->d_cs, cs, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(apply_cs_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_cs, d_result, d_state);
         RA_HIP(hipGetLastError());
-    }
-    if (e->fused) {
-        // particle-resident search: one kernel, no spectra workspace; still launched per chunk so that
-        // one launch stays a bounded unit of work for timing
-        fused_fn fk = select_fused(g.maxrin);
-        for (int start = 0; start < n; start += e->chunk) {
-            const int cn = std::min(e->chunk, n - start);
-            std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
-            if (evc) RA_HIP(hipEventRecord(evc->first, e->stream));
-            hipLaunchKernelGGL(fk, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_fused, e->stream, e->dg,
-                               d_particles + (size_t)start * npix, d_state + (size_t)start * 2, cn, e->d_Bf, d_result + start,
-                               e->cfg.nref);
-            RA_HIP(hipGetLastError());
-            if (evc) RA_HIP(hipEventRecord(evc->second, e->stream));
-        }
-        return RA_OK;
     }
     hipStream_t sp = e->stream;
     for (int start = 0; start < n; start += e->chunk) {
@@ -1021,6 +906,10 @@ struct Legacy {
     int *h_counts = nullptr;
     size_t stage_imgs = 0;
     unsigned sbj_loaded = 0;
+    // class-resident (ISAC) mode: particles sorted by class, one reference per class
+    bool isac = false;
+    std::vector<unsigned> cid_idx;       // [ref_num + 1] first particle of every class
+    unsigned *d_cid_idx = nullptr;
 } L;
 
 void die(const char *what)
@@ -1106,7 +995,7 @@ extern "C" void gpu_clear(void)
     if (L.h_counts) (void)hipHostFree(L.h_counts);
     if (L.h_res) (void)hipHostFree(L.h_res);
     for (void *p : {(void *)L.d_sbj, (void *)L.d_ref, (void *)L.d_aligned, (void *)L.d_state, (void *)L.d_sums,
-                    (void *)L.d_counts, (void *)L.d_res})
+                    (void *)L.d_counts, (void *)L.d_res, (void *)L.d_cid_idx})
         if (p) (void)hipFree(p);
     int dev = L.device;
     L = Legacy();
@@ -1233,4 +1122,149 @@ extern "C" void reset_shifts(const float shift_range, const float shift_step)
 {
     if (!L.eng) { fprintf(stderr, "libralign_hip: reset_shifts before pre_align_init\n"); exit(EXIT_FAILURE); }
     if (ra_reset_shifts(L.eng, shift_range, shift_range, shift_step)) die("reset_shifts");
+}
+
+// ---------------------------------------------------------------------------------------------
+// class-resident reference-free alignment (cuda/gpu_aln_noref.h:94-109, gpu_aln_noref.cu:559-782; SURVEY.md
+// section 8 row f-3): particles arrive sorted by class, every particle is aligned to the average of its own class
+// (single-reference search with sp_alignment.ormq semantics), transformed, and the class averages are rebuilt
+// on the device from the aligned images; ref_free_alignment_2D_filter_references applies the tangent low-pass.
+
+// mean of the aligned images of the contiguous class range [cid_idx[r], cid_idx[r+1]) in particle order
+// (cu_average_batch, gpu_aln_noref.cu:1199-1229); an empty class keeps its previous reference
+__global__ __launch_bounds__(256) void class_mean_kernel(int npix, const float *__restrict__ aligned,
+                                                         const unsigned *__restrict__ cid_idx, float *__restrict__ refs)
+{
+    const int r = blockIdx.x;
+    const unsigned b = cid_idx[r], e = cid_idx[r + 1];
+    if (e <= b) return;
+    for (int pix = blockIdx.y * blockDim.x + threadIdx.x; pix < npix; pix += gridDim.y * blockDim.x) {
+        float avg = 0.f;
+        for (unsigned i = b; i < e; i++) avg += aligned[(size_t)i * npix + pix];
+        refs[(size_t)r * npix + pix] = avg / (float)(e - b);
+    }
+}
+
+static size_t isac_bytes(const AlignConfig *c)
+{
+    AlignConfig one = *c;
+    one.ref_num = 1;
+    const size_t npix = (size_t)c->img_dim * c->img_dim;
+    size_t need = legacy_bytes(c->sbj_num, &one);
+    if (need == (size_t)-1) return need;
+    return need + (size_t)c->ref_num * npix * 4 + ((size_t)c->ref_num + 1) * 4;
+}
+
+extern "C" AlignParam *ref_free_alignment_2D_init(const AlignConfig *aln_cfg, const float **sbj_data_list,
+                                                  const float **ref_data_list, const int *sbj_cid_list,
+                                                  const unsigned int device_id)
+{
+    if (!aln_cfg || !sbj_data_list || !ref_data_list || !sbj_cid_list) {
+        fprintf(stderr, "libralign_hip: ref_free_alignment_2D_init: null argument\n");
+        exit(EXIT_FAILURE);
+    }
+    if (L.device != -1 && L.device != (int)device_id) {
+        fprintf(stderr, "libralign_hip: device id may not change within a process\n");
+        exit(EXIT_FAILURE);
+    }
+    if (L.eng) gpu_clear();
+    L.device = (int)device_id;
+    L.cfg = *aln_cfg;
+    L.num_particles = aln_cfg->sbj_num;
+    L.isac = true;
+    const size_t npix = (size_t)aln_cfg->img_dim * aln_cfg->img_dim;
+    const size_t B = aln_cfg->sbj_num, R = aln_cfg->ref_num;
+    // class index list as the reference builds it (gpu_aln_noref.cu:611-620): a new class starts where the id changes
+    L.cid_idx.assign(R + 1, (unsigned)B);
+    {
+        int cid = -1; size_t idx = 0;
+        for (size_t i = 0; i < B; i++)
+            if (sbj_cid_list[i] != cid) {
+                if (idx >= R) { fprintf(stderr, "libralign_hip: ref_free_alignment_2D_init: more class runs than references\n"); exit(EXIT_FAILURE); }
+                L.cid_idx[idx++] = (unsigned)i; cid = sbj_cid_list[i];
+            }
+    }
+    ra_config rc = legacy_config(aln_cfg, device_id, RA_MODE_REFFREE);
+    rc.nref = 1;
+    rc.chunk = (int)std::min<unsigned>(8192, std::max(2u, aln_cfg->sbj_num));
+    if (ra_create(&L.eng, &rc)) die("ref_free_alignment_2D_init");
+    hip_or_die(hipHostMalloc((void **)&L.h_param, sizeof(AlignParam) * std::max<size_t>(1, B)), "param alloc");
+    for (size_t i = 0; i < B; i++) {
+        L.h_param[i].sbj_id = -1; L.h_param[i].ref_id = sbj_cid_list[i]; L.h_param[i].shift_x = 0; L.h_param[i].shift_y = 0;
+        L.h_param[i].angle = 0; L.h_param[i].mirror = false;
+    }
+    L.stage_imgs = std::max(B, R);
+    hip_or_die(hipHostMalloc((void **)&L.h_stage, L.stage_imgs * npix * sizeof(float)), "stage alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_state, B * 2 * sizeof(float)), "state alloc");
+    hip_or_die(hipHostMalloc((void **)&L.h_res, B * sizeof(ra_result)), "res alloc");
+    hip_or_die(hipMalloc((void **)&L.d_sbj, B * npix * sizeof(float)), "sbj alloc");
+    hip_or_die(hipMalloc((void **)&L.d_aligned, B * npix * sizeof(float)), "aligned alloc");
+    hip_or_die(hipMalloc((void **)&L.d_ref, R * npix * sizeof(float)), "ref alloc");
+    hip_or_die(hipMalloc((void **)&L.d_state, B * 2 * sizeof(float)), "state alloc");
+    hip_or_die(hipMalloc((void **)&L.d_res, B * sizeof(ra_result)), "res alloc");
+    hip_or_die(hipMalloc((void **)&L.d_cid_idx, (R + 1) * sizeof(unsigned)), "cid alloc");
+    hip_or_die(hipMemset(L.d_res, 0, B * sizeof(ra_result)), "res clear");
+    hip_or_die(hipMemcpy(L.d_cid_idx, L.cid_idx.data(), (R + 1) * sizeof(unsigned), hipMemcpyHostToDevice), "cid upload");
+    for (size_t i = 0; i < B; i++) memcpy(L.h_stage + i * npix, sbj_data_list[i], npix * sizeof(float));
+    hip_or_die(hipMemcpy(L.d_sbj, L.h_stage, B * npix * sizeof(float), hipMemcpyHostToDevice), "image upload");
+    for (size_t i = 0; i < R; i++) memcpy(L.h_stage + i * npix, ref_data_list[i], npix * sizeof(float));
+    hip_or_die(hipMemcpy(L.d_ref, L.h_stage, R * npix * sizeof(float), hipMemcpyHostToDevice), "reference upload");
+    L.sbj_loaded = (unsigned)B;
+    return L.h_param;
+}
+
+extern "C" bool ref_free_alignment_2D_size_check(const AlignConfig *cfg, const unsigned int device_id, const float request,
+                                                 const bool verbose)
+{
+    if (!cfg) return false;
+    if (hipSetDevice((int)device_id) != hipSuccess) return false;
+    const size_t need = isac_bytes(cfg);
+    size_t fr = 0, tot = 0;
+    if (need == (size_t)-1 || hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    if (verbose)
+        printf("GPU[%u] SIZE CHECK: need %zu MB of %zu MB free (request %.2f)\n", device_id, need >> 20, fr >> 20, request);
+    return (double)need <= (double)fr * request;
+}
+
+extern "C" void ref_free_alignment_2D(void)
+{
+    if (!L.eng || !L.isac) { fprintf(stderr, "libralign_hip: ref_free_alignment_2D before ref_free_alignment_2D_init\n"); exit(EXIT_FAILURE); }
+    const size_t npix = (size_t)L.cfg.img_dim * L.cfg.img_dim;
+    const unsigned B = L.cfg.sbj_num, R = L.cfg.ref_num;
+    for (unsigned i = 0; i < B; i++) { L.h_state[2 * i] = L.h_param[i].shift_x; L.h_state[2 * i + 1] = L.h_param[i].shift_y; }
+    hip_or_die(hipMemcpy(L.d_state, L.h_state, sizeof(float) * 2 * B, hipMemcpyHostToDevice), "state upload");
+    for (unsigned r = 0; r < R; r++) {
+        const unsigned b = L.cid_idx[r], e = L.cid_idx[r + 1];
+        if (e <= b) continue;
+        if (ra_set_references(L.eng, L.d_ref + (size_t)r * npix)) die("ra_set_references");
+        if (ra_align(L.eng, L.d_sbj + (size_t)b * npix, (int)(e - b), L.d_state + 2 * (size_t)b, L.d_res + b, nullptr)) die("ra_align");
+    }
+    if (ra_transform_accumulate(L.eng, L.d_sbj, (int)B, 0, L.d_res, L.d_aligned, nullptr, nullptr)) die("transform");
+    hipLaunchKernelGGL(class_mean_kernel, dim3(R, 8), dim3(256), 0, L.eng->stream, (int)npix, L.d_aligned, L.d_cid_idx, L.d_ref);
+    hip_or_die(hipGetLastError(), "class_mean_kernel");
+    if (ra_sync(L.eng)) die("sync");
+    hip_or_die(hipMemcpy(L.h_res, L.d_res, sizeof(ra_result) * B, hipMemcpyDeviceToHost), "result download");
+    hip_or_die(hipMemcpy(L.h_state, L.d_state, sizeof(float) * 2 * B, hipMemcpyDeviceToHost), "state download");
+    for (unsigned i = 0; i < B; i++) {      // ref_id keeps the class id given at init (gpu_aln_noref.cu:607-608)
+        AlignParam &a = L.h_param[i];
+        a.shift_x = L.h_state[2 * i]; a.shift_y = L.h_state[2 * i + 1];
+        a.angle = L.h_res[i].alpha;
+        a.mirror = L.h_res[i].mirror != 0;
+    }
+}
+
+extern "C" void ref_free_alignment_2D_filter_references(const float cutoff_freq, const float falloff)
+{
+    if (!L.eng || !L.isac) { fprintf(stderr, "libralign_hip: filter_references before ref_free_alignment_2D_init\n"); exit(EXIT_FAILURE); }
+    if (ra_filter_references(L.eng, L.d_ref, (int)L.cfg.ref_num, cutoff_freq, falloff, 0, nullptr, 0, nullptr)) die("ra_filter_references");
+    if (ra_sync(L.eng)) die("sync");
+}
+
+// extension (not in the reference header): copy the current class averages [ref_num][nx][nx] to host memory
+extern "C" int ra_isac_get_references(float *h_out)
+{
+    if (!L.eng || !L.isac || !h_out) { g_last_error = "class-resident mode is not initialised"; return RA_ERR_STATE; }
+    const size_t npix = (size_t)L.cfg.img_dim * L.cfg.img_dim;
+    RA_HIP(hipMemcpy(h_out, L.d_ref, (size_t)L.cfg.ref_num * npix * sizeof(float), hipMemcpyDeviceToHost));
+    return RA_OK;
 }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
             const int ref0 = rtile * g.rpt;
             const int nvalid = min(g.rpt, nref - ref0);
             // ---- phase 1: contraction per Fourier bin (same operand layout as ccf_kernel)
-            if (!(g.dbg & 2)) {
+            if (!RA_DBG(g, 2)) {
                 const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
                 const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
                 const float *Bt = B + (size_t)rtile * g.LBP * 16;
@@ -250,11 +250,11 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
             }
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax, P pairs per batch, one wave per pair
-            if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
+            if (RA_DBG(g, ~0) && tid < 64) {   // profiling builds that skip a phase still emit in-range records
                 pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
                 for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
             }
-            if (!(g.dbg & 1))
+            if (!RA_DBG(g, 1))
             for (int base = 0; base < 64; base += P) {
                 // scratch [k][64 pairs] -> LDS [pair][k]: 8 independent loads per thread in flight
                 for (int idx0 = tid; idx0 < P * N; idx0 += 8 * RA_GCCF_THREADS) {

@@ -23,6 +23,15 @@
 #include "ralign_fft.h"
 #include "../../include/ralign.h"
 
+// phase-skip switches for in-situ timing experiments exist only in builds made with
+// -DRALIGN_PROFILE_SWITCHES (scripts/profile.sh); the shipped library compiles them out, so no
+// environment variable can make a production kernel skip work.
+#ifdef RALIGN_PROFILE_SWITCHES
+#define RA_DBG(g, bits) (((g).dbg & (bits)) != 0)
+#else
+#define RA_DBG(g, bits) false
+#endif
+
 namespace ralign {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,7 +44,7 @@ struct DevGeom {
     float step, xrng, yrng;
     float nn_weight;
     int mode;                     // RA_MODE_*
-    int dbg;                      // RALIGN_DEBUG bit mask (profiling experiments only; 0 in production)
+    int dbg;                      // phase-skip mask of profiling builds (-DRALIGN_PROFILE_SWITCHES); unused otherwise
     int sbuf;                     // LDS stride of one ring buffer (floats)
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
@@ -66,16 +75,6 @@ struct DevGeom {
     const float2 *qtab;           // first-quadrant (sinf, cosf) of alrl_ms per ring length
     const int4 *ringinfo;         // per ring {ring_off, radius, length, qtab offset}
     const float *ringw;           // per ring Normalize_ring weight r*2pi/n
-    // fused (particle-resident) kernel: 2 search offsets per pass, spectra never leave the CU
-    int f_on, f_sbuf, f_n_job, f_n_inst;
-    int f_ng, f_rc, f_nchunk, f_ps, f_nstep, f_bchunk, f_nunit;
-    const int4 *f_jobs, *f_inst;
-    const float *f_instw;
-    const int *f_goff;            // [f_ng+1] prefix of ring steps per 16-bin group
-    const int *f_aoff;            // [f_nstep] LDS float offset (ring_off + 32 g) of every (group, ring) step
-    const int4 *f_units;          // per-wave unit lists {group, ref pair, B float offset, 0}
-    const int *f_uoff;            // [17] unit range of every wave
-    const int *f_bsrc;            // [f_bchunk] (entry << 5 | ref in chunk << 1 | comp) of every B float, -1 = 0
 };
 
 // ------------------------------------------------------------------------------------------
@@ -337,7 +336,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         v[a] = make_float2(val[0], val[1]);
         if (a & 1) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 samples' taps in flight (VGPR budget)
     }
-    if (g.dbg & 256) {   // diagnostic: leave the raw samples in natural order, no FFT
+    if (RA_DBG(g, 256)) {   // diagnostic: leave the raw samples in natural order, no FFT
 #pragma unroll
         for (int a = 0; a < R1; a++) *reinterpret_cast<float2 *>(buf + 2 * (LR * a + t)) = v[a];
         return;
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             red[17 + 2 * tid] = cyf + g.shift_y[si];
         }
         __syncthreads();
-        if (!(g.dbg & 16)) {
+        if (!RA_DBG(g, 16)) {
 #pragma unroll 1
             for (int job = wave; job < g.n_job; job += nwave) {
                 const int4 jd = jobs_s[job];
@@ -481,7 +480,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
         __syncthreads();
         // write-out through the gather table: 4 consecutive ring slots of one (bin, row) per thread
         float4 *dstA = reinterpret_cast<float4 *>(A + ((size_t)p * ngroup + grp) * g.a_blk);
-        if (!(g.dbg & 64))
+        if (!RA_DBG(g, 64))
         for (int q = tid; q < g.LBP * 2; q += blockDim.x) {
             const int4 sidx = g.a_src4[q];
             // table element = LDS float index | offset slot << 24 (the slot picks 1/sigma); -1 = padding
@@ -595,7 +594,6 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
 // 8 waves: phase 1 gives each wave every 8th bin (operands straight from HBM/L2 into registers:
 // each MFMA lane owns KP/4 contiguous floats of its row, fetched as 16-B loads one bin ahead);
 // phase 2 transforms 4 pairs per wave and round, 16 lanes per transform.
-struct Cand { float val; float tot; int jtot; int refmir; };   // refmir = ref | mirror << 16
 // record of the two-kernel path: the 7-point neighbourhood of the maximum travels with the candidate
 // and Util::prb1d runs once per particle in finalize_kernel instead of once per pair
 struct CandT { float val; int jtot; int refmir; float t7[7]; };
@@ -692,104 +690,6 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
         contract_bin<N, NS>(nxt, Z, pair, odd, k1);
         if (k2 >= kend) break;
         k = k2;
-    }
-}
-
-// phase 2 for NP pairs handled by the same 16-lane group: N-point complex inverse FFT (radix
-// R1 x R2 through the LDS image laid out by ZL), argmax of real (q) and imaginary (t) parts with
-// the ">=" / last-index rule, prb1d on the 7-point neighbourhood of the winner.  Lanes j < NP
-// return the record of pair j in `out` (refmir holds the mirror bit only).
-template <class ZL, int N, int NP, int TWS, class REC>
-__device__ __forceinline__ void ifft_argmax_core(float *Z, const float2 *twl, int pairA, int pairB, int j, REC &out)
-{
-    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
-    const int pr[2] = {pairA, pairB};
-    float2 v[NP][16];
-    if (j < R2) {
-#pragma unroll
-        for (int q = 0; q < NP; q++)
-#pragma unroll
-            for (int k1 = 0; k1 < R1; k1++) v[q][k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], R2 * k1 + j));
-#pragma unroll
-        for (int q = 0; q < NP; q++) {
-            Dft<1, R1>::run(v[q]);
-#pragma unroll
-            for (int n0 = 1; n0 < R1; n0++) v[q][n0] = cmul(v[q][n0], twl[n0 * TWS]);   // TWS = 1: registers, else an LDS table
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (j < R2) {
-#pragma unroll
-        for (int q = 0; q < NP; q++)
-#pragma unroll
-            for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pr[q], n0 * R2 + j)) = v[q][n0];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (j < R1) {
-#pragma unroll
-        for (int q = 0; q < NP; q++)
-#pragma unroll
-            for (int k0 = 0; k0 < R2; k0++) v[q][k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pr[q], j * R2 + k0));
-#pragma unroll
-        for (int q = 0; q < NP; q++) Dft<1, R2>::run(v[q]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float bq[NP], bt[NP];
-    int iq[NP], it[NP];
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        bq[q] = -1.0e20f; bt[q] = -1.0e20f; iq[q] = 0; it[q] = 0;
-        if (j < R1) {
-#pragma unroll
-            for (int n1 = 0; n1 < R2; n1++) {
-                const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
-                *reinterpret_cast<float2 *>(Z + ZL::addr(pr[q], ix)) = v[q][n1];
-                if (v[q][n1].x >= bq[q]) { bq[q] = v[q][n1].x; iq[q] = ix; }
-                if (v[q][n1].y >= bt[q]) { bt[q] = v[q][n1].y; it[q] = ix; }
-            }
-        }
-        // 16-lane argmax, ties -> larger index (Crosrng_ms scans j ascending with >=).  The partners of the four
-        // steps are DPP row permutes (mirror 15-i, half mirror 7-i, quad [2,3,0,1], quad [1,0,3,2]): together they
-        // reach all 16 lanes of the row without a trip through the LDS crossbar; the tie rule is order-free.
-#define RA_DPP_STEP(CTRL)                                                                                              \
-        {                                                                                                              \
-            const float oq = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bq[q]), CTRL, 0xF, 0xF, true)); \
-            const int oiq = __builtin_amdgcn_update_dpp(0, iq[q], CTRL, 0xF, 0xF, true);                               \
-            const float ot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bt[q]), CTRL, 0xF, 0xF, true)); \
-            const int oit = __builtin_amdgcn_update_dpp(0, it[q], CTRL, 0xF, 0xF, true);                               \
-            if (oq > bq[q] || (oq == bq[q] && oiq > iq[q])) { bq[q] = oq; iq[q] = oiq; }                               \
-            if (ot > bt[q] || (ot == bt[q] && oit > it[q])) { bt[q] = ot; it[q] = oit; }                               \
-        }
-        RA_DPP_STEP(0x140) RA_DPP_STEP(0x141) RA_DPP_STEP(0x4E) RA_DPP_STEP(0xB1)
-#undef RA_DPP_STEP
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (j < NP) {
-        // lane q of the group finishes pair q: qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
-        const float mq = (j == 0) ? bq[0] : bq[NP - 1], mt = (j == 0) ? bt[0] : bt[NP - 1];
-        const int miq = (j == 0) ? iq[0] : iq[NP - 1], mit = (j == 0) ? it[0] : it[NP - 1];
-        const int pair = (j == 0) ? pr[0] : pr[NP - 1];
-        const bool mir = !(mq >= mt);
-        const int jt = mir ? mit : miq;
-        float t7[7];
-#pragma unroll
-        for (int k = -3; k <= 3; k++) {
-            float2 zz = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, (jt + k + N) & (N - 1)));
-            t7[k + 3] = mir ? zz.y : zz.x;
-        }
-        out.val = mir ? mt : mq;
-        out.jtot = jt + 1;
-        if constexpr (sizeof(REC) == sizeof(Cand)) {
-            out.tot = (float)(jt + 1) + prb1d7(t7);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 7; k++) out.t7[k] = t7[k];
-        }
-        out.refmir = (mir ? 1 : 0) << 16;
     }
 }
 
@@ -916,14 +816,14 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
     for (int rtile = 0; rtile < nrtile; rtile++) {
     const int ref0 = rtile * g.rpt;                       // references [ref0, ref0 + nvalid) of this tile
     const int nvalid = min(g.rpt, nref - ref0);
-    if (g.dbg && tid < 64) {   // profiling builds that skip a phase still emit in-range records
+    if (RA_DBG(g, ~0) && tid < 64) {   // profiling builds that skip a phase still emit in-range records
         pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
         for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
     }
     // ---- phase 1: contraction, class by class (static shapes inside a class)
-    if (!(g.dbg & 2)) {
+    if (!RA_DBG(g, 2)) {
         const int r16 = lane & 15, kk = lane >> 4;
-        const int mt_eff = (g.dbg & 8192) ? (mtile & 63) : mtile;      // profiling: operands from an L2-resident subset
+        const int mt_eff = RA_DBG(g, 8192) ? (mtile & 63) : mtile;      // profiling: operands from an L2-resident subset
         const float *Ablk = A + (size_t)(2 * mt_eff + (r16 >> 3)) * g.a_blk;
         const float *Bt = B + (size_t)rtile * g.LBP * 16;
         const int odd = lane & 1;
@@ -948,7 +848,7 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
     // pair = 16*sub + b, b = (ref slot, particle-offset parity): liveness depends on b only,
     // so a wave is either wholly busy or wholly idle in a round.  With 8 waves a wave transforms two
     // pairs per lane group at a time (independent register chains hide the DFT's dependent latency).
-    if (!(g.dbg & 1)) {
+    if (!RA_DBG(g, 1)) {
         const int j = lane & 15, sub = lane >> 4;
         const int nlive = 2 * nvalid;                 // live b values: (b & 7) < nvalid
         for (int idx = wave; idx < nlive; idx += 2 * NW) {
@@ -975,254 +875,6 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
     }
     __syncthreads();
     }   // rtile
-}
-
-// ------------------------------------------------------------------------------------------
-// K-fused: the whole search of one particle inside one workgroup (16 waves); the particle
-// spectra never leave the CU.  Per pass of 2 search offsets:
-//   P1  wave-jobs: polar sampling + ring FFT of both offsets into two LDS ring buffers
-//       (ring_job, as in polar_fft_kernel), Normalize_ring statistics, DC correction;
-//   P2  CCF contraction on `v_mfma_f32_4x4x1_16b_f32`: one MFMA = 16 Fourier bins x
-//       [4 rows = 2 offsets x (Re,Im) D] x [4 cols = 2 references x (Re,Im) C] for one ring;
-//       A operand straight from the LDS ring buffers, B operand (prepared references, unit-major)
-//       streamed from L2; units (16-bin group, reference pair) are spread over the waves;
-//   P3  one N-point complex inverse FFT per (offset, reference) pair + wavefront argmax;
-//   P4  wave 0 folds the pass into the particle's running best with EMAN2's order
-//       (offsets y-outer/x-inner, references ascending, ">=": later wins).
-// References are processed in chunks of f_rc so that the CCF spectra of a pass fit LDS.
-struct __attribute__((aligned(8))) FusedBest { float val, tot; int jtot, mirror, ref, sidx; };
-
-template <int N> struct ZLayoutF {
-    // pair stride == 8 (mod 64) dwords: the 4 pairs x 4 bins of a ds_write_b64 group and the
-    // partner pairs (p, p+4) of a half-wave in the FFT passes are bank-conflict free
-    static constexpr int kBase = 2 * (N + N / 16);
-    static constexpr int kPairStride = kBase + ((8 - kBase % 64) + 64) % 64;
-    static __device__ __forceinline__ int addr(int pair, int slot) { return pair * kPairStride + 2 * (slot + (slot >> 4)); }
-};
-
-template <int N>
-__global__ __launch_bounds__(RA_POLAR_THREADS) void align_fused_kernel(DevGeom g, const float *__restrict__ particles,
-                                                                       float *__restrict__ state, int n,
-                                                                       const float *__restrict__ Bf,
-                                                                       ra_result *__restrict__ res, int nref)
-{
-    typedef ZLayoutF<N> ZL;
-    extern __shared__ __align__(16) float lds[];
-    const int npad = g.pst * g.pst;
-    float *img = lds;
-    float *bufs = lds + ((npad + 3) & ~3);                              // [2][f_sbuf]
-    float *Z = bufs + 2 * g.f_sbuf;                                     // [2*f_rc][kPairStride]
-    float2 *tw_s = reinterpret_cast<float2 *>(Z + 2 * g.f_rc * ZL::kPairStride);   // [maxrin]
-    float2 *qt_s = tw_s + g.maxrin;                                     // [n_qtab]
-    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));
-    int4 *jobs_s = inst_s + g.f_n_inst;
-    Cand *pc = reinterpret_cast<Cand *>(jobs_s + g.f_n_job);            // [2*f_rc]
-    float *instw_s = reinterpret_cast<float *>(pc + 2 * g.f_rc);
-    int *aoff_s = reinterpret_cast<int *>(instw_s + g.f_n_inst);        // [f_nstep]
-    float *red = reinterpret_cast<float *>(aoff_s + g.f_nstep);         // as in polar_fft_kernel
-    const int p = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwave = blockDim.x >> 6;
-    if (p >= n) return;
-
-    const float *src = particles + (size_t)p * g.nx * g.nx;
-    for (int i = tid; i < npad; i += blockDim.x) {
-        const int y = i / g.pst - g.bd, x = i % g.pst - g.bd;
-        img[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.nx) ? src[y * g.nx + x] : 0.f;
-    }
-    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
-    for (int i = tid; i < g.maxrin; i += blockDim.x) tw_s[i] = g.tw[i];
-    for (int i = tid; i < g.n_qtab; i += blockDim.x) qt_s[i] = g.qtab[i];
-    for (int i = tid; i < g.f_n_inst; i += blockDim.x) { inst_s[i] = g.f_inst[i]; instw_s[i] = g.f_instw[i]; }
-    for (int i = tid; i < g.f_n_job; i += blockDim.x) jobs_s[i] = g.f_jobs[i];
-    for (int i = tid; i < g.f_nstep; i += blockDim.x) aoff_s[i] = g.f_aoff[i];
-    for (int i = tid; i < 2 * g.f_sbuf; i += blockDim.x) bufs[i] = 0.f;   // the slack behind the last ring stays zero
-    if (tid == 0) red[22] = 0.f;      // a runtime zero: per-phase lane arithmetic derived from it cannot be hoisted out of the pass loop
-    const float sx0 = state[2 * p], sy0 = state[2 * p + 1];
-    const Window w = particle_window(g, sx0, sy0);
-    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
-    const int nx1 = 2 * g.nkx + 1;
-
-    FusedBest best; best.val = -1.0e23f; best.tot = 1.f; best.jtot = 1; best.mirror = 0; best.ref = 0; best.sidx = 0;
-    int best_order = -1;
-
-    const int npass = (g.nshift + 1) / 2;
-    for (int pass = 0; pass < npass; pass++) {
-        if (tid < 2) {
-            const int si = min(pass * 2 + tid, g.nshift - 1);
-            red[16 + 2 * tid] = cxf + g.shift_x[si];
-            red[17 + 2 * tid] = cyf + g.shift_y[si];
-        }
-        __syncthreads();
-        // ---- P1: polar sampling + ring FFT of the two offsets
-        if (!(g.dbg & 1024))
-#pragma unroll 1
-        for (int job = wave; job < g.f_n_job; job += nwave) {
-            const int4 jd = jobs_s[job];
-            switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-            case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.f_sbuf); break;
-            }
-        }
-        __syncthreads();
-        if (wave < 2) {      // Normalize_ring statistics of offset slot `wave` (fixed butterfly: reproducible)
-            float a = 0.f, q = 0.f;
-            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
-            a = wave_sum(a); q = wave_sum(q);
-            if (lane == 0) {
-                float avg = 0.f, rsg = 1.f;
-                if (g.mode == RA_MODE_MREF) {
-                    const float nn = g.nn_weight;
-                    avg = a / nn;
-                    rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
-                }
-                red[8 + wave] = avg; red[12 + wave] = rsg;
-            }
-        }
-        __syncthreads();
-        if (g.mode == RA_MODE_MREF && tid < 2 * g.nring) {
-            const int s = tid / g.nring, i = tid - s * g.nring;
-            const int4 ri = g.ringinfo[i];
-            bufs[s * g.f_sbuf + ri.x] -= red[8 + s] * (float)ri.z;
-        }
-        __syncthreads();
-
-        for (int chunk = 0; chunk < g.f_nchunk; chunk++) {
-            const int rc_live = min(g.f_rc, nref - chunk * g.f_rc);
-            // ---- P2: contraction, units (16-bin group, reference pair) of this wave
-            if (!(g.dbg & 2048)) {
-                const int ln = lane + __float_as_int(red[22]);
-                const int blk = ln >> 2, irow = ln & 3, odd = ln & 1;
-                const float rs = red[12 + (irow >> 1)];
-                const float *abase = bufs + (irow >> 1) * g.f_sbuf + 2 * blk + (irow & 1);
-                const float *bchunk = Bf + (size_t)chunk * g.f_bchunk + ln;
-                const int u1 = g.f_uoff[wave + 1];
-#pragma unroll 1
-                for (int u = g.f_uoff[wave]; u < u1; u++) {
-                    const int4 ud = g.f_units[u];
-                    const int grp = ud.x, rp = ud.y;
-                    const int st0 = g.f_goff[grp], nst = g.f_goff[grp + 1] - st0;
-                    const float *bp = bchunk + ud.z;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    int st = 0;
-                    for (; st + 4 <= nst; st += 4) {
-                        const int o0 = aoff_s[st0 + st], o1 = aoff_s[st0 + st + 1], o2 = aoff_s[st0 + st + 2], o3 = aoff_s[st0 + st + 3];
-                        const float b0 = bp[(st) * 64], b1 = bp[(st + 1) * 64], b2 = bp[(st + 2) * 64], b3 = bp[(st + 3) * 64];
-                        const float a0 = abase[o0] * rs, a1 = abase[o1] * rs, a2 = abase[o2] * rs, a3 = abase[o3] * rs;
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, b2, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, b3, acc, 0, 0, 0);
-                    }
-                    for (; st < nst; st++) {
-                        const float a0 = abase[aoff_s[st0 + st]] * rs, b0 = bp[st * 64];
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc, 0, 0, 0);
-                    }
-                    // acc[i], i = (offset slot, Re/Im D); lane = 4*bin + (ref in pair, Re/Im C).
-                    // 2x2 block exchange between the Re/Im column lanes of one reference:
-                    float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-                    float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                    float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
-                    float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
-                    float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
-                    const int k = 16 * grp + blk;
-                    const int pair = (2 * rp + ((ln & 3) >> 1)) * 2 + odd;     // (ref in chunk) * 2 + offset slot
-                    if (k <= N / 2) {
-                        *reinterpret_cast<float2 *>(Z + ZL::addr(pair, k)) = make_float2(apd + bpc, cmb + amd);
-                        *reinterpret_cast<float2 *>(Z + ZL::addr(pair, (N - k) & (N - 1))) = make_float2(apd - bpc, amd - cmb);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- P3: inverse FFT + argmax; a wave takes 4 pairs {b, b+4, b+1, b+5} of an 8-block
-            if (!(g.dbg & 4096)) {
-                const int ln = lane + __float_as_int(red[22]);
-                const int j = ln & 15, sub = ln >> 4;
-                float2 twl[16];
-#pragma unroll
-                for (int n0 = 0; n0 < 16; n0++) {
-                    float2 t = tw_s[(n0 * j * (g.maxrin / N)) & (g.maxrin - 1)];
-                    twl[n0] = make_float2(t.x, -t.y);
-                }
-                const int nround = 2 * ((2 * rc_live + 7) / 8);
-                for (int r = wave; r < nround; r += nwave) {
-                    const int pair = 8 * (r >> 1) + 2 * (r & 1) + (sub >> 1) + 4 * (sub & 1);
-                    if (pair < 2 * rc_live) {      // uniform over the 16-lane group
-                        Cand c;
-                        ifft_argmax_core<ZL, N, 1, 1, Cand>(Z, twl, pair, pair, j, c);
-                        if (j == 0) { c.refmir |= chunk * g.f_rc + (pair >> 1); pc[pair] = c; }
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- P4: fold the pass into the running best (wave 0; key = (value, EMAN2 visiting order))
-            if (wave == 0) {
-                float v = -3.0e38f, tot = 0.f; int jt = 0, rm = 0, order = -1, sidx = 0;
-                if (lane < 2 * rc_live) {
-                    sidx = pass * 2 + (lane & 1);
-                    const int iy = sidx / nx1 - g.nky, ix = sidx % nx1 - g.nkx;
-                    const bool ok = sidx < g.nshift && ix >= -w.lkx && ix <= w.rkx && iy >= -w.lky && iy <= w.rky;
-                    if (ok) {
-                        const Cand c = pc[lane];
-                        v = c.val; tot = c.tot; jt = c.jtot; rm = c.refmir;
-                        order = sidx * nref + (rm & 0xffff);
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(v, o), ot = __shfl_xor(tot, o);
-                    const int oj = __shfl_xor(jt, o), orm = __shfl_xor(rm, o), oo = __shfl_xor(order, o), os = __shfl_xor(sidx, o);
-                    if (oo >= 0 && (order < 0 || ov > v || (ov == v && oo > order))) { v = ov; tot = ot; jt = oj; rm = orm; order = oo; sidx = os; }
-                }
-                if (order >= 0 && (best_order < 0 || v > best.val || (v == best.val && order > best_order))) {
-                    best.val = v; best.tot = tot; best.jtot = jt; best.mirror = rm >> 16; best.ref = rm & 0xffff; best.sidx = sidx;
-                    best_order = order;
-                }
-            }
-        }
-    }
-    // ---- parameters (ang_n, ormq tail, combine_params2), as finalize_kernel
-    if (tid == 0) {
-        const float ang = fmodf(((best.tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
-        const float ixw = g.shift_x[best.sidx], iyw = g.shift_y[best.sidx];
-        const float sx = -ixw, sy = -iyw;
-        const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
-        const float sxs = sx * co - sy * so, sys = sx * so + sy * co;
-        const double a = (double)ang * M_PI / 180.0, c = cos(a), s = sin(a);
-        const double tx = c * (double)(-w.sxi) + s * (double)(-w.syi) + (double)sxs;
-        const double ty = -s * (double)(-w.sxi) + c * (double)(-w.syi) + (double)sys;
-        double alpha = atan2(s, c) * 180.0 / M_PI;
-        alpha = fmod(alpha, 360.0);
-        if (alpha < 0) alpha += 360.0;
-        if (alpha >= 360.0) alpha -= 360.0;
-        ra_result r;
-        r.alpha = (float)alpha; r.sx = (float)tx; r.sy = (float)ty;
-        r.mirror = best.mirror; r.ref_id = best.ref; r.peak = best.val; r.angle_bin = best.jtot; r.shift_idx = best.sidx;
-        res[p] = r;
-        state[2 * p] = w.sxi + ixw;
-        state[2 * p + 1] = w.syi + iyw;
-    }
-}
-
-// prepared references -> unit-major B stream of the fused kernel (Applyws weights and 1/maxrin folded in)
-__global__ void pack_refs_fused_kernel(DevGeom g, const float *__restrict__ refspec, int nref, float *__restrict__ Bf)
-{
-    const int total = g.f_nchunk * g.f_bchunk;
-    const float inv = 1.0f / (float)g.maxrin;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int ch = idx / g.f_bchunk, f = idx - ch * g.f_bchunk;
-        const int code = g.f_bsrc[f];
-        float v = 0.f;
-        if (code >= 0) {
-            const int e = code >> 5, ref = ch * g.f_rc + ((code >> 1) & 15);
-            if (((code >> 1) & 15) < g.f_rc && ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (code & 1)] * g.ent_wgt[e] * inv;
-        }
-        Bf[idx] = v;
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -227,6 +227,10 @@ class RefFreeAligner:
             else:
                 got = self.engine.filter_references(self.tavg, fl, aa, center=1 if center == 1 else 0, normalize=False)
                 cs = [float(got[0, 0]), float(got[0, 1])]
+        elif center == -1 and (cs[0] or cs[1]):
+            # no user function: the average is still shifted by -cs, together with the parameter correction
+            # inside ra_align (fshift(tavg, -cs[0], -cs[1]), test_reffree_gpu_align.py:403-410)
+            self.engine.filter_references(self.tavg, 0.0, 0.0, center=-1, cs_in=[cs], normalize=False)
         self.cs = cs
         self.engine.set_references(self.tavg)
         self.engine.align(self.particles, self.state, self.result, cs if (cs[0] or cs[1]) else None)

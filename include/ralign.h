@@ -81,6 +81,21 @@ int *get_num_ref(void);
 /* cuda/gpu_aln_noref.cu:119 (exported, not in the header) */
 void reset_shifts(const float shift_range, const float shift_step);
 
+/* class-resident reference-free alignment (GPU-ISAC), cuda/gpu_aln_noref.h:94-109, gpu_aln_noref.cu:559-782:
+ * particles sorted by class (sbj_cid_list non-decreasing runs), one reference per class; every call aligns each
+ * particle to the average of its own class, transforms it and rebuilds the class averages on the device.
+ * cuda/gpu_aln_noref.h:94-99.  Returns host-visible AlignParam[sbj_num]; ref_id holds the class id. */
+AlignParam *ref_free_alignment_2D_init(const AlignConfig *aln_cfg, const float **sbj_data_list,
+                                       const float **ref_data_list, const int *sbj_cid_list,
+                                       const unsigned int device_id);
+/* cuda/gpu_aln_noref.h:101-105 */
+bool ref_free_alignment_2D_size_check(const AlignConfig *cfg, const unsigned int device_id, const float request,
+                                      const bool verbose);
+/* cuda/gpu_aln_noref.h:107 */
+void ref_free_alignment_2D(void);
+/* cuda/gpu_aln_noref.h:109 ; tangent low-pass of every class average (gpu_aln_noref.cu:786-816) */
+void ref_free_alignment_2D_filter_references(const float cutoff_freq, const float falloff);
+
 /* ------------------------------------------------------ (2) handle-based API */
 
 #define RA_OK            0
@@ -182,6 +197,10 @@ int  ra_class_averages(ra_engine *e, const float *d_sums, const int *d_counts, i
  * model_circle(last_ring) if normalize != 0 (:563).  h_cs_out [nimg][2] (may be NULL) = applied centres. */
 int  ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
                           const float *h_cs_in, int normalize, float *h_cs_out);
+
+/* class-resident mode only (extension, no counterpart in the reference header, where the averages stay in
+ * device textures): copy the current class averages [ref_num][nx][nx] to host memory */
+int  ra_isac_get_references(float *h_out);
 
 /* block until the engine's stream is idle */
 int  ra_sync(ra_engine *e);

@@ -140,7 +140,12 @@ def tanl_filter_values(nx, fl, aa):
     ky = np.arange(nx)
     ky = np.where(ky > nx // 2, ky - nx, ky).astype(np.float64)[:, None] / nx
     kx = np.arange(nx // 2 + 1).astype(np.float64)[None, :] / nx
-    d = np.sqrt(kx * kx + ky * ky)
+    return tanl_profile(np.sqrt(kx * kx + ky * ky), fl, aa)
+
+
+def tanl_profile(d, fl, aa):
+    """tangent low-pass H(d) at absolute frequency d; pinned by tests/golden/tanl_ref.npz, which holds the
+    output of the reference tree's own kernel text (cuda/gpu_aln_noref.cu:799-814)"""
     c = math.pi / (2.0 * aa * fl)
     return 0.5 * (np.tanh(c * (d + fl)) - np.tanh(c * (d - fl)))
 

@@ -53,10 +53,12 @@ def test_synthetic_generator_is_seeded():
 def header_symbols():
     txt = open(os.path.join(ROOT, "include", "ralign.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"\b([a-z_0-9]+)\s*\(", txt)
+    names = re.findall(r"\b([A-Za-z_0-9]+)\s*\(", txt)
     return sorted(set(n for n in names if n.startswith("ra_") or n in (
         "print_gpu_info", "gpu_clear", "pre_align_init", "pre_align_size_check", "pre_align_fetch", "pre_align_run",
-        "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts")))
+        "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
+        "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
+        "ref_free_alignment_2D_filter_references")))
 
 
 def test_library_exports_every_declared_symbol():
@@ -242,3 +244,56 @@ def test_mdf_hdf5_writer_round_trip_and_libhdf5_check(tmp_path):
         p = tmp_path / "bad.hdf"
         p.write_bytes(b"not hdf5" * 100)
         mdfio.read_mdf_stack(str(p))
+
+
+def test_reference_binding_statements_run_unchanged(golden_dir):
+    """every `cu_module.<symbol>.restype = ...` statement the reference's drivers execute at import
+    (test_mref_gpu_align.py:95-97, test_reffree_gpu_align.py:97-99, test_reffree.py:56-57,
+    test_mref_cheng_yu_bdb_cuda.py:60-63) and every library function they call resolves in libralign_hip.so.
+    The statement list is data collected from the reference tree by tests/golden/make_binding_fixture.py."""
+    import json
+    cu_module = ctypes.CDLL(api.LIB_PATH)     # what `ctypes.CDLL(CUDA_PATH + "gpu_aln_pack.so")` becomes
+    fx = json.load(open(os.path.join(golden_dir, "binding_symbols.json")))
+    assert set(fx) == {"test_mref_gpu_align.py", "test_reffree_gpu_align.py", "test_reffree.py", "test_mref_cheng_yu_bdb_cuda.py"}
+    env = {"ctypes": ctypes, "cu_module": cu_module}
+    for driver, d in fx.items():
+        assert d["restype_statements"], driver
+        for st in d["restype_statements"]:
+            exec("cu_module.%s.restype = %s" % (st["symbol"], st["restype"]), env)      # AttributeError if not exported
+        for name in d["called"]:
+            assert hasattr(cu_module, name), (driver, name)
+    assert cu_module.ref_free_alignment_2D_init.restype is ctypes.c_ulonglong
+
+
+def test_tangent_filter_profile_matches_the_reference_tree(golden_dir):
+    """H(d) of the oracle's filt_tanl against the output of the reference tree's kernel text
+    (cuda/gpu_aln_noref.cu:786-816, run on the host by tests/golden/make_reftree_pins.py)"""
+    from oracle import refine_oracle as ro
+    t = np.load(os.path.join(golden_dir, "tanl_ref.npz"))
+    assert int(t["ncase"]) == 6
+    for k in range(int(t["ncase"])):
+        nx, fl, aa = t["par%d" % k]
+        got = ro.tanl_profile(t["d%d" % k].astype(np.float64), fl, aa)
+        assert np.abs(got - t["H%d" % k]).max() < 5e-7       # float tanhf vs double tanh
+    # and the filter the oracle applies is that profile on EMAN2's frequency grid (kx/nx, ky/ny)
+    H = ro.tanl_filter_values(90, 0.2, 0.1)
+    assert H.shape == (90, 46) and abs(H[0, 0] - 1.0) < 1e-6 and H[45, 45] < 1e-6
+    assert abs(H[0, 18] - 0.5) < 1e-6            # |k| = fl = 18/90: the half-height point
+
+
+def test_filter_clamps_match_the_reference_run_log(golden_dir):
+    """notebook/00 cell 3 logs "cut-off 0.120 / fall-off 0.200": ref_ali2d clamps fl to [0.12, 0.4] and aa to <= 0.2"""
+    import json
+    from oracle import refine_oracle as ro
+    rows = json.load(open(os.path.join(golden_dir, "filter_log.json")))["cutoff_falloff"]
+    assert [0.12, 0.2] in rows
+    assert min(r[0] for r in rows) == 0.12 and max(r[1] for r in rows) == 0.2
+    # an FSC that drops at once drives fit_tanh below the lower clamp and above the fall-off clamp
+    n = 46
+    freq = [i / 90.0 for i in range(n)]
+    fsc = [1.0, 0.9, 0.3, 0.05] + [0.0] * (n - 4)
+    img = np.zeros((90, 90), np.float32); img[45, 45] = 1.0
+    _, _, fl, aa = ro.ref_ali2d(None, 0, img, [freq, fsc, [1.0] * n])
+    assert fl == 0.12 and aa <= 0.2
+    f2, a2 = api.fit_tanh([list(freq), list(fsc), [1.0] * n])
+    assert max(min(0.4, f2), 0.12) == 0.12

@@ -169,7 +169,7 @@ def test_model_circle_and_normalize_mask():
     np.testing.assert_allclose(b, geometry.normalize_mask(img, m, 1), atol=1e-5)
 
 
-def test_rot_shift2d_identity_mirror_and_numpy_twin():
+def test_rot_shift2d_identity_and_mirror_rule():
     rng = np.random.default_rng(6)
     for nx in (32, 33):
         img = rng.normal(size=(nx, nx)).astype(np.float32)
@@ -181,9 +181,25 @@ def test_rot_shift2d_identity_mirror_and_numpy_twin():
         # integer shift moves content by (+sx, +sy)
         sh = orc.rot_shift2d(img, 0, 2, -1, 0)
         np.testing.assert_allclose(sh[5:-5, 5:-5], np.roll(np.roll(img, 2, 1), -1, 0)[5:-5, 5:-5], atol=1e-6)
-        for ang, sx, sy, m in [(33.3, 2.0, -1.0, 1), (190.0, -0.5, 0.25, 0), (359.9, 3, 3, 1)]:
-            np.testing.assert_allclose(orc.rot_shift2d(img, ang, sx, sy, m), synth.rot_shift2d_np(img, ang, sx, sy, m),
-                                       atol=2e-5)
+
+
+def test_rot_shift2d_matches_the_reference_tree_bit_for_bit(golden_dir):
+    """tests/golden/rot_shift2d_ref.npz holds what the reference tree's own text of rot_scale_trans2D_background /
+    quadri_background (notebook/02 cell 2) computes, compiled as host C++ by tests/golden/make_reftree_pins.py.
+    The oracle must reproduce it exactly."""
+    g = np.load(os.path.join(golden_dir, "rot_shift2d_ref.npz"))
+    assert int(g["ncase"]) == 3
+    for k in range(int(g["ncase"])):
+        img, ang, dx, dy, out = (g["%s%d" % (n, k)] for n in ("img", "ang", "dx", "dy", "out"))
+        for i in range(len(img)):
+            got = orc.rot_shift2d(img[i], float(ang[i]), float(dx[i]), float(dy[i]), 0)
+            np.testing.assert_array_equal(got, out[i])
+            # mirror = the notebook's python line applied to the same output
+            start = 1 - img.shape[-1] % 2
+            want = out[i].copy(); want[:, start:] = want[:, start:][:, ::-1]
+            np.testing.assert_array_equal(orc.rot_shift2d(img[i], float(ang[i]), float(dx[i]), float(dy[i]), 1), want)
+            if abs(dx[i]) < img.shape[-1]:      # the generator's numpy twin (synthetic stacks only) agrees to rounding
+                np.testing.assert_allclose(synth.rot_shift2d_np(img[i], ang[i], dx[i], dy[i], 0), out[i], atol=2e-6)
 
 
 def test_search_range_rule():
