@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = [
     "print_gpu_info", "gpu_clear", "pre_align_init", "pre_align_size_check", "pre_align_fetch",
     "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
     "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
-    "ref_free_alignment_2D_filter_references", "ra_isac_get_references",
+    "ref_free_alignment_2D_filter_references", "ra_isac_get_references", "ra_legacy_bytes",
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
@@ -140,6 +140,8 @@ def load_library(path=None):
     L.ref_free_alignment_2D_filter_references.restype = None
     L.ref_free_alignment_2D_filter_references.argtypes = [ctypes.c_float, ctypes.c_float]
     L.ra_isac_get_references.argtypes = [float_ptr]
+    L.ra_legacy_bytes.restype = ctypes.c_size_t
+    L.ra_legacy_bytes.argtypes = [ctypes.c_uint, ctypes.POINTER(AlignConfig)]
     if path is None:
         _lib = L
     return L

@@ -299,9 +299,47 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
     return RA_OK;
 }
 
+// device workspace of one engine, shared by ra_create and the size checks of the reference surface
+// (pre_align_size_check / ref_free_alignment_2D_size_check), so that the estimate cannot drift from what is allocated
+struct WorkspacePlan {
+    int chunk;
+    size_t a_floats, cand_recs, refspec_floats, b_floats, alscratch_floats, zscr_recs;
+    size_t bytes;          // everything ra_create and the first reference update take from the device
+};
+
+static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, bool generic)
+{
+    WorkspacePlan w{};
+    const int a_blk = g.LBP * 8 + 64, nrtile = (cfg.nref + 7) / 8;
+    int chunk = cfg.chunk > 0 ? cfg.chunk : 8192;
+    chunk = std::min((chunk + 1) & ~1, 32768);      // class_sum_kernel keeps a chunk's member list in LDS
+    const int ngroup = g.nshift_pad / 4;
+    {   // keep the spectra workspace of one chunk within ~12 GB (large boxes: tens of MB per particle)
+        const size_t per_particle = (size_t)ngroup * a_blk * sizeof(float);
+        const size_t cap = std::max<size_t>(2, ((size_t)12 << 30) / per_particle);
+        if ((size_t)chunk > cap) chunk = (int)(cap & ~(size_t)1);
+    }
+    w.chunk = chunk;
+    w.a_floats = ((size_t)chunk * ngroup + 2) * a_blk;
+    w.cand_recs = ((size_t)chunk * g.nshift_pad + 8) * nrtile;
+    w.refspec_floats = (size_t)cfg.nref * g.lring;
+    w.b_floats = (size_t)nrtile * g.LBP * 16;
+    w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
+    w.zscr_recs = generic ? (size_t)512 * 64 * g.maxrin : 0;
+    const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
+    const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
+    const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
+    w.bytes = (w.a_floats + w.refspec_floats + w.b_floats + w.alscratch_floats + 2) * sizeof(float) + w.cand_recs * sizeof(CandT) +
+              w.zscr_recs * sizeof(float2) + refine + tables;
+    // every hipMalloc is rounded up to the allocator's granule; ~40 small tables and buffers
+    w.bytes += (size_t)48 * (2 << 20);
+    return w;
+}
+
 extern "C" const char *ra_last_error(void) { return g_last_error.c_str(); }
 
 typedef void (*ccf_fn)(DevGeom, const float *, const float *, int, int, int, CandT *);
+static ccf_fn select_ccf(int maxrin);
 static ccf_fn select_ccf(int maxrin)
 {
     switch (maxrin) {
@@ -311,6 +349,25 @@ static ccf_fn select_ccf(int maxrin)
     case 32: return ccf_kernel<32>;
     default: return nullptr;
     }
+}
+
+// the LDS-resident kernels cover <= 48 rings of 8..256 samples and images whose padded copy plus four ring buffers
+// fit one CU's LDS; everything else runs the size-generic kernels
+static ccf_fn select_ccf(int maxrin);
+static bool fits_specialised_kernels(const Geometry &g0, const ra_config &cfg)
+{
+    bool fast = g0.nring <= 4 * RA_CCF_MAXNS && select_ccf(g0.maxrin) != nullptr && g0.numr[2] >= 8;
+    const int bd0 = (int)std::ceil(std::max(cfg.xrng, cfg.yrng)) + 2, pst0 = g0.nx + 2 * bd0;
+    const int sbuf0 = (g0.lring + 31) / 32 * 32 + 8;
+    if ((size_t)(pst0 * pst0 + 4 * sbuf0 + 2 * g0.maxrin + 4096) * sizeof(float) > 160 * 1024) fast = false;
+    int ncls = 0, prev = -1;
+    for (int k = 0; k < g0.nbins; k++) {
+        const int ns = (g0.bin_offp[k + 1] - g0.bin_offp[k]) / 4;
+        if (ns != prev) { ncls++; prev = ns; }
+    }
+    if (ncls > 8) fast = false;
+    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) fast = false;
+    return fast;
 }
 
 extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
@@ -337,26 +394,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         delete e;
         return RA_ERR_ARG;
     }
-    {   // the LDS-resident kernels cover <= 48 rings of 8..256 samples and images whose padded copy
-        // plus four ring buffers fit one CU's LDS; everything else runs the size-generic kernels
-        const Geometry &g0 = e->geo;
-        bool fast = g0.nring <= 4 * RA_CCF_MAXNS && select_ccf(g0.maxrin) != nullptr && g0.numr[2] >= 8;
-        const int bd0 = (int)std::ceil(std::max(cfg->xrng, cfg->yrng)) + 2, pst0 = g0.nx + 2 * bd0;
-        const int sbuf0 = (g0.lring + 31) / 32 * 32 + 8;
-        if ((size_t)(pst0 * pst0 + 4 * sbuf0 + 2 * g0.maxrin + 4096) * sizeof(float) > 160 * 1024) fast = false;
-        int ncls = 0, prev = -1;
-        for (int k = 0; k < g0.nbins; k++) {
-            const int ns = (g0.bin_offp[k + 1] - g0.bin_offp[k]) / 4;
-            if (ns != prev) { ncls++; prev = ns; }
-        }
-        if (ncls > 8) fast = false;
-        if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) fast = false;
-        e->generic = !fast;
-        if (e->geo.maxrin > 4096) {
-            g_last_error = "rings longer than 4096 samples are not supported";
-            delete e;
-            return RA_ERR_ARG;
-        }
+    e->generic = !fits_specialised_kernels(e->geo, *cfg);
+    if (e->geo.maxrin > 4096) {
+        g_last_error = "rings longer than 4096 samples are not supported";
+        delete e;
+        return RA_ERR_ARG;
     }
     e->nrtile = (cfg->nref + 7) / 8;
     e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
@@ -398,30 +440,21 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
 
     // workspace: bin-major spectra of `chunk` particles + candidate records
-    int chunk = cfg->chunk > 0 ? cfg->chunk : 8192;
-    chunk = std::min((chunk + 1) & ~1, 32768);      // class_sum_kernel keeps a chunk's member list in LDS
-    const int ngroup = g.nshift_pad / 4;
-    {   // keep the spectra workspace of one chunk within ~12 GB (large boxes: tens of MB per particle)
-        const size_t per_particle = (size_t)ngroup * e->dg.a_blk * sizeof(float);
-        const size_t cap = std::max<size_t>(2, ((size_t)12 << 30) / per_particle);
-        if ((size_t)chunk > cap) chunk = (int)(cap & ~(size_t)1);
-    }
+    const WorkspacePlan wp = plan_workspace(g, *cfg, e->generic);
+    const int chunk = wp.chunk;
     e->chunk = chunk;
-    const size_t a_floats = ((size_t)chunk * ngroup + 2) * e->dg.a_blk;
-    const size_t cand_recs = ((size_t)chunk * g.nshift_pad + 8) * e->nrtile;
-    if ((rc = dev_alloc(e, &e->d_A, a_floats, true)) ||
-        (rc = dev_alloc(e, &e->d_cand, cand_recs, true)) ||
-
-        (rc = dev_alloc(e, &e->d_refspec, (size_t)cfg->nref * g.lring, true)) ||
-        (rc = dev_alloc(e, &e->d_B, (size_t)e->nrtile * g.LBP * 16, true)) ||
+    if ((rc = dev_alloc(e, &e->d_A, wp.a_floats, true)) ||
+        (rc = dev_alloc(e, &e->d_cand, wp.cand_recs, true)) ||
+        (rc = dev_alloc(e, &e->d_refspec, wp.refspec_floats, true)) ||
+        (rc = dev_alloc(e, &e->d_B, wp.b_floats, true)) ||
         (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
-        (rc = dev_alloc(e, &e->d_alscratch, (size_t)chunk * g.nx * g.nx, false))) {
+        (rc = dev_alloc(e, &e->d_alscratch, wp.alscratch_floats, false))) {
         ra_destroy(e);
         return rc;
     }
     if (e->generic) {
         e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
-        if ((rc = dev_alloc(e, &e->d_zscr, (size_t)e->g_nblk * 64 * g.maxrin, false))) { ra_destroy(e); return rc; }
+        if ((rc = dev_alloc(e, &e->d_zscr, wp.zscr_recs, false))) { ra_destroy(e); return rc; }
     }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
@@ -933,14 +966,19 @@ ra_config legacy_config(const AlignConfig *c, unsigned device, int mode)
 
 size_t legacy_bytes(unsigned num_particles, const AlignConfig *c)
 {
+    // everything pre_align_init takes from the device: the engine's workspace (same plan as ra_create) plus the
+    // resident batch (particles, aligned images, state, results), the references and the class sums
     Geometry g;
-    if (!build_rings(g, (int)c->img_dim, 1, (int)c->ring_num, 1) || !build_shifts(g, c->shift_rng_x, c->shift_rng_y, c->shift_step))
+    if (c->img_dim < 8 || c->ref_num < 1 || !build_rings(g, (int)c->img_dim, 1, (int)c->ring_num, 1) ||
+        !build_shifts(g, c->shift_rng_x, c->shift_rng_y, c->shift_step))
         return (size_t)-1;
-    size_t npix = (size_t)c->img_dim * c->img_dim;
-    size_t chunk = std::min<size_t>(8192, (c->sbj_num + 1) & ~1u);
-    size_t ws = (chunk * (g.nshift_pad / 4) + 2) * ((size_t)g.LBP * 8 + 64) * 4 + (chunk * g.nshift_pad + 8) * ((c->ref_num + 7) / 8) * sizeof(CandT);
-    size_t imgs = ((size_t)c->sbj_num * 2 + c->ref_num * 3) * npix * 4;
-    return ws + imgs + (size_t)num_particles * 64;
+    ra_config rc = legacy_config(c, 0, RA_MODE_MREF);
+    rc.chunk = (int)std::min<unsigned>(8192, std::max(2u, c->sbj_num));
+    const WorkspacePlan wp = plan_workspace(g, rc, !fits_specialised_kernels(g, rc));
+    const size_t npix = (size_t)c->img_dim * c->img_dim, B = c->sbj_num, R = c->ref_num;
+    const size_t batch = B * npix * 4 * 2 + B * (2 * sizeof(float) + sizeof(ra_result)) + R * npix * 4 * 3 + R * 4;
+    (void)num_particles;     // the AlignParam array lives in pinned host memory
+    return wp.bytes + batch + (size_t)8 * (2 << 20);
 }
 
 void run_search(int start, int stop, int mode)
@@ -1015,7 +1053,7 @@ extern "C" AlignParam *pre_align_init(const unsigned int num_particles, const Al
     L.cfg = *aln_cfg;
     L.num_particles = num_particles;
     ra_config rc = legacy_config(aln_cfg, device_id, RA_MODE_MREF);
-    rc.chunk = (int)std::min<unsigned>(8192, aln_cfg->sbj_num);
+    rc.chunk = (int)std::min<unsigned>(8192, std::max(2u, aln_cfg->sbj_num));
     if (ra_create(&L.eng, &rc)) die("pre_align_init");
     const size_t npix = (size_t)aln_cfg->img_dim * aln_cfg->img_dim;
     const size_t B = aln_cfg->sbj_num, R = aln_cfg->ref_num;
@@ -1267,4 +1305,10 @@ extern "C" int ra_isac_get_references(float *h_out)
     const size_t npix = (size_t)L.cfg.img_dim * L.cfg.img_dim;
     RA_HIP(hipMemcpy(h_out, L.d_ref, (size_t)L.cfg.ref_num * npix * sizeof(float), hipMemcpyDeviceToHost));
     return RA_OK;
+}
+
+// diagnostic: the device-memory estimate behind pre_align_size_check, in bytes ((size_t)-1 = bad geometry)
+extern "C" size_t ra_legacy_bytes(const unsigned int num_particles, const AlignConfig *cfg)
+{
+    return cfg ? legacy_bytes(num_particles, cfg) : (size_t)-1;
 }

@@ -202,6 +202,9 @@ int  ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float
  * device textures): copy the current class averages [ref_num][nx][nx] to host memory */
 int  ra_isac_get_references(float *h_out);
 
+/* diagnostic: the device-memory estimate (bytes) behind pre_align_size_check; (size_t)-1 for a bad geometry */
+size_t ra_legacy_bytes(const unsigned int num_particles, const AlignConfig *cfg);
+
 /* block until the engine's stream is idle */
 int  ra_sync(ra_engine *e);
 
