@@ -15,6 +15,7 @@
 #include "ralign_geom.h"
 #include "ralign_kernels.h"
 #include "ralign_generic.h"
+#include "ralign_fused.h"
 #include "ralign_refine.h"
 
 using namespace ralign;
@@ -32,6 +33,14 @@ static thread_local std::string g_last_error;
             return RA_ERR_HIP;                                                                \
         }                                                                                     \
     } while (0)
+
+// device workspace of one engine, shared by ra_create and the size checks of the reference surface
+// (pre_align_size_check / ref_free_alignment_2D_size_check), so that the estimate cannot drift from what is allocated
+struct WorkspacePlan {
+    int chunk;
+    size_t a_floats, cand_recs, refspec_floats, b_floats, alscratch_floats, zscr_recs;
+    size_t bytes;          // everything ra_create and the first reference update take from the device
+};
 
 struct ra_engine {
     ra_config cfg{};
@@ -62,6 +71,19 @@ struct ra_engine {
     double2 *d_rfT = nullptr, *d_rfF = nullptr, *d_rftw = nullptr;
     float *d_rfmean = nullptr, *d_rffsc = nullptr, *d_rfcs = nullptr;
     bool refs_ready = false;
+    // particle-resident search kernel (ralign_fused.h)
+    FusedPlanHost fplan;
+    std::vector<int> qoff;              // quadrant-table offset per log2(ring length)
+    std::vector<float> ringw_h;
+    bool fused = false;                 // plan valid for the current window and not disabled (RALIGN_FUSED=0)
+    float *d_Bf = nullptr, *d_cdc = nullptr;
+    int4 *d_fjobs = nullptr, *d_finst = nullptr;
+    float *d_finstw = nullptr, *d_fcdcw = nullptr;
+    int *d_fbsrc = nullptr;
+    size_t f_cap_inst = 0, f_cap_job = 0, f_cap_b = 0;
+    CandT *d_fcand = nullptr;           // [(chunk * nshift_pad + 8)][nzr]
+    bool unfused_ws = false;            // spectra workspace of the two-kernel path allocated
+    WorkspacePlan wp{};
     // kernel timing
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -176,7 +198,8 @@ static int build_device_geometry(ra_engine *e)
     std::vector<float> instw;
     std::vector<int4> jobs;
     {
-        std::vector<int> qoff(32, -1);
+        std::vector<int> &qoff = e->qoff;
+        qoff.assign(32, -1);
         const double qpi = 2 * atan(1.0);
         for (int i = 0; i < g.nring; i++) {
             const int n = g.numr[3 * i + 2], lg = ilog2_floor(n);
@@ -222,6 +245,7 @@ static int build_device_geometry(ra_engine *e)
         if (!e->generic) make_jobs(4, jobs, inst, instw);
     }
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
+    e->ringw_h = ringw;
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
     // row stride of the padded LDS image: the lanes of a ring job sit along an arc and across consecutive radii, so
@@ -299,14 +323,6 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
     return RA_OK;
 }
 
-// device workspace of one engine, shared by ra_create and the size checks of the reference surface
-// (pre_align_size_check / ref_free_alignment_2D_size_check), so that the estimate cannot drift from what is allocated
-struct WorkspacePlan {
-    int chunk;
-    size_t a_floats, cand_recs, refspec_floats, b_floats, alscratch_floats, zscr_recs;
-    size_t bytes;          // everything ra_create and the first reference update take from the device
-};
-
 static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, bool generic)
 {
     WorkspacePlan w{};
@@ -349,6 +365,66 @@ static ccf_fn select_ccf(int maxrin)
     case 32: return ccf_kernel<32>;
     default: return nullptr;
     }
+}
+
+typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, const float *, int, CandT *);
+static fused_fn select_fused(int maxrin, int nt)
+{
+    if (maxrin == 256) return nt == 1 ? search_fused_kernel<256, 1> : search_fused_kernel<256, 2>;
+    if (maxrin == 128) return nt == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;
+    return nullptr;
+}
+
+template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap, const std::vector<T> &h)
+{
+    if (h.size() > *cap || !*dptr) {
+        void *d = nullptr;
+        const size_t n = std::max<size_t>(h.size(), 1);
+        RA_HIP(hipMalloc(&d, n * sizeof(T)));
+        e->owned.push_back(d);
+        *dptr = (T *)d; *cap = n;
+    }
+    if (!h.empty()) RA_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RA_OK;
+}
+
+// (re)plan the particle-resident search kernel for the current search window and upload its tables.  The plan
+// depends on the window through the number of x-offsets per row; geometries it does not cover keep the two-kernel path.
+static int setup_fused(ra_engine *e)
+{
+    e->fused = false;
+    e->fplan.f.on = 0;
+    if (e->generic) return RA_OK;
+    if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
+    const Geometry &g = e->geo;
+    FusedPlanHost &fp = e->fplan;
+    if (!select_fused(g.maxrin, (e->cfg.nref + 7) / 8)) return RA_OK;
+    if (!build_fused_plan(g, e->cfg.nref, e->dg.pst, e->dg.n_qtab, e->qoff, e->ringw_h, fp)) return RA_OK;
+    int rc;
+    size_t cap_w = e->d_finstw ? e->f_cap_inst : 0, cap_c = e->d_fcdcw ? (size_t)g.nring : 0;
+    if ((rc = grow_upload(e, &e->d_finst, &e->f_cap_inst, fp.inst)) || (rc = grow_upload(e, &e->d_finstw, &cap_w, fp.instw)) ||
+        (rc = grow_upload(e, &e->d_fjobs, &e->f_cap_job, fp.jobs)) || (rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc)) ||
+        (rc = grow_upload(e, &e->d_fcdcw, &cap_c, fp.cdc_w)))
+        return rc;
+    if (!e->d_Bf) {
+        if ((rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true)) || (rc = dev_alloc(e, &e->d_cdc, 16, true))) return rc;
+    }
+    fp.f.jobs = e->d_fjobs; fp.f.inst = e->d_finst; fp.f.instw = e->d_finstw; fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_fcdcw;
+    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, fp.f.nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    e->fused = true;
+    return RA_OK;
+}
+
+// spectra workspace of the two-kernel path, allocated on first use (the fused kernel does not need it)
+static int ensure_unfused_ws(ra_engine *e)
+{
+    if (e->unfused_ws) return RA_OK;
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_A, e->wp.a_floats, true)) || (rc = dev_alloc(e, &e->d_cand, e->wp.cand_recs, true))) return rc;
+    if (e->generic && (rc = dev_alloc(e, &e->d_zscr, e->wp.zscr_recs, false))) return rc;
+    e->unfused_ws = true;
+    return RA_OK;
 }
 
 // the LDS-resident kernels cover <= 48 rings of 8..256 samples and images whose padded copy plus four ring buffers
@@ -439,23 +515,21 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); ra_destroy(e); return RA_ERR_HIP; }
 
-    // workspace: bin-major spectra of `chunk` particles + candidate records
+    // workspace.  The spectra panels and candidate records of the two-kernel path are allocated on first use only
+    // (ensure_unfused_ws); the fused kernel needs candidate records alone.
     const WorkspacePlan wp = plan_workspace(g, *cfg, e->generic);
-    const int chunk = wp.chunk;
-    e->chunk = chunk;
-    if ((rc = dev_alloc(e, &e->d_A, wp.a_floats, true)) ||
-        (rc = dev_alloc(e, &e->d_cand, wp.cand_recs, true)) ||
-        (rc = dev_alloc(e, &e->d_refspec, wp.refspec_floats, true)) ||
+    e->wp = wp;
+    e->chunk = wp.chunk;
+    if ((rc = dev_alloc(e, &e->d_refspec, wp.refspec_floats, true)) ||
         (rc = dev_alloc(e, &e->d_B, wp.b_floats, true)) ||
         (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
-        (rc = dev_alloc(e, &e->d_alscratch, wp.alscratch_floats, false))) {
+        (rc = dev_alloc(e, &e->d_alscratch, wp.alscratch_floats, false)) ||
+        (rc = dev_alloc(e, &e->d_fcand, ((size_t)wp.chunk * g.nshift_pad + 8) * ((cfg->nref + RF_ZREFS - 1) / RF_ZREFS), true))) {
         ra_destroy(e);
         return rc;
     }
-    if (e->generic) {
-        e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
-        if ((rc = dev_alloc(e, &e->d_zscr, wp.zscr_recs, false))) { ra_destroy(e); return rc; }
-    }
+    if (e->generic) e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
+    if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
     return RA_OK;
@@ -479,6 +553,7 @@ extern "C" int ra_set_stream(ra_engine *e, void *hip_stream)
     return RA_OK;
 }
 
+extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
 extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }
@@ -513,7 +588,7 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
     e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad;
     e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
-    return RA_OK;
+    return setup_fused(e);
 }
 
 extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
@@ -531,6 +606,14 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     hipLaunchKernelGGL(pack_refs_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, e->dg, e->d_refspec,
                        e->cfg.nref, e->nrtile, e->d_B);
     RA_HIP(hipGetLastError());
+    if (e->d_Bf) {      // the fused kernel's stream does not depend on the search window: keep it current
+        FusedGeom f = e->fplan.f;
+        if (f.b_floats > 0 && f.bsrc) {
+            hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(2048, (f.b_floats + 255) / 256)), dim3(256), 0, e->stream, e->dg, f,
+                               e->d_refspec, e->cfg.nref, e->d_Bf, e->d_cdc);
+            RA_HIP(hipGetLastError());
+        }
+    }
     e->refs_ready = true;
     return RA_OK;
 }
@@ -591,6 +674,30 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipGetLastError());
     }
     hipStream_t sp = e->stream;
+    if (e->fused) {
+        // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
+        // launch stays a bounded unit of work (timing, candidate workspace)
+        const FusedGeom f = e->fplan.f;
+        fused_fn fk = select_fused(g.maxrin, f.nt);
+        for (int start = 0; start < n; start += e->chunk) {
+            const int cn = std::min(e->chunk, n - start);
+            float *st = d_state + (size_t)start * 2;
+            std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
+            if (evc) RA_HIP(hipEventRecord(evc->first, sp));
+            hipLaunchKernelGGL(fk, dim3(cn), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
+                               (const float *)st, cn, (const float *)e->d_Bf, (const float *)e->d_cdc, e->cfg.nref, e->d_fcand);
+            RA_HIP(hipGetLastError());
+            if (evc) RA_HIP(hipEventRecord(evc->second, sp));
+            hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, f.nzr, cn, st,
+                               d_result + start, e->d_cs);
+            RA_HIP(hipGetLastError());
+        }
+        return RA_OK;
+    }
+    {
+        int rcw = ensure_unfused_ws(e);
+        if (rcw) return rcw;
+    }
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *Abuf = e->d_A;
@@ -632,6 +739,10 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
 {
     if (!e || !d_particles || !d_state || !h_out || n < 1 || n > e->chunk) { g_last_error = "bad argument"; return RA_ERR_ARG; }
     const Geometry &g = e->geo;
+    {
+        int rcw = ensure_unfused_ws(e);
+        if (rcw) return rcw;
+    }
     if (e->generic)
         hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
                            e->dg, d_particles, d_state, n, e->d_A);

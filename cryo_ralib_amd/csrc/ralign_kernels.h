@@ -288,9 +288,12 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
     } while (0)
 
-template <int R1, int LR>
+// `part` receives the Normalize_ring partial sums {sum w x, sum w x^2} of every (offset slot, ring).  NYQ1 (fused
+// search kernel): the Nyquist coefficient of a full-length ring (n == maxrin) is stored in the imaginary slot of
+// bin 0, EMAN2's own packing, so that the contraction sees bins 0 .. maxrin/2 - 1 only.
+template <int R1, int LR, bool NYQ1 = false>
 __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
-                                         const float2 *qt_s, const float *ctr, float *red, const int4 *inst_s,
+                                         const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
                                          const float *instw_s, int inst0, int count, int zero, int sbuf)
 {
     // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
@@ -377,8 +380,12 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     for (int k = t; k <= H / 2; k += LR) {
         float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
         if (k == 0) {
-            *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
-            *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+            if (NYQ1 && NR == g.maxrin) {
+                *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, zk.x - zk.y);
+            } else {
+                *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
+                *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+            }
         } else {
             float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
             float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
@@ -391,7 +398,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     }
     // Normalize_ring partial sums of this ring -> its own slot (summed in ring order later)
     av = group_sum_dpp<LR>(av); sq = group_sum_dpp<LR>(sq);
-    if (t == 0) { red[24 + 2 * (slot * g.nring + ring)] = av; red[25 + 2 * (slot * g.nring + ring)] = sq; }
+    if (t == 0) { part[2 * (slot * g.nring + ring)] = av; part[2 * (slot * g.nring + ring) + 1] = sq; }
 }
 
 __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
@@ -443,14 +450,14 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             for (int job = wave; job < g.n_job; job += nwave) {
                 const int4 jd = jobs_s[job];
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 6: ring_job<16, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 7: ring_job<8, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 0: ring_job<8, 16>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 1: ring_job<8, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 2: ring_job<4, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 3: ring_job<4, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 6: ring_job<16, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 7: ring_job<8, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 }
             }
         }
@@ -697,7 +704,7 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
 // (lane j holds the outputs with index = j mod R1; every one of the 7 neighbours sits in a different lane, which
 // selects it with a compare chain and stores it straight into the candidate record) -- the transformed sequence is
 // never written back to LDS.  Records: pc[pair] = {val, jtot, refmir = mirror << 16 | ref0 + (pair & 7), t7[7]}.
-template <int N, int NP>
+template <int N, int NP, int REFMASK = 7>
 __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *twl, int pairA, int pairB, int j, int ref0)
 {
     typedef ZLayout<N> ZL;
@@ -779,7 +786,7 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
         if (j == 0) {
             dst->val = mir ? bt : bq;
             dst->jtot = jt + 1;
-            dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + (pr[q] & 7));
+            dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + (pr[q] & REFMASK));
         }
     }
 }

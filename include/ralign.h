@@ -141,6 +141,9 @@ int  ra_set_stream(ra_engine *e, void *hip_stream);
 int  ra_num_shifts(const ra_engine *e);
 int  ra_maxrin(const ra_engine *e);
 int  ra_lcirc(const ra_engine *e);
+/* which kernels ra_align runs for the current geometry and window: 1 = particle-resident fused search kernel,
+ * 0 = polar + contraction kernel pair, 2 = size-generic kernels (large boxes) */
+int  ra_search_path(const ra_engine *e);
 /* change the search window without re-allocating (reset_shifts analogue); the number of
  * offsets may not grow beyond what ra_create sized */
 int  ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step);

