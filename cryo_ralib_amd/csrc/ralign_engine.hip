@@ -368,10 +368,12 @@ static ccf_fn select_ccf(int maxrin)
 }
 
 typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, const float *, int, CandT *);
-static fused_fn select_fused(int maxrin, int nt)
+static fused_fn select_fused(int maxrin, int nref)
 {
-    if (maxrin == 256) return nt == 1 ? search_fused_kernel<256, 1> : search_fused_kernel<256, 2>;
-    if (maxrin == 128) return nt == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;
+    const int nrp = nref > 8 ? (nref - 8 + 1) / 2 : 0;
+    if (nref > RF_MAXREF) return nullptr;
+    if (maxrin == 256) return nrp == 0 ? search_fused_kernel<256, 0> : nrp == 1 ? search_fused_kernel<256, 1> : search_fused_kernel<256, 2>;
+    if (maxrin == 128) return nrp == 0 ? search_fused_kernel<128, 0> : nrp == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;
     return nullptr;
 }
 
@@ -398,7 +400,7 @@ static int setup_fused(ra_engine *e)
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (!select_fused(g.maxrin, (e->cfg.nref + 7) / 8)) return RA_OK;
+    if (!select_fused(g.maxrin, e->cfg.nref)) return RA_OK;
     if (!build_fused_plan(g, e->cfg.nref, e->dg.pst, e->dg.n_qtab, e->qoff, e->ringw_h, fp)) return RA_OK;
     int rc;
     size_t cap_w = e->d_finstw ? e->f_cap_inst : 0, cap_c = e->d_fcdcw ? (size_t)g.nring : 0;
@@ -410,7 +412,7 @@ static int setup_fused(ra_engine *e)
         if ((rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true)) || (rc = dev_alloc(e, &e->d_cdc, 16, true))) return rc;
     }
     fp.f.jobs = e->d_fjobs; fp.f.inst = e->d_finst; fp.f.instw = e->d_finstw; fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_fcdcw;
-    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, fp.f.nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     e->fused = true;
     return RA_OK;
@@ -524,7 +526,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         (rc = dev_alloc(e, &e->d_B, wp.b_floats, true)) ||
         (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
         (rc = dev_alloc(e, &e->d_alscratch, wp.alscratch_floats, false)) ||
-        (rc = dev_alloc(e, &e->d_fcand, ((size_t)wp.chunk * g.nshift_pad + 8) * ((cfg->nref + RF_ZREFS - 1) / RF_ZREFS), true))) {
+        (rc = dev_alloc(e, &e->d_fcand, (size_t)wp.chunk * g.nshift_pad + 8, true))) {
         ra_destroy(e);
         return rc;
     }
@@ -678,7 +680,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
-        fused_fn fk = select_fused(g.maxrin, f.nt);
+        fused_fn fk = select_fused(g.maxrin, e->cfg.nref);
         for (int start = 0; start < n; start += e->chunk) {
             const int cn = std::min(e->chunk, n - start);
             float *st = d_state + (size_t)start * 2;
@@ -688,7 +690,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
                                (const float *)st, cn, (const float *)e->d_Bf, (const float *)e->d_cdc, e->cfg.nref, e->d_fcand);
             RA_HIP(hipGetLastError());
             if (evc) RA_HIP(hipEventRecord(evc->second, sp));
-            hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, f.nzr, cn, st,
+            hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, 1, cn, st,
                                d_result + start, e->d_cs);
             RA_HIP(hipGetLastError());
         }

@@ -337,7 +337,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
             sq += s * s * wt;
         }
         v[a] = make_float2(val[0], val[1]);
-        if (a & 1) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 samples' taps in flight (VGPR budget)
+        if (NYQ1 || (a & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 (fused kernel: 2) samples' taps in flight (VGPR budget)
     }
     if (RA_DBG(g, 256)) {   // diagnostic: leave the raw samples in natural order, no FFT
 #pragma unroll
