@@ -75,13 +75,12 @@ struct ra_engine {
     FusedPlanHost fplan;
     std::vector<int> qoff;              // quadrant-table offset per log2(ring length)
     std::vector<float> ringw_h;
-    bool fused = false;                 // plan valid for the current window and not disabled (RALIGN_FUSED=0)
-    float *d_Bf = nullptr, *d_cdc = nullptr;
-    int4 *d_fjobs = nullptr, *d_finst = nullptr;
-    float *d_finstw = nullptr, *d_fcdcw = nullptr;
+    bool fused = false;                 // plan valid and not disabled (RALIGN_FUSED=0)
+    float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
-    size_t f_cap_inst = 0, f_cap_job = 0, f_cap_b = 0;
+    size_t f_cap_b = 0;
     CandT *d_fcand = nullptr;           // [(chunk * nshift_pad + 8)][nzr]
+    int n_cu = 256;
     bool unfused_ws = false;            // spectra workspace of the two-kernel path allocated
     WorkspacePlan wp{};
     // kernel timing
@@ -367,13 +366,20 @@ static ccf_fn select_ccf(int maxrin)
     }
 }
 
-typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, const float *, int, CandT *);
+typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *);
 static fused_fn select_fused(int maxrin, int nref)
 {
-    const int nrp = nref > 8 ? (nref - 8 + 1) / 2 : 0;
     if (nref > RF_MAXREF) return nullptr;
-    if (maxrin == 256) return nrp == 0 ? search_fused_kernel<256, 0> : nrp == 1 ? search_fused_kernel<256, 1> : search_fused_kernel<256, 2>;
-    if (maxrin == 128) return nrp == 0 ? search_fused_kernel<128, 0> : nrp == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;
+    const int nrp = (nref + 1) / 2;
+    if (maxrin == 256) {
+        switch ((nrp + 1) / 2) {       // 2 waves per 16-bin group
+        case 1: return search_fused_kernel<256, 1>;
+        case 2: return search_fused_kernel<256, 2>;
+        case 3: return search_fused_kernel<256, 3>;
+        default: return search_fused_kernel<256, 4>;
+        }
+    }
+    if (maxrin == 128) return (nrp + 3) / 4 == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;      // 4 waves per group
     return nullptr;
 }
 
@@ -390,8 +396,8 @@ template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap
     return RA_OK;
 }
 
-// (re)plan the particle-resident search kernel for the current search window and upload its tables.  The plan
-// depends on the window through the number of x-offsets per row; geometries it does not cover keep the two-kernel path.
+// plan of the particle-resident search kernel (ralign_fused.h) and its tables.  It covers every search window of a
+// geometry the LDS-resident kernels cover, up to RF_MAXREF references; everything else keeps the two-kernel path.
 static int setup_fused(ra_engine *e)
 {
     e->fused = false;
@@ -401,17 +407,11 @@ static int setup_fused(ra_engine *e)
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
     if (!select_fused(g.maxrin, e->cfg.nref)) return RA_OK;
-    if (!build_fused_plan(g, e->cfg.nref, e->dg.pst, e->dg.n_qtab, e->qoff, e->ringw_h, fp)) return RA_OK;
+    if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
     int rc;
-    size_t cap_w = e->d_finstw ? e->f_cap_inst : 0, cap_c = e->d_fcdcw ? (size_t)g.nring : 0;
-    if ((rc = grow_upload(e, &e->d_finst, &e->f_cap_inst, fp.inst)) || (rc = grow_upload(e, &e->d_finstw, &cap_w, fp.instw)) ||
-        (rc = grow_upload(e, &e->d_fjobs, &e->f_cap_job, fp.jobs)) || (rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc)) ||
-        (rc = grow_upload(e, &e->d_fcdcw, &cap_c, fp.cdc_w)))
-        return rc;
-    if (!e->d_Bf) {
-        if ((rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true)) || (rc = dev_alloc(e, &e->d_cdc, 16, true))) return rc;
-    }
-    fp.f.jobs = e->d_fjobs; fp.f.inst = e->d_finst; fp.f.instw = e->d_finstw; fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_fcdcw;
+    if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
+    if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true))) return rc;
+    fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = nullptr;
     hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     e->fused = true;
@@ -466,6 +466,10 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
 
     ra_engine *e = new ra_engine();
     e->cfg = *cfg;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    }
     if (!build_rings(e->geo, cfg->nx, cfg->first_ring, cfg->last_ring, cfg->ring_skip > 0 ? cfg->ring_skip : 1) ||
         !build_shifts(e->geo, cfg->xrng, cfg->yrng, cfg->step)) {
         g_last_error = "bad ring / shift geometry";
@@ -612,7 +616,7 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
         FusedGeom f = e->fplan.f;
         if (f.b_floats > 0 && f.bsrc) {
             hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(2048, (f.b_floats + 255) / 256)), dim3(256), 0, e->stream, e->dg, f,
-                               e->d_refspec, e->cfg.nref, e->d_Bf, e->d_cdc);
+                               e->d_refspec, e->cfg.nref, e->d_Bf);
             RA_HIP(hipGetLastError());
         }
     }
@@ -686,8 +690,9 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             float *st = d_state + (size_t)start * 2;
             std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
             if (evc) RA_HIP(hipEventRecord(evc->first, sp));
-            hipLaunchKernelGGL(fk, dim3(cn), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
-                               (const float *)st, cn, (const float *)e->d_Bf, (const float *)e->d_cdc, e->cfg.nref, e->d_fcand);
+            // one workgroup per CU (LDS-bound); each walks over its share of the chunk
+            hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
+                               (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand);
             RA_HIP(hipGetLastError());
             if (evc) RA_HIP(hipEventRecord(evc->second, sp));
             hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, 1, cn, st,

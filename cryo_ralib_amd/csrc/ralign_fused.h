@@ -1,23 +1,24 @@
 // Particle-resident search kernel for gfx950 (MI355X): the whole search of one particle -- polar resampling,
 // Normalize_ring, ring FFTs, the reference x particle contraction (Crosrng_ms), inverse FFTs and argmax -- runs inside
-// one workgroup (16 waves); the particle spectra never leave the CU.  HBM sees the image once (32 KB at 90 x 90) and a
-// few candidate records; the prepared references (the MFMA B operand) stream from L2.
+// one workgroup (16 waves); the particle spectra never leave the CU.  HBM sees the image once (32 KB at 90 x 90) and one
+// candidate record per search offset; the prepared references (the MFMA B operand) stream from L2.
 //
-// Structure ("ring streaming"): a pass handles one row of the search grid (<= 8 x-offsets = the 16 rows of a
-// v_mfma_f32_16x16x4_f32 tile: offset x (Re, Im)).  The rings are cut into k-slots of 4 rings (the K = 4 of the MFMA),
-// k-slots into steps of up to 16 wave-jobs.  Per step the waves sample the step's rings for every offset of the row and
-// FFT them in an LDS stage (ring_job, shared with polar_fft_kernel), then multiply-accumulate them into CCF-spectrum
-// accumulators that stay in REGISTERS for the whole pass:
-//   * references 0..7: v_mfma_f32_16x16x4_f32, wave w owns the Fourier bins k = w (mod 16): 8 bins x 4 VGPRs;
-//   * references 8..11 (pairs): v_mfma_f32_4x4x1_16b_f32, one instruction = 16 bins x (2 offsets x Re/Im) x
-//     (2 references x Re/Im) for one ring; wave w owns bins 16 (w >> 1) .. +15 and two offset pairs: 8 VGPRs per pair
-//     of references instead of the 32 a second, mostly empty 16-column tile would take.
-// So 10 references need 40 accumulator VGPRs per wave, which leaves a 16-wave workgroup (128 VGPRs per wave) enough
-// registers for the ring jobs.  Only a stage of 8 ... 20 rings x 8 offsets is ever in LDS.  After the last step the
-// accumulators hold all bins of every (offset, reference) pair of the row; they are combined into Z_k = Q_k + i T_k,
-// written to LDS (the stage space, idle by then) in rounds of <= 5 references, inverse-transformed there and reduced
-// by the wavefront argmax of ralign_kernels.h.  Normalize_ring is linear, so it is applied after the contraction: the
-// DC bin is corrected by avg * sum_r n_r C_r(0) and the peak values are scaled by 1/sigma.
+// A pass handles 4 consecutive search offsets, exactly like a pass of polar_fft_kernel (same wave-jobs, same LDS ring
+// buffers): Polar2Dm + Normalize_ring statistics + Frngs of all rings into 4 ring buffers.  Instead of writing operand
+// panels to HBM, the pass goes on inside the CU:
+//   contraction   v_mfma_f32_4x4x1_16b_f32: one instruction = 16 Fourier bins x [4 rows = 2 offsets x (Re, Im) D] x
+//                 [4 columns = 2 references x (Re, Im) C] for ONE ring -- no padding of the reference count (10
+//                 references = 5 pairs) and none of the ring count.  The A operand is read straight from the LDS ring
+//                 buffers (one ds_read per MFMA), the B operand (4 rings per 16-byte load) from L2.  A unit =
+//                 (16-bin group, reference pair, offset pair) accumulates over the rings that have those bins in
+//                 4 VGPRs; the accumulators exist only between the ring jobs and the inverse FFT of the same pass,
+//                 so they never compete with the ring jobs for registers.
+//   spectra       Z_k = Q_k + i T_k, Z_{N-k} = conj Q_k + i conj T_k go to LDS (the ring-buffer space, idle by then),
+//                 one N-point complex inverse FFT per (offset, reference) pair yields q and t together, wavefront
+//                 argmax with EMAN2's tie rules (ifft_argmax of ralign_kernels.h); the best reference per offset
+//                 leaves the CU as one 40-byte record.
+// Normalize_ring is applied as in polar_fft_kernel (DC bin corrected in the ring buffer before the contraction) except
+// for the scale 1/sigma, which multiplies the peak record instead of every spectrum element.
 //
 // Reference call sites restated: Util.multiref_polar_ali_2d / ormq as called from test_mref_gpu_align.py:1043-1044 and
 // sp_alignment.ali2d_single_iter (test_reffree_gpu_align.py:844-847); SURVEY.md Appendix A.3-A.9.
@@ -33,47 +34,30 @@ namespace ralign {
 
 constexpr int RF_WAVES = 16;
 constexpr int RF_THREADS = RF_WAVES * 64;
-constexpr int RF_MAXKS = 16;      // k-slots of 4 rings: nring <= 64
-constexpr int RF_MAXSTEP = 8;
-constexpr int RF_MAXREF = 12;     // 8 on the 16x16x4 tile + 2 pairs on 4x4x1 blocks
+constexpr int RF_MAXREF = 16;     // references the accumulators of one pass hold (<= 4 reference pairs x 2 offset pairs per wave)
 
 struct FusedGeom {
-    int on;                        // plan valid for the current window
-    int nxo;                       // live x-offsets per pass (row of the search grid), <= 8
-    int npass;                     // rows of the search grid
-    int nks, nstep;
-    int nrp;                       // reference pairs beyond the first 8 references (0..2)
+    int on;
+    int ng;                        // 16-bin groups: maxrin / 32 (the Nyquist bin of full-length rings rides in bin 0)
+    int wpg;                       // waves per group = 16 / ng
+    int nrp;                       // reference pairs
+    int nrpw;                      // reference pairs per wave = ceil(nrp / wpg): template parameter of the kernel
     int rz, nzr;                   // references per inverse-FFT round, rounds
-    int r_floats;                  // LDS region shared by the stage and the CCF spectra
-    int n_inst, n_job;
-    int b_floats;                  // prepared-reference stream
-    int step_ks0[RF_MAXSTEP + 1];  // k-slots [step_ks0[s], step_ks0[s+1]) form step s
-    int step_os[RF_MAXSTEP];       // stride between offset slots in the stage (== 2 mod 32)
-    int step_job0[RF_MAXSTEP + 1];
-    int ks_base[RF_MAXKS];         // float offset of the k-slot inside an offset slot
-    int ks_rs[RF_MAXKS];           // stride between the 4 rings of the k-slot (== 16 mod 32)
-    int ks_nbin[RF_MAXKS];         // bins 0 .. nbin-1 exist in the k-slot
-    int ks_boff[RF_MAXKS];         // float offset of the k-slot's B block for the 16x16x4 tile: [wave][chunk][lane][4]
-    int ks_bw[RF_MAXKS];           // floats per wave inside that block (chunks of 256)
-    int ks_bxoff[RF_MAXKS];        // float offset of the k-slot's B block for the 4x4x1 pairs: [pair][bin group][lane][4 rings]
-    const int4 *jobs;              // {size code, first instance, count, 0}
-    const int4 *inst;              // {offset slot | ring << 8, float offset inside the slot, qtab offset, radius}
-    const float *instw;
+    int b_floats;
+    int grp_ring0[8];              // first ring that has bins of group m (rings are sorted by length)
+    int grp_boff[8];               // float offset of group m's B block: [pair][ring quad][lane][4 rings]
+    int grp_nq[8];                 // ring quads of group m
     const int *bsrc;               // [b_floats] (entry << 5 | reference << 1 | imaginary part), -1 = 0
-    const float *cdc_w;            // [nring] n_r * Applyws weight of bin 0 / maxrin: DC correction weights
+    int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's); kernel-argument memory: scalar loads
+    const float *cdc_w;            // unused by the kernel (the DC correction happens in the ring buffer); kept for diagnostics
 };
 
-// ------------------------------------------------------------------------------------------
-// host: plan of the fused kernel for geometry g and the current search window
 struct FusedPlanHost {
     FusedGeom f{};
-    std::vector<int4> jobs, inst;
-    std::vector<float> instw, cdc_w;
     std::vector<int> bsrc;
+    std::vector<float> cdc_w;
     size_t lds_bytes = 0;
 };
-
-inline int rf_align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // B-stream source of (bin k, ring r, reference ref, Re/Im part): entry code or -1 (zero).  The Nyquist coefficient of
 // a full-length ring rides in the imaginary slot of bin 0 (EMAN2's packing); bins a ring does not have are zero.
@@ -91,139 +75,62 @@ inline int rf_bsrc_code(const Geometry &g, int k, int r, int ref, int part)
     return (e << 5) | (ref << 1) | part;
 }
 
-// qoff[log2 n] = offset of the ring length's quadrant table inside qtab; ringw = Normalize_ring weights
-inline bool build_fused_plan(const Geometry &g, int nref, int pst, int n_qtab, const std::vector<int> &qoff,
-                             const std::vector<float> &ringw, FusedPlanHost &out)
+// lds_polar_floats: LDS floats polar_fft_kernel needs for this geometry (image, 4 ring buffers, tables, reductions)
+inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_polar_floats, FusedPlanHost &out)
 {
     FusedGeom &f = out.f;
     f = FusedGeom{};
-    out.jobs.clear(); out.inst.clear(); out.instw.clear(); out.bsrc.clear(); out.cdc_w.clear();
-    const int nx1 = 2 * g.nkx + 1;
-    if (g.step != 1.0f || nx1 > 8 || nref > RF_MAXREF || g.nring > 4 * RF_MAXKS) return false;
-    if (!(g.maxrin == 256 || g.maxrin == 128) || g.numr[2] < 8) return false;
-    f.nxo = nx1; f.npass = 2 * g.nky + 1;
-    f.nrp = nref > 8 ? (nref - 8 + 1) / 2 : 0;
-    f.nks = (g.nring + 3) / 4;
-    const int nbw_all = g.maxrin / 32;         // bins per wave at full length (bins 0 .. maxrin/2-1, Nyquist merged into bin 0)
+    out.bsrc.clear(); out.cdc_w.clear();
+    if (nref > RF_MAXREF || !(g.maxrin == 256 || g.maxrin == 128) || g.numr[2] < 8) return false;
+    f.ng = g.maxrin / 32; f.wpg = RF_WAVES / f.ng;
+    f.nrp = (nref + 1) / 2;
+    f.nrpw = (f.nrp + f.wpg - 1) / f.wpg;
+    if (f.nrpw > 4) return false;
     const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
-    // k-slot geometry
-    std::vector<int> nmax(f.nks), rs(f.nks), nbin(f.nks);
-    for (int q = 0; q < f.nks; q++) {
-        const int last = std::min(4 * q + 3, g.nring - 1);
-        nmax[q] = g.numr[3 * last + 2];
-        rs[q] = rf_align_up(nmax[q] + 2, 32) + 16;
-        nbin[q] = (nmax[q] == g.maxrin) ? g.maxrin / 2 : nmax[q] / 2 + 1;
-    }
-    // ring-job shapes by ring length: code (ring_job variant) and instances per wave-job
-    auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 7; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
-    auto per_job = [](int n) { switch (n) { case 256: return 4; case 128: return 8; default: return 16; } };
-    auto jobs_of = [&](int q0, int q1) {
-        int cnt[9] = {0};
-        for (int q = q0; q < q1; q++)
-            for (int r = 4 * q; r < std::min(4 * q + 4, g.nring); r++) cnt[ilog2_floor(g.numr[3 * r + 2])] += f.nxo;
-        int j = 0;
-        for (int lg = 3; lg <= 8; lg++) j += (cnt[lg] + per_job(1 << lg) - 1) / per_job(1 << lg);
-        return j;
-    };
-    // steps: consecutive k-slots while the ring jobs of the step fit one round of the 16 waves and the stage stays
-    // below ~74 KB
-    f.nstep = 0;
-    int q = 0;
-    const int stage_cap = 18944;               // floats
-    int stage_floats = 0;
-    while (q < f.nks) {
-        if (f.nstep == RF_MAXSTEP) return false;
-        int q1 = q + 1, os = 4 * rs[q] + 2;
-        while (q1 < f.nks && jobs_of(q, q1 + 1) <= RF_WAVES && 8 * (os + 4 * rs[q1]) <= stage_cap) { os += 4 * rs[q1]; q1++; }
-        f.step_ks0[f.nstep] = q; f.step_os[f.nstep] = os;
-        int base = 0;
-        for (int qq = q; qq < q1; qq++) { f.ks_base[qq] = base; f.ks_rs[qq] = rs[qq]; f.ks_nbin[qq] = nbin[qq]; base += 4 * rs[qq]; }
-        stage_floats = std::max(stage_floats, 8 * os);
-        f.nstep++;
-        q = q1;
-    }
-    f.step_ks0[f.nstep] = f.nks;
-    // inverse-FFT rounds: as many references per round as 64 lane groups and ~80 KB of spectra allow, balanced
-    int rzmax = std::min(64 / f.nxo, 20480 / (f.nxo * zstride));
-    rzmax = std::max(1, std::min(rzmax, 8));
+    int rzmax = std::min(64 / 4, (4 * sbuf) / (4 * zstride));
+    rzmax = std::max(1, rzmax);
     f.nzr = (nref + rzmax - 1) / rzmax;
     f.rz = (nref + f.nzr - 1) / f.nzr;
-    f.r_floats = rf_align_up(std::max(stage_floats, f.nxo * f.rz * zstride), 64);
-
-    // ring jobs per step: instances (offset slot, ring) by ring length (longest first)
-    for (int s = 0; s < f.nstep; s++) {
-        f.step_job0[s] = (int)out.jobs.size();
-        for (int lg = 8; lg >= 3; lg--) {
-            const int n = 1 << lg, code = code_of(n);
-            std::vector<int4> cls; std::vector<float> clsw;
-            for (int o = 0; o < f.nxo; o++)
-                for (int qq = f.step_ks0[s]; qq < f.step_ks0[s + 1]; qq++)
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int r = 4 * qq + kk;
-                        if (r >= g.nring || g.numr[3 * r + 2] != n) continue;
-                        cls.push_back(make_int4(o | (r << 8), f.ks_base[qq] + kk * f.ks_rs[qq], qoff[lg], g.numr[3 * r]));
-                        clsw.push_back(ringw[r]);
-                    }
-            const int pj = per_job(n);
-            for (size_t b = 0; b < cls.size(); b += pj) {
-                const int cnt = (int)std::min<size_t>(pj, cls.size() - b);
-                out.jobs.push_back(make_int4(code, (int)out.inst.size(), cnt, 0));
-                for (int c = 0; c < cnt; c++) { out.inst.push_back(cls[b + c]); out.instw.push_back(clsw[b + c]); }
-            }
-        }
-    }
-    f.step_job0[f.nstep] = (int)out.jobs.size();
-    f.n_inst = (int)out.inst.size(); f.n_job = (int)out.jobs.size();
-
-    // B stream
     int boff = 0;
-    for (int qq = 0; qq < f.nks; qq++) {
-        const int nbw_max = std::min(nbw_all, (nbin[qq] + RF_WAVES - 1) / RF_WAVES);
-        const int nch = (nbw_max + 3) / 4;
-        f.ks_boff[qq] = boff; f.ks_bw[qq] = nch * 256;
-        boff += RF_WAVES * nch * 256;
-        f.ks_bxoff[qq] = boff;
-        boff += f.nrp * ((nbin[qq] + 15) / 16) * 256;
+    for (int m = 0; m < f.ng; m++) {
+        int r0 = 0;
+        while (r0 < g.nring) {      // first ring with a bin >= 16 m (bins 0 .. n/2, the full-length Nyquist merged into bin 0)
+            const int n = g.numr[3 * r0 + 2], nbin = (n == g.maxrin) ? n / 2 : n / 2 + 1;
+            if (16 * m < nbin) break;
+            r0++;
+        }
+        f.grp_ring0[m] = r0;
+        f.grp_nq[m] = (g.nring - r0 + 3) / 4;
+        f.grp_boff[m] = boff;
+        boff += f.nrp * f.grp_nq[m] * 256;
     }
     f.b_floats = boff;
     out.bsrc.assign(boff, -1);
-    for (int qq = 0; qq < f.nks; qq++) {
-        // 16x16x4 tile: wave w, bin k = 16 i + w, lane = (ring kk, column = reference x Re/Im)
-        for (int w = 0; w < RF_WAVES; w++)
-            for (int i = 0; RF_WAVES * i + w < nbin[qq]; i++)
-                for (int lane = 0; lane < 64; lane++) {
-                    const int kk = lane >> 4, col = lane & 15;
-                    out.bsrc[f.ks_boff[qq] + w * f.ks_bw[qq] + ((i >> 2) * 64 + lane) * 4 + (i & 3)] =
-                        rf_bsrc_code(g, RF_WAVES * i + w, 4 * qq + kk, col >> 1, col & 1);
-                }
-        // 4x4x1 pairs: bin group m (bins 16 m + b), lane = (block b, column j = reference in pair x Re/Im), 4 rings
-        const int nm = (nbin[qq] + 15) / 16;
+    for (int m = 0; m < f.ng; m++)
         for (int rp = 0; rp < f.nrp; rp++)
-            for (int m = 0; m < nm; m++)
+            for (int rq = 0; rq < f.grp_nq[m]; rq++)
                 for (int lane = 0; lane < 64; lane++)
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int k = 16 * m + (lane >> 2), j = lane & 3;
-                        if (k >= nbin[qq]) continue;
-                        out.bsrc[f.ks_bxoff[qq] + ((rp * nm + m) * 64 + lane) * 4 + kk] =
-                            rf_bsrc_code(g, k, 4 * qq + kk, 8 + 2 * rp + (j >> 1), j & 1);
+                    for (int c = 0; c < 4; c++) {
+                        const int r = f.grp_ring0[m] + 4 * rq + c, k = 16 * m + (lane >> 2), j = lane & 3;
+                        const int ref = 2 * rp + (j >> 1);
+                        if (ref >= nref) continue;
+                        out.bsrc[f.grp_boff[m] + ((rp * f.grp_nq[m] + rq) * 64 + lane) * 4 + c] = rf_bsrc_code(g, k, r, ref, j & 1);
                     }
-    }
-    out.cdc_w.resize(g.nring);
-    for (int r = 0; r < g.nring; r++) out.cdc_w[r] = (float)g.numr[3 * r + 2] * g.wr[r] / (float)g.maxrin;
-    size_t fl = ((size_t)(pst * pst + 3) & ~(size_t)3) + f.r_floats + 2 * g.maxrin + 2 * n_qtab + 2 + 4 * f.n_inst + 4 * f.n_job + 4 +
-                f.n_inst + 32 + 16 * g.nring + 2 * g.maxrin + 8 * RF_MAXREF * (sizeof(CandT) / 4) + 64;
+    out.cdc_w.assign(g.nring, 0.f);
+    if (g.nring > 64) return false;
+    for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
+    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + g.nring + 64;
     out.lds_bytes = fl * sizeof(float);
-    f.on = out.lds_bytes <= 160 * 1024;
+    f.on = out.lds_bytes <= 160 * 1024 && 4 * f.rz * zstride <= 4 * sbuf;
     return f.on != 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // device
 
-// prepared references -> B stream of the fused kernel (Applyws weights and 1/maxrin folded in) and the per-reference
-// DC weights Cdc[ref] = sum_r n_r * B_r(bin 0, Re)
+// prepared references -> B stream of the fused kernel (Applyws weights and 1/maxrin folded in)
 __global__ void pack_refs_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ refspec, int nref,
-                                       float *__restrict__ Bf, float *__restrict__ cdc)
+                                       float *__restrict__ Bf)
 {
     const float inv = 1.0f / (float)g.maxrin;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < f.b_floats; idx += gridDim.x * blockDim.x) {
@@ -235,26 +142,19 @@ __global__ void pack_refs_fused_kernel(DevGeom g, FusedGeom f, const float *__re
         }
         Bf[idx] = v;
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < nref) {
-        const int ref = threadIdx.x;
-        float s = 0.f;
-        for (int r = 0; r < g.nring; r++) s += refspec[(size_t)ref * g.lring + g.ringinfo[r].x] * f.cdc_w[r];
-        cdc[ref] = s;
-    }
 }
 
 __device__ __forceinline__ float rf_f4(const float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // Z_k = Q_k + i T_k and Z_{N-k} = conj Q_k + i conj T_k from the four products a = c1 d1, b = c1 d2, c = c2 d1,
 // d = c2 d2 summed over rings (Util::Crosrng_ms: Q = (a + d) + i (c - b), T = (a - d) - i (b + c)); bin 0 carries the
-// DC term in a (minus the Normalize_ring mean) and the Nyquist term of the full-length rings in d
+// DC term in a and the Nyquist term of the full-length rings in d
 template <int N>
-__device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca, float cb, float cc, float cd, float dcw)
+__device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca, float cb, float cc, float cd)
 {
     typedef ZLayout<N> ZL;
     if (k == 0) {
-        const float a0 = ca - dcw;
-        *reinterpret_cast<float2 *>(Z + ZL::addr(zslot, 0)) = make_float2(a0, a0);
+        *reinterpret_cast<float2 *>(Z + ZL::addr(zslot, 0)) = make_float2(ca, ca);
         *reinterpret_cast<float2 *>(Z + ZL::addr(zslot, N / 2)) = make_float2(cd, cd);
     } else {
         const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
@@ -263,38 +163,56 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
     }
 }
 
-template <int N, int NRP>
+template <int N, int NRPW>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
-                                                                  const float *__restrict__ Bf,
-                                                                  const float *__restrict__ cdc, int nref,
+                                                                  const float *__restrict__ Bf, int nref,
                                                                   CandT *__restrict__ cand)
 {
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
-    constexpr int NBW = N / 32;                 // bins per wave of the 16x16x4 tile (k = 16 i + wave)
-    constexpr int NCH = (NBW + 3) / 4;          // float4 B registers per k-slot
-    constexpr int NRPA = NRP > 0 ? NRP : 1;
     extern __shared__ __align__(16) float lds[];
+    // LDS plan of polar_fft_kernel, then the extras of this kernel
     const int npad = g.pst * g.pst;
     float *img = lds;
-    float *R = lds + ((npad + 3) & ~3);                                   // [r_floats] stage | CCF spectra
-    float2 *tw_s = reinterpret_cast<float2 *>(R + f.r_floats);            // [maxrin]
-    float2 *qt_s = tw_s + g.maxrin;                                        // [n_qtab]
-    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));
-    int4 *jobs_s = inst_s + f.n_inst;
-    float *instw_s = reinterpret_cast<float *>(jobs_s + f.n_job);          // [n_inst]
-    float *ctr = instw_s + ((f.n_inst + 3) & ~3);                          // [16] sampling centres of the 8 offset slots
-    float *nrm = ctr + 16;                                                 // [8] avg, [8] 1/sigma
-    float *part = nrm + 16;                                                // [8][nring][2] Normalize_ring partial sums
-    float2 *tws = reinterpret_cast<float2 *>(part + 16 * g.nring);         // [R1*R2] inverse-FFT twiddles
-    CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);                  // [8][nref] records of the pass
-    const int p = blockIdx.x;
+    float *bufs = lds + ((npad + 3) & ~3);                             // [4][sbuf] ring buffers | CCF spectra
+    float2 *tw_s = reinterpret_cast<float2 *>(bufs + 4 * g.sbuf);     // [maxrin]
+    float2 *qt_s = tw_s + g.maxrin;                                    // [n_qtab]
+    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));   // [n_inst]
+    int4 *jobs_s = inst_s + g.n_inst;                                  // [n_job]
+    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);      // [n_inst]
+    float *red = instw_s + g.n_inst;    // [8] -, [8] avg / rsigma, [8] centres, [4*nring*2] ring partials
+    float2 *tws = reinterpret_cast<float2 *>(red + 24 + 8 * g.nring + ((g.n_inst + 8 * g.nring) & 1));   // [R1*R2] inverse-FFT twiddles
+    CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);              // [4][nref] records of the pass
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (p >= n) return;
 
-    // ---- particle image into the zero-bordered LDS array, tables
+    // tables and the ring-buffer slack are set up once per workgroup; the workgroup then walks over its particles
+    for (int i = tid; i < g.maxrin; i += RF_THREADS) tw_s[i] = g.tw[i];
+    for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
+    for (int i = tid; i < g.n_inst; i += RF_THREADS) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
+    for (int i = tid; i < g.n_job; i += RF_THREADS) jobs_s[i] = g.jobs[i];
+    for (int i = tid; i < R1 * R2; i += RF_THREADS) {
+        const float2 t = g.tw[((i / R2) * (i % R2) * (g.maxrin / N)) & (g.maxrin - 1)];
+        tws[i] = make_float2(t.x, -t.y);
+    }
+    for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;      // slack between rings must hold finite values
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+
+    // contraction roles: group m = 16 bins (block b = lane >> 2 is bin 16 m + b); a wave takes NRPW reference pairs
+    // rp0 .. rp0 + NRPW - 1 of its group and both offset pairs: unit (h, op) accumulates in acc[2 h + op].
+    // A row = lane & 3 = (offset in pair, Re/Im), C column = lane & 3 = (reference in pair, Re/Im); after the 2x2
+    // exchange the even lane keeps the first offset of the pair, the odd lane the second.
+    // (The lane arithmetic of the contraction and of the spectra rounds is rebuilt in every pass from a zero the
+    // compiler cannot see through -- red[7], rewritten per pass -- so that it is not hoisted out of the pass loop and
+    // kept alive across the ring jobs, which need every register they can get.)
+    constexpr int NU = 2 * NRPW;
+    const int xm = wave / f.wpg, rp0 = (wave % f.wpg) * NRPW;
+
+    const int ngroup = g.nshift_pad / 4;
+#pragma unroll 1
+    for (int p = blockIdx.x; p < n; p += gridDim.x) {
+    __syncthreads();                           // the previous particle's last pass has left the image and `red`
     const float *src = particles + (size_t)p * g.nx * g.nx;
-    for (int row = wave; row < g.pst; row += RF_WAVES) {
+    for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
         const int y = row - g.bd;
         const bool yin = y >= 0 && y < g.nx;
         for (int c = lane; c < g.pst; c += 64) {
@@ -302,184 +220,149 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
         }
     }
-    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
-    for (int i = tid; i < g.maxrin; i += RF_THREADS) tw_s[i] = g.tw[i];
-    for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
-    for (int i = tid; i < f.n_inst; i += RF_THREADS) { inst_s[i] = f.inst[i]; instw_s[i] = f.instw[i]; }
-    for (int i = tid; i < f.n_job; i += RF_THREADS) jobs_s[i] = f.jobs[i];
-    for (int i = tid; i < R1 * R2; i += RF_THREADS) {
-        const float2 t = g.tw[((i / R2) * (i % R2) * (g.maxrin / N)) & (g.maxrin - 1)];
-        tws[i] = make_float2(t.x, -t.y);
-    }
-    for (int i = tid; i < f.r_floats; i += RF_THREADS) R[i] = 0.f;        // stage slack must hold finite values
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
-    const float2 *twl = tws + (lane & 15);
-
-    // lane roles.  16x16x4: A row = lane & 15 = (offset slot, Re/Im), k-slot ring = lane >> 4; C column = lane & 15 =
-    // (reference, Re/Im); after the 2x2 exchange the even lane keeps offset 2*(lane>>4), the odd lane the next one.
-    // 4x4x1: block = lane >> 2 = bin in the group, A row = lane & 3 = (offset in pair, Re/Im), C column = lane & 3.
-    const int kk = lane >> 4, arow = lane & 15, odd = lane & 1;
-    const int o_epi = 2 * kk + odd, r8 = (lane & 15) >> 1;
-    const int xm = wave >> 1, xb = lane >> 2, xj = lane & 3;
-
-    const int nx1 = 2 * g.nkx + 1;
-    for (int pass = 0; pass < f.npass; pass++) {
-        __syncthreads();                       // previous pass has left the stage / spectra region and `ctr`
-        if (tid < 8) {
-            const int si = pass * nx1 + min(tid, f.nxo - 1);
-            ctr[2 * tid] = cxf + g.shift_x[si];
-            ctr[2 * tid + 1] = cyf + g.shift_y[si];
+    for (int grp = 0; grp < ngroup; grp++) {
+        if (tid < 4) {
+            const int si = min(grp * 4 + tid, g.nshift - 1);
+            red[16 + 2 * tid] = cxf + g.shift_x[si];
+            red[17 + 2 * tid] = cyf + g.shift_y[si];
+            red[7] = 0.f;
         }
-        f32x4 acc[NBW];
-        f32x4 accx[NRPA][2];
-#pragma unroll
-        for (int i = 0; i < NBW; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rp = 0; rp < NRPA; rp++) { accx[rp][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[rp][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         __syncthreads();
-        for (int st = 0; st < f.nstep; st++) {
-            const int os = f.step_os[st];
-            // ---- ring jobs of the step: sampling + Normalize_ring statistics + ring FFT into the stage
-            if (!RA_DBG(g, 16)) {
-                const int j1 = f.step_job0[st + 1];
+        // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
+        if (!RA_DBG(g, 16)) {
 #pragma unroll 1
-                for (int job = f.step_job0[st] + wave; job < j1; job += RF_WAVES) {
-                    const int4 jd = jobs_s[job];
-                    switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                    case 0: ring_job<8, 16, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    case 1: ring_job<8, 8, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    case 7: ring_job<8, 4, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    case 3: ring_job<4, 4, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    case 4: ring_job<2, 4, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    default: ring_job<1, 4, true>(g, imgb, R, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, os); break;
-                    }
+            for (int job = wave; job < g.n_job; job += RF_WAVES) {
+                const int4 jd = jobs_s[job];
+                switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 }
             }
-            // ---- contraction of the step: accumulate its k-slots into the bins this wave owns.  The B operands of the
-            // next k-slot are requested while the current one is multiplied; those of the first k-slot before the barrier.
-            float4 breg[2][NCH], bx[2][NRPA];
-            auto load_b = [&](int q, float4 (&b1)[NCH], float4 (&b2)[NRPA]) {
-                const float *bp = Bf + f.ks_boff[q] + wave * f.ks_bw[q] + lane * 4;
-                const int nch = f.ks_bw[q] >> 8, nbq = f.ks_nbin[q];
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-                    if (c < nch) b1[c] = *reinterpret_cast<const float4 *>(bp + c * 256);
-                if (NRP > 0 && 16 * xm < nbq) {
-                    const int nm = (nbq + 15) >> 4;
-#pragma unroll
-                    for (int rp = 0; rp < NRP; rp++)
-                        b2[rp] = *reinterpret_cast<const float4 *>(Bf + f.ks_bxoff[q] + ((rp * nm + xm) * 64 + lane) * 4);
-                }
-            };
-            auto mul_q = [&](int q, const float4 (&b1)[NCH], const float4 (&b2)[NRPA]) {
-                const int nb = f.ks_nbin[q], rs = f.ks_rs[q], kb = f.ks_base[q];
-                const float *ab = R + (arow >> 1) * os + kb + kk * rs + (arow & 1) + 2 * wave;
-#pragma unroll
-                for (int i = 0; i < NBW; i++)
-                    if (RF_WAVES * i + wave < nb)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[2 * RF_WAVES * i], rf_f4(b1[i >> 2], i & 3), acc[i], 0, 0, 0);
-                if (NRP > 0 && 16 * xm < nb) {
-#pragma unroll
-                    for (int opi = 0; opi < 2; opi++) {
-                        const int op = 2 * (wave & 1) + opi;
-                        const float *ax = R + (2 * op + (xj >> 1)) * os + kb + (xj & 1) + 2 * (16 * xm + xb);
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; k4++) {
-                            const float a = ax[k4 * rs];
-#pragma unroll
-                            for (int rp = 0; rp < NRP; rp++)
-                                accx[rp][opi] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, rf_f4(b2[rp], k4), accx[rp][opi], 0, 0, 0);
-                        }
-                    }
-                }
-            };
-            const int q0 = f.step_ks0[st], q1 = f.step_ks0[st + 1];
-            if (!RA_DBG(g, 2)) load_b(q0, breg[0], bx[0]);
-            __syncthreads();
-            if (!RA_DBG(g, 2)) {
-                for (int q = q0; q < q1; q += 2) {
-                    if (q + 1 < q1) load_b(q + 1, breg[1], bx[1]);
-                    mul_q(q, breg[0], bx[0]);
-                    if (q + 1 < q1) {
-                        if (q + 2 < q1) load_b(q + 2, breg[0], bx[0]);
-                        mul_q(q + 1, breg[1], bx[1]);
-                    }
-                }
-            }
-            __syncthreads();
         }
-        // ---- Normalize_ring statistics of every offset slot (ring order, fixed butterfly: reproducible)
-        if (wave < f.nxo) {
-            float a = 0.f, q2 = 0.f;
-            for (int i = lane; i < g.nring; i += 64) { a += part[2 * (wave * g.nring + i)]; q2 += part[2 * (wave * g.nring + i) + 1]; }
-            a = wave_sum(a); q2 = wave_sum(q2);
+        __syncthreads();
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n in the ring buffer, 1/sigma later
+        if (wave < 4) {
+            float a = 0.f, q = 0.f;
+            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
+            a = wave_sum(a); q = wave_sum(q);
             if (lane == 0) {
                 float avg = 0.f, rsg = 1.f;
                 if (g.mode == RA_MODE_MREF) {
                     const float nn = g.nn_weight;
                     avg = a / nn;
-                    rsg = 1.0f / sqrtf((q2 - a * a / nn) / nn);
+                    rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
                 }
-                nrm[wave] = avg; nrm[8 + wave] = rsg;
+                red[8 + wave] = avg; red[12 + wave] = rsg;
             }
         }
         __syncthreads();
-        // ---- CCF spectra -> LDS, inverse FFT, argmax: rounds of f.rz references
-        if (RA_DBG(g, ~0) && tid < f.nxo * nref) {   // profiling builds that skip a phase still emit in-range records
+        if (g.mode == RA_MODE_MREF && tid < 4 * g.nring) {
+            const int s = tid / g.nring, i = tid - s * g.nring;
+            const int4 ri = g.ringinfo[i];
+            bufs[s * g.sbuf + ri.x] -= red[8 + s] * (float)ri.z;
+        }
+        __syncthreads();
+        // ---- contraction: accumulate this wave's units over the rings that have bins of its group
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
+        const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
+        f32x4 acc[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!RA_DBG(g, 2) && rp0 < f.nrp) {
+            const int nq = f.grp_nq[xm], r0 = f.grp_ring0[xm];
+            const float *bp = Bf + f.grp_boff[xm] + ln * 4;
+            // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
+            const float *abase = bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1);
+            float4 bA[NRPW], bB[NRPW];
+            auto load_b = [&](int rq, float4 (&b)[NRPW]) {
+#pragma unroll
+                for (int h = 0; h < NRPW; h++)      // a pair beyond the last one re-reads the last: its units are never stored
+                    b[h] = *reinterpret_cast<const float4 *>(bp + (min(rp0 + h, f.nrp - 1) * nq + rq) * 256);
+            };
+            auto mul_rq = [&](int rq, const float4 (&b)[NRPW]) {
+                float a0[4], a1[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int o = f.roff[r0 + 4 * rq + c];       // scalar load (padded ring slots have zero B)
+                    a0[c] = abase[o];
+                    a1[c] = abase[o + 2 * g.sbuf];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int h = 0; h < NRPW; h++) {
+                        acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
+                        acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[c], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+                    }
+            };
+            // two ring quads per trip, B operands of the next quad requested before the current one is multiplied
+            // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use)
+            load_b(0, bA);
+#pragma unroll 1
+            for (int rq = 0; rq < nq; rq += 2) {
+                load_b(min(rq + 1, nq - 1), bB);
+                __builtin_amdgcn_sched_barrier(0);
+                mul_rq(rq, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(min(rq + 2, nq - 1), bA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rq + 1 < nq) mul_rq(rq + 1, bB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                       // every wave has finished reading the ring buffers
+        // ---- CCF spectra -> LDS (over the ring buffers), inverse FFT, argmax: rounds of f.rz references
+        if (RA_DBG(g, ~0) && tid < 4 * nref) {   // profiling builds that skip a phase still emit in-range records
             pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = tid % nref;
             for (int k7 = 0; k7 < 7; k7++) pc[tid].t7[k7] = 0.f;
         }
-        for (int zr = 0; zr < f.nzr && !RA_DBG(g, 4); zr++) {
-            const int ref_lo = zr * f.rz, nrz = min(f.rz, nref - ref_lo);
-            {   // 16x16x4 accumulators: this lane holds (offset o_epi, reference r8) of the bins 16 i + wave
-                const int rr = r8 - ref_lo;
-                const bool mine = o_epi < f.nxo && r8 < nref && rr >= 0 && rr < nrz;
-                const int zslot = o_epi * f.rz + rr;
-                const float dcw = mine ? cdc[r8] * nrm[o_epi] : 0.f;
-                if (ref_lo < 8) {
+        auto store_round = [&](int ref_lo, int nrz) {
 #pragma unroll
-                    for (int i = 0; i < NBW; i++) {
-                        const f32x4 c4 = acc[i];
-                        const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
-                        const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                        const float ca = odd ? r0 : c4[0], cb = odd ? r1 : c4[1];
-                        const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
-                        if (mine) rf_store_z<N>(R, zslot, RF_WAVES * i + wave, ca, cb, cc, cd, dcw);
-                    }
+            for (int i = 0; i < NU; i++) {
+                const int rp = rp0 + (i >> 1), ref = 2 * rp + (xj >> 1), o = 2 * (i & 1) + odd, rr = ref - ref_lo;
+                const f32x4 c4 = acc[i];
+                const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
+                const float r0x = swap_lane_pair(s0), r1x = swap_lane_pair(s1);
+                const float ca = odd ? r0x : c4[0], cb = odd ? r1x : c4[1];
+                const float cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
+                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz)
+                    rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca, cb, cc, cd);
+            }
+        };
+        auto ifft_round = [&](int ref_lo, int nrz) {
+            // lane groups (sub, sub ^ 1) of a half-wave take spectrum slots zs and zs + 16: their LDS images are 32 banks apart
+            const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
+            const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
+            const int rr = zs % f.rz, o = zs / f.rz;
+            if (zs < 4 * f.rz && rr < nrz && !RA_DBG(g, 1))      // uniform over the 16-lane group
+                ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr);
+        };
+        if (!RA_DBG(g, 4)) {
+            if (f.nzr == 1) {                  // the accumulators die before the inverse FFT: no register pressure from them
+                store_round(0, nref);
+                __syncthreads();
+                ifft_round(0, nref);
+                __syncthreads();
+            } else {
+                for (int zr = 0; zr < f.nzr; zr++) {
+                    const int ref_lo = zr * f.rz, nrz = min(f.rz, nref - ref_lo);
+                    store_round(ref_lo, nrz);
+                    __syncthreads();
+                    ifft_round(ref_lo, nrz);
+                    __syncthreads();
                 }
             }
-            if (NRP > 0 && ref_lo + nrz > 8 && 16 * xm < N / 2) {
-                // 4x4x1 accumulators: (offset 2 op + odd, reference 8 + 2 rp + (column >> 1)) of bin 16 xm + xb
-#pragma unroll
-                for (int rp = 0; rp < NRP; rp++) {
-                    const int ref = 8 + 2 * rp + (xj >> 1), rr = ref - ref_lo;
-#pragma unroll
-                    for (int opi = 0; opi < 2; opi++) {
-                        const int o = 2 * (2 * (wave & 1) + opi) + odd;
-                        const f32x4 c4 = accx[rp][opi];
-                        const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
-                        const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                        const float ca = odd ? r0 : c4[0], cb = odd ? r1 : c4[1];
-                        const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
-                        if (o < f.nxo && ref < nref && rr >= 0 && rr < nrz)
-                            rf_store_z<N>(R, o * f.rz + rr, 16 * xm + xb, ca, cb, cc, cd, cdc[ref] * nrm[o]);
-                    }
-                }
-            }
-            __syncthreads();
-            {
-                // lane groups (sub, sub ^ 1) of a half-wave take spectrum slots zs and zs + 16: their LDS images are 32 banks apart
-                const int j = lane & 15, sub = lane >> 4, u = 2 * wave + (sub >> 1);
-                const int zs = (u & 15) + 16 * (sub & 1) + 32 * (u >> 4);
-                const int rr = zs % f.rz, o = zs / f.rz;
-                if (zs < f.nxo * f.rz && rr < nrz && !RA_DBG(g, 1))      // uniform over the 16-lane group
-                    ifft_argmax<N, 1, 0>(R, pc + (o * nref + ref_lo + rr) - zs, twl, zs, zs, j, ref_lo + rr);
-            }
-            __syncthreads();
         }
-        // best reference per offset of the row (ascending reference, ">=": later wins), scaled by 1/sigma
-        if (tid < f.nxo * (int)(sizeof(CandT) / 4)) {
+        // best reference per offset of the pass (ascending reference, ">=": later wins), scaled by 1/sigma
+        if (tid < 4 * (int)(sizeof(CandT) / 4)) {
             constexpr int W = sizeof(CandT) / 4;
             const int o = tid / W, wd = tid - o * W;
             float bv = pc[o * nref].val; int br = 0;
@@ -487,11 +370,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const float v = pc[o * nref + q3].val;
                 if (v >= bv) { bv = v; br = q3; }
             }
-            const int sft = pass * nx1 + o;
             int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
-            if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * nrm[8 + o]);     // val, t7[]
-            reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + sft)[wd] = word;
+            if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
+            reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + grp * 4 + o)[wd] = word;
         }
+        __syncthreads();
+    }
     }
 }
 
