@@ -48,7 +48,8 @@ struct FusedGeom {
     int grp_boff[8];               // float offset of group m's B block: [pair][ring quad][lane][4 rings]
     int grp_nq[8];                 // ring quads of group m
     const int *bsrc;               // [b_floats] (entry << 5 | reference << 1 | imaginary part), -1 = 0
-    int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's); kernel-argument memory: scalar loads
+    int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's)
+    int gstr;                      // ints per group in the LDS table of ring offsets (quads of 4, padded by one quad)
     const float *cdc_w;            // unused by the kernel (the DC correction happens in the ring buffer); kept for diagnostics
 };
 
@@ -119,7 +120,8 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     out.cdc_w.assign(g.nring, 0.f);
     if (g.nring > 64) return false;
     for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
-    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + g.nring + 64;
+    f.gstr = 4 * ((g.nring + 3) / 4) + 4;
+    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + 8 * (g.nring + 8) + 64;
     out.lds_bytes = fl * sizeof(float);
     f.on = out.lds_bytes <= 160 * 1024 && 4 * f.rz * zstride <= 4 * sbuf;
     return f.on != 0;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     float *red = instw_s + g.n_inst;    // [8] -, [8] avg / rsigma, [8] centres, [4*nring*2] ring partials
     float2 *tws = reinterpret_cast<float2 *>(red + 24 + 8 * g.nring + ((g.n_inst + 8 * g.nring) & 1));   // [R1*R2] inverse-FFT twiddles
     CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);              // [4][nref] records of the pass
+    int *goff_s = reinterpret_cast<int *>(pc + 4 * RF_MAXREF + 4);     // [ng][gstr] ring offsets (bytes) of every group's ring quads
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // tables and the ring-buffer slack are set up once per workgroup; the workgroup then walks over its particles
@@ -195,6 +198,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         tws[i] = make_float2(t.x, -t.y);
     }
     for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;      // slack between rings must hold finite values
+    for (int i = tid; i < f.ng * f.gstr; i += RF_THREADS) {
+        const int m = i / f.gstr, j = i - m * f.gstr;
+        goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
+    }
     const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
 
     // contraction roles: group m = 16 bins (block b = lane >> 2 is bin 16 m + b); a wave takes NRPW reference pairs
@@ -248,26 +255,23 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             }
         }
         __syncthreads();
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n in the ring buffer, 1/sigma later
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n in the ring buffer, 1/sigma later.
+        // Wave s (< 4) reduces the ring partials of offset s with a fixed butterfly (reproducible) and corrects its DC bins.
         if (wave < 4) {
             float a = 0.f, q = 0.f;
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
             a = wave_sum(a); q = wave_sum(q);
-            if (lane == 0) {
-                float avg = 0.f, rsg = 1.f;
-                if (g.mode == RA_MODE_MREF) {
-                    const float nn = g.nn_weight;
-                    avg = a / nn;
-                    rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+            float avg = 0.f, rsg = 1.f;
+            if (g.mode == RA_MODE_MREF) {
+                const float nn = g.nn_weight;
+                avg = a / nn;
+                rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+                for (int i = lane; i < g.nring; i += 64) {
+                    const int ro = f.roff[i], nlen = (i + 1 < g.nring ? f.roff[i + 1] : g.lring) - ro - kRingPad;
+                    bufs[wave * g.sbuf + ro] -= avg * (float)nlen;
                 }
-                red[8 + wave] = avg; red[12 + wave] = rsg;
             }
-        }
-        __syncthreads();
-        if (g.mode == RA_MODE_MREF && tid < 4 * g.nring) {
-            const int s = tid / g.nring, i = tid - s * g.nring;
-            const int4 ri = g.ringinfo[i];
-            bufs[s * g.sbuf + ri.x] -= red[8 + s] * (float)ri.z;
+            if (lane == 0) { red[8 + wave] = avg; red[12 + wave] = rsg; }
         }
         __syncthreads();
         // ---- contraction: accumulate this wave's units over the rings that have bins of its group
@@ -277,44 +281,64 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
 #pragma unroll
         for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
-            const int nq = f.grp_nq[xm], r0 = f.grp_ring0[xm];
+            const int nq = f.grp_nq[xm];
             const float *bp = Bf + f.grp_boff[xm] + ln * 4;
             // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
-            const float *abase = bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1);
+            const char *abase = reinterpret_cast<const char *>(bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
+            const int a1off = 8 * g.sbuf;
+            const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
             float4 bA[NRPW], bB[NRPW];
+            float aA[8], aB[8];
             auto load_b = [&](int rq, float4 (&b)[NRPW]) {
 #pragma unroll
                 for (int h = 0; h < NRPW; h++)      // a pair beyond the last one re-reads the last: its units are never stored
-                    b[h] = *reinterpret_cast<const float4 *>(bp + (min(rp0 + h, f.nrp - 1) * nq + rq) * 256);
+                    b[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : (min(rp0 + h, f.nrp - 1) * nq + rq) * 256));
             };
-            auto mul_rq = [&](int rq, const float4 (&b)[NRPW]) {
-                float a0[4], a1[4];
+            auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
+                if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
+                a[0] = *reinterpret_cast<const float *>(abase + o.x); a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off);
+                a[2] = *reinterpret_cast<const float *>(abase + o.y); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
+                a[4] = *reinterpret_cast<const float *>(abase + o.z); a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off);
+                a[6] = *reinterpret_cast<const float *>(abase + o.w); a[7] = *reinterpret_cast<const float *>(abase + o.w + a1off);
+            };
+            auto mul_rq = [&](const float (&a)[8], const float4 (&b)[NRPW]) {
+                if (RA_DBG(g, 128)) {        // profiling: operands stay live, no matrix instructions
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int o = f.roff[r0 + 4 * rq + c];       // scalar load (padded ring slots have zero B)
-                    a0[c] = abase[o];
-                    a1[c] = abase[o + 2 * g.sbuf];
+                    for (int c = 0; c < 8; c++) asm volatile("" :: "v"(a[c]));
+#pragma unroll
+                    for (int h = 0; h < NRPW; h++) asm volatile("" :: "v"(b[h].x), "v"(b[h].y), "v"(b[h].z), "v"(b[h].w));
+                    return;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++)
 #pragma unroll
                     for (int h = 0; h < NRPW; h++) {
-                        acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
-                        acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[c], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+                        acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
+                        acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
                     }
             };
-            // two ring quads per trip, B operands of the next quad requested before the current one is multiplied
-            // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use)
+            // modulo schedule over the ring quads: while quad rq is multiplied, the A operands of quad rq + 1 are on
+            // their way from LDS, its B operands from L2, and the ring offsets of quad rq + 2 from the LDS table
+            // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  In-situ
+            // measurements (scripts/fused_phases.sh): the phase is paced by the B stream through the vector memory
+            // path (283 KB per pass and CU at 64 B/clk) plus the matrix instructions; deeper prefetch does not help.
+            const int ql = nq - 1;
+            int4 oA = gq[0], oB = gq[min(1, ql)];
             load_b(0, bA);
+            read_a(oA, aA);
 #pragma unroll 1
             for (int rq = 0; rq < nq; rq += 2) {
-                load_b(min(rq + 1, nq - 1), bB);
+                load_b(min(rq + 1, ql), bB);
+                read_a(oB, aB);
+                oA = gq[min(rq + 2, ql)];
                 __builtin_amdgcn_sched_barrier(0);
-                mul_rq(rq, bA);
+                mul_rq(aA, bA);
                 __builtin_amdgcn_sched_barrier(0);
-                load_b(min(rq + 2, nq - 1), bA);
+                load_b(min(rq + 2, ql), bA);
+                read_a(oA, aA);
+                oB = gq[min(rq + 3, ql)];
                 __builtin_amdgcn_sched_barrier(0);
-                if (rq + 1 < nq) mul_rq(rq + 1, bB);
+                if (rq + 1 < nq) mul_rq(aB, bB);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
