@@ -1,39 +1,87 @@
 #!/usr/bin/env python3
-"""bench.py -- particles/s of the multi-reference 2-D alignment hot path on MI355X.
+"""bench.py -- particles/s of the 2-D alignment hot path on MI355X.
 
-One "step" = one alignment iteration over the resident particle shard: reference preparation,
-search over (reference, shift, mirror, angle), rot_shift2D + per-class even/odd accumulation,
-the class-sum all-reduce and the reference update (test_mref_gpu_align.py:408-575).
-Workload at N=1: BASELINE.json configs[1] -- 50 000 synthetic 90x90 particles, nref=10,
-xr=yr=3, ts=1, ou=36.  Particles are already resident in HBM when the timed region starts.
-For N>1 every rank holds its own 50 000-particle shard (weak scaling) and the only collective
-is the RCCL all-reduce of the class sums.
+One "step" = one alignment iteration over the resident particle shard: reference preparation, search over
+(reference, shift, mirror, angle), rot_shift2D + per-class even/odd accumulation, the class-sum all-reduce and the
+reference update (test_mref_gpu_align.py:408-575; test_reffree_gpu_align.py:361-540 for --workload reffree).
+Particles are already resident in HBM when the timed region starts.  For N>1 every rank holds its own shard (weak
+scaling) and the only collective is the RCCL all-reduce of the class sums.
 
-    python bench.py --gpus 1 --steps 6 --warmup 1
+    python bench.py --gpus 1 --steps 6 --warmup 1                       # BASELINE configs[1] (the metric's config)
+    python bench.py --workload reffree                                  # BASELINE configs[2]
+    python bench.py --workload largebox                                 # BASELINE configs[4] geometry, one GPU's share
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`--gpus N` without a torch.distributed launcher re-launches itself under one (N child processes) before any GPU call;
+a launcher whose world size differs from N is an error.  It never silently runs a single rank.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from cryo_ralib_amd import api, dist as rdist, geometry, synth  # noqa: E402
-from cryo_ralib_amd.mref import MrefAligner  # noqa: E402
-
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+
+WORKLOADS = {
+    # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
+    "mref": ("configs[1]", 90, 36, 3.0, 10, 50000, 6, 1),
+    "reffree": ("configs[2]", 90, 36, 3.0, 1, 50000, 10, 1),
+    "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 4096, 2, 1),
+}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mref")
+    ap.add_argument("--particles", type=int, default=None, help="particles per GPU")
+    ap.add_argument("--nref", type=int, default=None)
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ou", type=int, default=None)
+    ap.add_argument("--xr", type=float, default=None)
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--function", default="ref_ali2d", help="reference preparation per iteration: ref_ali2d (the "
+                    "reference's default --function: FSC-fitted tangent filter + centring, on the device) | none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    args = ap.parse_args(argv)
+    cfg, nx, ou, xr, nref, n, steps, warm = WORKLOADS[args.workload]
+    args.config_name = cfg
+    args.nx = args.nx or nx; args.ou = args.ou or ou; args.xr = xr if args.xr is None else args.xr
+    args.nref = args.nref or nref; args.particles = args.particles or n
+    args.steps = steps if args.steps is None else args.steps
+    args.warmup = warm if args.warmup is None else args.warmup
+    return args
+
+
+def relaunch_under_launcher(args):
+    """--gpus N given to a plain `python bench.py`: start N ranks as child processes (before this process touches
+    the GPU) and hand back their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def algorithmic_flops(nx, ou, xr, yr, ts, nref):
-    """SURVEY.md §8(d) work formula, split into the polar/FFT stage and the CCF stage."""
+    """SURVEY.md section 8(d) work formula, split into the polar/FFT stage and the CCF stage."""
+    from cryo_ralib_amd import geometry
     numr = geometry.numrinit(1, ou, 1)
     lens = numr[2::3]
     L = sum(lens)
@@ -46,10 +94,13 @@ def algorithmic_flops(nx, ou, xr, yr, ts, nref):
 
 def generate_shard(engine_dev, refs_np, n, xr, yr, sigma, shard, nx, ou):
     """synthetic particles built ON the GPU with the product's own rot_shift2D kernel
-    (rotate -> shift -> mirror of a random class reference) + Gaussian noise; BASELINE.md §3."""
+    (rotate -> shift -> mirror of a random class reference) + Gaussian noise; BASELINE.md section 3."""
+    import numpy as np
+    import torch
+    from cryo_ralib_amd import api, synth
     nref = refs_np.shape[0]
     truth = synth.plant_truth(nref, n, xr, yr, 2000 + shard)
-    gen = api.Engine(nx, ou, xr, yr, 1.0, nref, api.RA_MODE_MREF, device=engine_dev.index)
+    gen = api.Engine(nx, ou, xr, yr, 1.0, min(nref, 8), api.RA_MODE_MREF, device=engine_dev.index)
     gen.use_current_stream()
     refs = torch.from_numpy(refs_np).to(engine_dev)
     out = torch.empty((n, nx, nx), dtype=torch.float32, device=engine_dev)
@@ -60,7 +111,7 @@ def generate_shard(engine_dev, refs_np, n, xr, yr, sigma, shard, nx, ou):
     rec["mirror"] = truth["mir"]; rec["ref_id"] = truth["cls"]
     res = torch.from_numpy(rec.view(np.int32).reshape(n, 8)).to(engine_dev)
     cls = torch.from_numpy(truth["cls"].astype(np.int64)).to(engine_dev)
-    step = 8192
+    step = 8192 if nx <= 128 else 512
     for s in range(0, n, step):
         e = min(n, s + step)
         src = refs[cls[s:e]].contiguous()
@@ -84,48 +135,118 @@ def host_cores():
     return n
 
 
-def cpu_baseline(refs_np, nx, ou, xr, yr, nref, target_seconds=15.0):
-    """the CPU restatement of the EMAN2 path (oracle/, kind "port") timed on this host's cores
-    on a bounded sample of the same workload."""
+def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=12.0):
+    """the CPU restatement of the EMAN2 path (oracle/, kind "port") timed on this host's cores on a bounded sample
+    of the same workload: all cores (OpenMP over particles), and one thread (what one EMAN2 MPI rank does)."""
+    import numpy as np
+    from cryo_ralib_amd import synth
     from oracle import oracle as orc
     threads = host_cores()
     rg = orc.rings(1, ou, 1)
     mask = orc.model_circle(ou, nx, nx)
-    _, cref = orc.prepare_refs(refs_np, mask, rg)
-    n0 = 4 * threads
+    _, cref = orc.prepare_refs(refs_np, mask if not reffree else None, rg)
+    n0 = 4 * threads if nx <= 128 else threads
     parts, _ = synth.make_particles(refs_np, n0, xr, yr, 1.0, shard=99, ou=ou)
-    d = np.zeros((n0, 2), np.float32)
-    t = time.perf_counter()
-    orc.mref_iteration(parts, cref, rg, xr, yr, 1.0, d, nthreads=threads)
-    rate = n0 / (time.perf_counter() - t)
+
+    def run(p, nthreads):
+        d = np.zeros((p.shape[0], 2), np.float32)
+        t = time.perf_counter()
+        if reffree:
+            orc.reffree_iteration(p, cref[0], rg, xr, yr, 1.0, (0, 0), d, np.zeros((p.shape[0], 6), np.float32), nthreads=nthreads)
+        else:
+            orc.mref_iteration(p, cref, rg, xr, yr, 1.0, d, nthreads=nthreads)
+        return time.perf_counter() - t
+
+    rate = n0 / run(parts, threads)
     n1 = int(max(n0, min(20000, rate * target_seconds)))
-    reps = (n1 + n0 - 1) // n0
-    big = np.concatenate([parts] * reps)[:n1]
-    d = np.zeros((n1, 2), np.float32)
-    t = time.perf_counter()
-    orc.mref_iteration(big, cref, rg, xr, yr, 1.0, d, nthreads=threads)
-    dt = time.perf_counter() - t
+    big = np.concatenate([parts] * ((n1 + n0 - 1) // n0))[:n1]
+    runs = sorted(run(big, threads) for _ in range(1 if nx > 128 else 2))
+    dt = runs[len(runs) // 2]
+    n2 = int(max(4, min(n1, rate / threads * 6.0)))
+    dt1 = run(big[:n2], 1)
+    what = "ali2d_single_iter" if reffree else "mref_ali2d"
     return {"value": n1 / dt, "unit": "particles/s", "cores": threads, "kind": "port",
-            "sample": "%d particles x 1 iteration of the oracle's mref_ali2d loop (search + rot_shift2D + class sums), "
-                      "%d OpenMP threads, %.1f s" % (n1, threads, dt)}
+            "sample": "%d particles x 1 iteration of the oracle's %s loop (search + rot_shift2D + class sums), "
+                      "%d OpenMP threads, %.1f s (median of %d)" % (n1, what, threads, dt, len(runs)),
+            "single_thread": {"value": n2 / dt1, "unit": "particles/s", "cores": 1,
+                              "sample": "%d particles x 1 iteration, 1 thread, %.1f s" % (n2, dt1)}}
+
+
+def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=512):
+    """SURVEY.md section 8(d) "parity checks reported with every perf number": the engine against the oracle on a
+    sigma = 0.25 and a sigma = 1.0 subsample of the same synthetic workload."""
+    import numpy as np
+    import torch
+    from cryo_ralib_amd import api
+    from oracle import oracle as orc
+    if nx > 128:
+        n = 8
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    out = {"particles_per_set": n, "peak_tolerance": 1e-4}
+    for sigma in (0.25, 1.0):
+        parts_t, _ = generate_shard(dev, refs_np, n, xr, xr, sigma, 7, nx, ou)
+        parts = parts_t.cpu().numpy()
+        parts = np.stack([orc.normalize_mask(p, mask, 0) for p in parts])
+        d = np.zeros((n, 2), np.float32)
+        if reffree:
+            tavg = parts.mean(0)[None].astype(np.float32)
+            refs_n, cref = orc.prepare_refs(tavg, None, rg)
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32),
+                                                        nthreads=host_cores())
+            mode = api.RA_MODE_REFFREE
+        else:
+            refs_n, cref = orc.prepare_refs(refs_np, mask, rg)
+            params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=host_cores())
+            mode = api.RA_MODE_MREF
+        eng = api.Engine(nx, ou, xr, xr, 1.0, refs_n.shape[0], mode, device=dev.index)
+        eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(dev))
+        st, res = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(dev), st, res)
+        eng.sync()
+        r = eng.result_to_numpy(res)
+        path = eng.search_path
+        eng.close()
+        jt = np.array([infos[i].jtot for i in range(n)])
+        same = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & (r["angle_bin"] == jt) & \
+               (np.abs(st.cpu().numpy() - d).max(1) < 1e-6)
+        rel = np.abs(r["peak"] - params[:, 5]) / np.abs(params[:, 5])
+        key = "sigma_%g" % sigma
+        out[key] = {"max_rel_peak": float(rel.max()), "exact_match_rate": float(same.mean()),
+                    "tie_flips": int((~same).sum()),
+                    "max_rel_peak_gap_of_flips": float(rel[~same].max()) if (~same).any() else 0.0}
+        out["search_path"] = {0: "kernel pair", 1: "fused", 2: "generic"}[path]
+    return out
+
+
+def committed_traffic(kernel_substr):
+    """HBM bytes per particle of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); PMC counters cannot be read from inside this process."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            for k, v in pm["kernels"].items():
+                if kernel_substr in k and "hbm_bytes_per_dispatch_corrected" in v:
+                    return v["hbm_bytes_per_dispatch_corrected"] / pm["particles_per_dispatch"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--particles", type=int, default=50000, help="particles per GPU")
-    ap.add_argument("--nref", type=int, default=10)
-    ap.add_argument("--nx", type=int, default=90)
-    ap.add_argument("--ou", type=int, default=36)
-    ap.add_argument("--xr", type=float, default=3.0)
-    ap.add_argument("--sigma", type=float, default=1.0)
-    ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--function", default="ref_ali2d", help="reference preparation per iteration: ref_ali2d (the "
-                    "reference's default --function: FSC-fitted tangent filter + centring, on the device) | none")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(relaunch_under_launcher(args))
+    if world_env is not None and int(world_env) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, world_env))
+
+    import numpy as np
+    import torch
+    from cryo_ralib_amd import api, dist as rdist, synth
+    from cryo_ralib_amd.mref import MrefAligner, RefFreeAligner
 
     rank, local, world = rdist.init_from_env()
     if not torch.cuda.is_available():
@@ -134,63 +255,99 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nx, ou, xr, nref, n = args.nx, args.ou, args.xr, args.nref, args.particles
-
-    refs_np = synth.make_references(nref, nx, ou)
-    particles, _ = generate_shard(dev, refs_np, n, xr, xr, args.sigma, rank, nx, ou)
-    # the run starts from the generating references; every step re-estimates them from the data
-    al = MrefAligner(particles, refs_np, ou, xr, xr, 1.0, device=local, index0=rank * n, total_nima=n * world,
-                     preprocess=True, chunk=args.chunk)
+    reffree = args.workload == "reffree"
     user_func = None if args.function in ("none", "None", "") else args.function
+
+    refs_np = synth.make_references(max(nref, 1), nx, ou)
+    particles, _ = generate_shard(dev, refs_np, n, xr, xr, args.sigma, rank, nx, ou)
+    pcie = None
+    if rank == 0 and not args.no_pcie:
+        # the boundary hands over host buffers (pre_align_fetch): one pinned H2D copy of the shard, measured once
+        host = torch.empty(particles.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(particles)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        particles.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        pcie = time.perf_counter() - t
+        del host
+    # the run starts from the generating references; every step re-estimates them from the data
+    if reffree:
+        al = RefFreeAligner(particles, ou, xr, xr, 1.0, device=local, index0=rank * n, total_nima=n * world, preprocess=True,
+                            chunk=args.chunk)
+        step = lambda: al.iterate(-1, user_func)
+    else:
+        al = MrefAligner(particles, refs_np, ou, xr, xr, 1.0, device=local, index0=rank * n, total_nima=n * world,
+                         preprocess=True, chunk=args.chunk)
+        step = lambda: al.iterate(user_func, 1)
     for _ in range(args.warmup):
-        al.iterate(user_func, 1)
+        step()
     al.engine.kernel_time(True)          # arm HIP-event timing of the hot kernels on the engine's stream
     rdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        al.iterate(user_func, 1)
+        step()
     rdist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = rdist.max_over_ranks(dt, dev)
-    ms_ccf, n_ccf, ms_polar, n_polar = al.engine.kernel_time(False)
+    ms_a, n_a, ms_b, n_b = al.engine.kernel_time(False)
+    path = al.engine.search_path
 
     if rank == 0:
-        # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
-        # gfx950 + WRITE_SIZE, per particle), scaled to this run's particles per launch
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_v8_pmc_summary.json")) as f:
-                pm = json.load(f)
-            if (nx, ou, nref) == (90, 36, 10):
-                key = [k for k in pm["kernels"] if "ccf_kernel<256>" in k][0]
-                per_particle = pm["kernels"][key]["hbm_bytes_per_dispatch_corrected"] / pm["particles_per_dispatch"]
-                traffic = per_particle * (n * args.steps / max(n_ccf, 1))
-        except (OSError, KeyError, ValueError, IndexError):
-            pass
         total = n * world * args.steps
         polar_f, ccf_f, S, L, M = algorithmic_flops(nx, ou, xr, xr, 1.0, nref)
-        # average launch: total particles through the kernel / launches
-        part_per_launch = n * args.steps / max(n_ccf, 1)
-        avg_ms = ms_ccf / max(n_ccf, 1)
-        achieved = ccf_f * part_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        per_launch = n * args.steps / max(n_a, 1)
+        kernels = {}
+        if path == 1:
+            kernels["search_fused_kernel<%d>" % M] = {
+                "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + inverse FFT + argmax, "
+                        "particle-resident", "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
+        else:
+            nm = ("ccf_generic_kernel", "polar_generic_kernel") if path == 2 else ("ccf_kernel<%d>" % M, "polar_fft_kernel")
+            kernels[nm[0]] = {"what": "Crosrng_ms contraction (16x16x4 MFMA) + inverse FFT + argmax", "avg_launch_ms": ms_a / max(n_a, 1),
+                              "launches": n_a, "flops_per_particle": ccf_f}
+            kernels[nm[1]] = {"what": "Polar2Dm + Normalize_ring + Frngs", "avg_launch_ms": ms_b / max(n_b, 1), "launches": n_b,
+                              "flops_per_particle": polar_f}
+        for k in kernels.values():
+            k["achieved_tflops"] = k["flops_per_particle"] * per_launch / (k["avg_launch_ms"] * 1e-3) / 1e12 if k["avg_launch_ms"] > 0 else 0.0
+            k["frac"] = k["achieved_tflops"] / PEAK_F32_TFLOPS
+        dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+        kern_ms = sum(k["avg_launch_ms"] * k["launches"] for k in kernels.values())
+        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0])
+        whole = (polar_f + ccf_f) * total / world / dt / 1e12
+        what = ("%s: %d synthetic %dx%d particles per GPU, %s, xr=yr=%g, ts=1, ou=%d; step = one %s iteration (search + rot_shift2D + "
+                "class sums + all-reduce + reference update with --function=%s)") % (
+                   "BASELINE " + args.config_name if (args.nx, args.ou, args.xr, args.nref) == WORKLOADS[args.workload][1:5] else "custom",
+                   n, nx, nx, "reference-free (running average)" if reffree else "nref=%d" % nref, xr, ou,
+                   "ali2d" if reffree else "mref_ali2d", args.function)
         line = {
-            "metric": "particles/sec aligned, %dx%d nref=%d xr=yr=%g ou=%d" % (nx, nx, nref, xr, ou),
+            "metric": "particles/sec aligned, %dx%d %s xr=yr=%g ou=%d" % (nx, nx, "reference-free ali2d" if reffree else "nref=%d" % nref, xr, ou),
             "value": total / dt, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("%s: %d synthetic %dx%d particles per GPU, nref=%d, xr=yr=%g, ts=1, "
-                                    "ou=%d; step = one mref_ali2d iteration (search + rot_shift2D + class sums + "
-                                    "all-reduce + reference update with --function=" + str(args.function) + ")") % (
-                                       "BASELINE configs[1]" if (nx, ou, nref, xr) == (90, 36, 10, 3.0) else "custom", n, nx, nx, nref, xr, ou),
-                       "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "kernel": "ccf_kernel<%d> (Crosrng_ms contraction + IFFT + argmax)" % M,
-                         "flops_per_particle": ccf_f, "particles_per_launch": part_per_launch,
-                         "avg_launch_ms": avg_ms, "launches": n_ccf,
-                         "polar_fft_kernel": {"avg_launch_ms": ms_polar / max(n_polar, 1), "flops_per_particle": polar_f}},
+            "config": {"workload": what, "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world,
+                       "search_path": {0: "kernel pair", 1: "fused", 2: "generic"}[path]},
+            "roofline": {"bound": "mfma", "achieved": kernels[dom]["achieved_tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": kernels[dom]["frac"],
+                         "traffic": traffic_pp * per_launch if traffic_pp is not None else None,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE per particle x particles per launch)",
+                         "traffic_per_particle": traffic_pp, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_particle": 2 * nx * nx * 4 + 24,
+                         "kernel": dom, "flops_per_particle": kernels[dom]["flops_per_particle"],
+                         "particles_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_launch_ms"],
+                         "launches": kernels[dom]["launches"], "kernels": kernels,
+                         "hot_kernels_share_of_step": kern_ms / (dt * 1e3),
+                         "whole_path": {"achieved": whole, "frac": whole / PEAK_F32_TFLOPS,
+                                        "flops_per_particle": polar_f + ccf_f}},
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = {"value": total / world / (pcie + dt), "unit": "particles/s per GPU",
+                                      "h2d_seconds": pcie, "h2d_gb_per_s": particles.numel() * 4 / pcie / 1e9,
+                                      "note": "one pinned H2D copy of the shard + the %d timed steps" % args.steps}
+        if world == 1 and not args.no_parity:
+            line["parity"] = parity_block(refs_np, nx, ou, xr, nref, reffree, dev)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(refs_np, nx, ou, xr, xr, nref)
+            line["cpu_baseline"] = cpu_baseline(refs_np, nx, ou, xr, xr, nref, reffree)
         print(json.dumps(line))
     al.close()
     if world > 1:

@@ -297,3 +297,21 @@ def test_filter_clamps_match_the_reference_run_log(golden_dir):
     assert fl == 0.12 and aa <= 0.2
     f2, a2 = api.fit_tanh([list(freq), list(fsc), [1.0] * n])
     assert max(min(0.4, f2), 0.12) == 0.12
+
+
+def test_bench_gpus_flag_never_runs_a_single_rank_silently():
+    """`bench.py --gpus 2` without a launcher starts 2 ranks itself (before any GPU call); here, without a GPU, both
+    ranks must fail loudly -- the one thing it may not do is print a 1-GPU line.  A launcher with another world size is
+    rejected."""
+    import subprocess
+    import sys
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--particles", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+    assert '"n_gpus": 1' not in r.stdout
+    env["WORLD_SIZE"] = "4"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "launcher started 4 ranks" in (r.stderr + r.stdout)
