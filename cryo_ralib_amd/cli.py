@@ -133,16 +133,24 @@ def main_reffree(argv=None):
     data = stackio.read_stack(args.stack)
     total, nx = data.shape[0], data.shape[-1]
     ou = int(args.ou) if args.ou > 0 else nx // 2 - 2
-    xr = _first(args.xr)
-    yr = xr if _first(args.yr) < 0 else _first(args.yr)
     lo, hi = rdist.shard_range(total, world, rank)
-    al = RefFreeAligner(data[lo:hi], ou, xr, yr, _first(args.ts), int(args.ir), int(args.rs), device=local, index0=lo,
-                        total_nima=total)
-    maxit = int(args.maxit) if int(args.maxit) > 0 else 10
-    for it in range(maxit):
-        a1 = al.iterate(int(args.center), _user_func(args.function))
-        if rank == 0:
-            print("Iteration #%4d   Criterion = %15.8e" % (it + 1, a1))
+    # "--xr '4 2 1 1' --ts '2 1 0.5 0.25'": one stage per entry, --maxit iterations each; --maxit 0 = 10 with auto-stop
+    al = RefFreeAligner(data[lo:hi], ou, args.xr, args.yr, args.ts, int(args.ir), int(args.rs), device=local, index0=lo,
+                        total_nima=total, nomirror=args.nomirror)
+    max_iter, auto_stop = (10, True) if int(args.maxit) == 0 else (int(args.maxit), False)
+    a0, it = -1.0e22, 0
+    for n_step in range(len(al.stages)):
+        al.set_stage(n_step)
+        for _ in range(max_iter):
+            it += 1
+            a1 = al.iterate(int(args.center), _user_func(args.function))
+            if rank == 0:
+                print("Iteration #%4d   X range = %5.2f   Y range = %5.2f   Step = %5.2f   Criterion = %15.8e" % ((it,) + al.stages[n_step] + (a1,)))
+            if a1 < a0:
+                if auto_stop:
+                    break
+            else:
+                a0 = a1
     r = al.params()
     rows = [(float(r["alpha"][i]), float(r["sx"][i]), float(r["sy"][i]), int(r["mirror"][i])) for i in range(hi - lo)]
     if world > 1:

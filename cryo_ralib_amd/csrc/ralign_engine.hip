@@ -124,7 +124,7 @@ static int build_device_geometry(ra_engine *e)
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
-    d.nn_weight = g.nn_weight; d.mode = e->cfg.mode;
+    d.nn_weight = g.nn_weight; d.mode = e->cfg.mode; d.nomirror = 0;
 #ifdef RALIGN_PROFILE_SWITCHES
     d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
 #else
@@ -559,6 +559,12 @@ extern "C" int ra_set_stream(ra_engine *e, void *hip_stream)
     return RA_OK;
 }
 
+extern "C" int ra_set_nomirror(ra_engine *e, int flag)
+{
+    if (!e) return RA_ERR_ARG;
+    e->dg.nomirror = flag ? 1 : 0;
+    return RA_OK;
+}
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }

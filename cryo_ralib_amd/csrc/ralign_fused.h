@@ -367,7 +367,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
             const int rr = zs % f.rz, o = zs / f.rz;
             if (zs < 4 * f.rz && rr < nrz && !RA_DBG(g, 1))      // uniform over the 16-lane group
-                ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr);
+                ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
         };
         if (!RA_DBG(g, 4)) {
             if (f.nzr == 1) {                  // the accumulators die before the inverse FFT: no register pressure from them

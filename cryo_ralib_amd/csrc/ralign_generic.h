@@ -291,7 +291,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                         if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
                     }
                     {
-                        const bool mir = !(bq >= bt);        // qn >= qm keeps the straight match
+                        const bool mir = !g.nomirror && !(bq >= bt);        // qn >= qm keeps the straight match; nomirror: straight only
                         const int jt = mir ? it : iq;
                         CandT *dst = pc + pair;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
                         if (lane < 7) {

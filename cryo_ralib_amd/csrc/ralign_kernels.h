@@ -44,6 +44,7 @@ struct DevGeom {
     float step, xrng, yrng;
     float nn_weight;
     int mode;                     // RA_MODE_*
+    int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
     int dbg;                      // phase-skip mask of profiling builds (-DRALIGN_PROFILE_SWITCHES); unused otherwise
     int sbuf;                     // LDS stride of one ring buffer (floats)
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
@@ -705,7 +706,8 @@ __device__ __forceinline__ void contract_class(const float *__restrict__ Ablk, c
 // selects it with a compare chain and stores it straight into the candidate record) -- the transformed sequence is
 // never written back to LDS.  Records: pc[pair] = {val, jtot, refmir = mirror << 16 | ref0 + (pair & 7), t7[7]}.
 template <int N, int NP, int REFMASK = 7>
-__device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *twl, int pairA, int pairB, int j, int ref0)
+__device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *twl, int pairA, int pairB, int j, int ref0,
+                                            bool nomirror = false)
 {
     typedef ZLayout<N> ZL;
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2, TWS = IfftPlan<N>::R2;
@@ -766,8 +768,8 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
         }
         RA_DPP_STEP(0x140) RA_DPP_STEP(0x141) RA_DPP_STEP(0x4E) RA_DPP_STEP(0xB1)
 #undef RA_DPP_STEP
-        // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d)
-        const bool mir = !(bq >= bt);
+        // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d); nomirror: Crosrng_ns, straight only
+        const bool mir = !nomirror && !(bq >= bt);
         const int jt = mir ? it : iq;
         CandT *dst = pc + pr[q];
         // neighbour jt + k (k = -3..3) lives in lane (jt + k) mod R1 at register (jt + k) / R1
@@ -863,8 +865,8 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
             const bool two = NW < 16 && idx2 < nlive;     // 16 waves cover all 16 live slots in one round
             const int bA = (idx / nvalid) * 8 + idx % nvalid;
             const int bB = two ? (idx2 / nvalid) * 8 + idx2 % nvalid : bA;
-            if constexpr (NW < 16) { if (two) { ifft_argmax<N, 2>(Z, pc, twl, 16 * sub + bA, 16 * sub + bB, j, ref0); continue; } }
-            ifft_argmax<N, 1>(Z, pc, twl, 16 * sub + bA, 16 * sub + bA, j, ref0);
+            if constexpr (NW < 16) { if (two) { ifft_argmax<N, 2>(Z, pc, twl, 16 * sub + bA, 16 * sub + bB, j, ref0, g.nomirror != 0); continue; } }
+            ifft_argmax<N, 1>(Z, pc, twl, 16 * sub + bA, 16 * sub + bA, j, ref0, g.nomirror != 0);
         }
     }
     __syncthreads();

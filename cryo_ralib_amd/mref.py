@@ -163,12 +163,26 @@ def mref_ali2d_gpu(stack, refim, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10,
     return out
 
 
+def _as_list(v):
+    """"4 2 1 1" / [4, 2, 1, 1] / 4 -> list of floats (get_input_from_string, test_reffree_gpu_align.py:215-216)"""
+    if isinstance(v, str):
+        return [float(t) for t in v.replace(",", " ").split()]
+    try:
+        return [float(t) for t in v]
+    except TypeError:
+        return [float(v)]
+
+
 class RefFreeAligner:
     """single-reference alignment to the running average (ali2d_base_gpu_isac_CLEAN,
-    test_reffree_gpu_align.py:153-577; CPU twin ali2d_base -> ali2d_single_iter -> ormq)."""
+    test_reffree_gpu_align.py:153-577; CPU twin ali2d_base -> ali2d_single_iter -> ormq).
+
+    xr / yr / ts may be lists ("--xr '4 2 1 1' --ts '2 1 0.5 0.25'"): one search window per stage
+    (test_reffree_gpu_align.py:215-216); `set_stage(i)` switches the engine to stage i (reset_shifts, :355-357).
+    The engine is sized once for the stage with the most search offsets and the widest range."""
 
     def __init__(self, particles, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 preprocess=False, chunk=0):
+                 preprocess=False, chunk=0, nomirror=False):
         self.dev = torch.device("cuda", device)
         if isinstance(particles, np.ndarray):
             particles = torch.from_numpy(np.ascontiguousarray(particles, np.float32))
@@ -177,9 +191,24 @@ class RefFreeAligner:
         self.ou = int(ou)
         self.index0 = int(index0)
         self.total_nima = int(total_nima if total_nima is not None else self.n)
-        self.engine = api.Engine(self.nx, self.ou, xr, yr, ts, 1, api.RA_MODE_REFFREE, first_ring=ir, ring_skip=rs,
+        xr, ts = _as_list(xr), _as_list(ts)
+        yr = _as_list(yr)
+        if len(yr) == 1 and yr[0] < 0:
+            yr = list(xr)                                   # "--yr -1": same as xr
+        nst = max(len(xr), len(ts), len(yr))
+        pad = lambda l: l + [l[-1]] * (nst - len(l))
+        self.stages = list(zip(pad(xr), pad(yr), pad(ts)))
+        # capacity window: the widest range, and a step that yields the largest offset count of any stage
+        rmax = max(max(x, y) for x, y, _ in self.stages)
+        nk = max(max(int(x / t), int(y / t)) for x, y, t in self.stages)
+        cap_step = (rmax / nk) * (1.0 - 1e-6) if nk > 0 else 1.0
+        self.engine = api.Engine(self.nx, self.ou, rmax, rmax, cap_step, 1, api.RA_MODE_REFFREE, first_ring=ir, ring_skip=rs,
                                  device=device, chunk=chunk)
         self.engine.use_current_stream()
+        self.stage = -1
+        self.set_stage(0)
+        if nomirror:
+            self.engine.set_nomirror(True)
         self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
         if preprocess:
             self.engine.normalize_particles(self.particles)
@@ -191,6 +220,13 @@ class RefFreeAligner:
         self.iteration = 0
         self.criteria = []
         self.filter_params = []
+
+    def set_stage(self, i):
+        """search window of stage i: cu_module.reset_shifts(xrng[N_step], step[N_step]) (test_reffree_gpu_align.py:357)"""
+        if i != self.stage:
+            x, y, t = self.stages[i]
+            self.engine.reset_shifts(x, y, t)
+            self.stage = i
 
     def _sum_oe_raw(self):
         # iteration 0: plain even/odd sums of the raw particles (sum_oe, :365)
@@ -253,12 +289,33 @@ class RefFreeAligner:
 
 
 def ali2d_base_gpu(stack, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, device=0, index0=0, total_nima=None,
-                   center=0, chunk=0, user_func=None):
+                   center=0, chunk=0, user_func=None, nomirror=False, on_iteration=None):
     """mirror of ali2d_base_gpu_isac_CLEAN; returns (params records, final average, criteria).
-    Rows of initial2Dparams.txt are (alpha, sx, sy, mirror) (test_reffree_gpu_align.py:561-569)."""
-    al = RefFreeAligner(stack, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, False, chunk)
-    for _ in range(int(maxit)):
-        al.iterate(center, user_func)
+    Rows of initial2Dparams.txt are (alpha, sx, sy, mirror) (test_reffree_gpu_align.py:561-569).
+
+    xrng / yrng / step may be lists: one stage per entry, `maxit` iterations each (SPHIRE ali2d_base; the reference's
+    copy keeps the lists and runs stage 0 only, test_reffree_gpu_align.py:355-357).  maxit = 0 means 10 iterations
+    per stage with auto-stop (:224-229): the criterion a1 = sum_mask tavg^2 "should increase; stop algorithm when it
+    decreases" (:392-396, :422-432) -- a stage ends with the iteration whose average scored below the best so far."""
+    al = RefFreeAligner(stack, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, False, chunk, nomirror)
+    if int(maxit) == 0:
+        max_iter, auto_stop = 10, True
+    else:
+        max_iter, auto_stop = int(maxit), False
+    a0 = -1.0e22
+    total_iter = 0
+    for n_step in range(len(al.stages)):
+        al.set_stage(n_step)
+        for _ in range(max_iter):
+            total_iter += 1
+            a1 = al.iterate(center, user_func)
+            if on_iteration is not None:
+                on_iteration(total_iter, al, a1)
+            if a1 < a0:
+                if auto_stop:
+                    break
+            else:
+                a0 = a1
     al.engine.sync()
     out = al.params().copy(), al.tavg[0].cpu().numpy(), al.criteria
     al.close()

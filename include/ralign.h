@@ -148,6 +148,10 @@ int  ra_search_path(const ra_engine *e);
  * offsets may not grow beyond what ra_create sized */
 int  ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step);
 
+/* --nomirror (test_reffree_gpu_align.py:921, passed to ali2d_single_iter -> ormq): only the straight half of
+ * Crosrng_ms takes part in the search (Util.Crosrng_ns); flag != 0 switches it on for subsequent ra_align calls */
+int  ra_set_nomirror(ra_engine *e, int flag);
+
 /* references: d_refs [nref][nx][nx] device, ALREADY normalised under the mask
  * (test_mref_gpu_align.py:336).  Polar transform, ring FFT and ring weights
  * (Polar2Dm/Frngs/Applyws, :1015-1017) happen on the device. */

@@ -182,6 +182,11 @@ def ormq(img, crefim, xrng, yrng, step, rg, cnx, cny, interp=INTERP_BILINEAR):
     return out, info
 
 
+def set_nomirror(flag):
+    """ormq(..., nomirror): only the straight half of Crosrng_ms (Util.Crosrng_ns); process-wide switch"""
+    lib().orc_set_nomirror(int(bool(flag)))
+
+
 def model_circle(r, nx, ny, edge_le=True):
     m = np.zeros((ny, nx), np.float32)
     lib().orc_model_circle(r, nx, ny, _f(m), int(edge_le))

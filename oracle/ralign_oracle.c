@@ -428,6 +428,11 @@ void orc_multiref_polar_ali_2d(const float *img, int nx, int ny,
     free(cimage);
 }
 
+/* ormq(..., nomirror): with nomirror SPHIRE calls Util.Crosrng_ns, the straight half of Crosrng_ms alone
+ * (test_reffree_gpu_align.py:846 passes nomirror down to ali2d_single_iter -> ormq).  Process-wide switch of the checker. */
+static int g_nomirror = 0;
+void orc_set_nomirror(int flag) { g_nomirror = flag; }
+
 /* sp_alignment.ormq : single reference, python doubles, no Normalize_ring
  * (reference call: test_reffree_gpu_align.py:844-847 -> ali2d_single_iter -> ormq) */
 void orc_ormq(const float *img, int nx, int ny, const float *crefim,
@@ -448,7 +453,9 @@ void orc_ormq(const float *img, int nx, int ny, const float *crefim,
             orc_frngs(cimage, rg);
             double qn, qm; float tot, tmt; int jn, jm;
             orc_crosrng_ms(crefim, cimage, rg, &qn, &tot, &qm, &tmt, &jn, &jm);
-            if (qn >= peak || qm >= peak) {
+            if (g_nomirror) {
+                if (qn >= peak) { sx = -ix; sy = -iy; ang = orc_ang_n(tot, rg->maxrin); peak = qn; mirror = 0; jbest = jn; totbest = tot; }
+            } else if (qn >= peak || qm >= peak) {
                 sx = -ix; sy = -iy;
                 if (qn >= qm) { ang = orc_ang_n(tot, rg->maxrin); peak = qn; mirror = 0; jbest = jn; totbest = tot; }
                 else          { ang = orc_ang_n(tmt, rg->maxrin); peak = qm; mirror = 1; jbest = jm; totbest = tmt; }

@@ -80,6 +80,7 @@ void orc_multiref_polar_ali_2d(const float *img, int nx, int ny,
                                float out[6], orc_search_info *info);
 /* sp_alignment.ormq (single reference, no Normalize_ring; test_reffree_gpu_align.py:844-847).
  * out = {ang, sxs, sys, mirror, peak} */
+void orc_set_nomirror(int flag);
 void orc_ormq(const float *img, int nx, int ny, const float *crefim,
               const float xrng[2], const float yrng[2], float step,
               const orc_rings *rg, float cnx, float cny, int interp,

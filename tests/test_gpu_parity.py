@@ -1057,3 +1057,102 @@ def test_fused_kernel_is_the_default_path_and_agrees_with_the_kernel_pair(monkey
         same &= a[fld] == b[fld]
     assert (~same).sum() <= 2 and (rel[~same] < TIE_RTOL).all()
     np.testing.assert_array_equal(sa[same], sb[same])
+
+
+# ---------------------------------------------------------------------------------------------
+# search schedules and variants
+
+def test_nomirror_search_matches_ormq_with_nomirror():
+    """--nomirror (test_reffree_gpu_align.py:921 -> ali2d_single_iter -> ormq(nomirror) -> Util.Crosrng_ns): only the
+    straight half of Crosrng_ms is searched, in both kernel families"""
+    nx, ou, xr, n = 90, 36, 3, 256
+    refs = synth.make_references(1, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)       # half of the particles are mirrored
+    rg = orc.rings(1, ou, 1)
+    _, cref = orc.prepare_refs(refs, None, rg)
+    orc.set_nomirror(True)
+    try:
+        d = np.zeros((n, 2), np.float32)
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=16)
+    finally:
+        orc.set_nomirror(False)
+    assert (params[:, 3] == 0).all() and truth["mir"].any()
+    for fused in ("1", "0"):
+        os.environ["RALIGN_FUSED"] = fused
+        try:
+            eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE)
+        finally:
+            del os.environ["RALIGN_FUSED"]
+        assert eng.search_path == int(fused)
+        eng.set_nomirror(True)
+        eng.set_references(torch.from_numpy(refs).to(eng.dev))
+        st, res = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+        eng.sync()
+        r = eng.result_to_numpy(res)
+        assert (r["mirror"] == 0).all()
+        flips = compare_search(r, st.cpu().numpy(), params, infos, d, alpha_outlier_frac=0.02)
+        _log_flips("nomirror fused=%s" % fused, n, flips)
+        # and with the mirror search back on, the mirrored particles are found mirrored
+        eng.set_nomirror(False)
+        st2, res2 = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st2, res2)
+        eng.sync()
+        assert (eng.result_to_numpy(res2)["mirror"] == truth["mir"]).mean() > 0.98
+        eng.close()
+
+
+def test_multi_stage_schedule_against_oracle():
+    """--xr "2 1" --ts "1 0.5": one search window per stage, the engine re-shifted per stage
+    (test_reffree_gpu_align.py:215-216, :355-357); every iteration against ali2d_single_iter with that stage's window"""
+    from cryo_ralib_amd.mref import ali2d_base_gpu
+    nx, ou, n = 64, 25, 160
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 2, 2, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    al = RefFreeAligner(parts, ou, "2 1", "-1", "1 0.5")
+    assert al.stages == [(2.0, 2.0, 1.0), (1.0, 1.0, 0.5)]
+    assert al.engine.num_shifts == 25
+    for stage in (0, 1):
+        al.set_stage(stage)
+        x, y, t = al.stages[stage]
+        assert al.engine.num_shifts == (2 * int(x / t) + 1) ** 2
+        for it in range(2):
+            prev = al.params().copy()
+            d = al.state.cpu().numpy().copy()
+            al.iterate(0, None)
+            al.engine.sync()
+            _, cref = orc.prepare_refs(al.tavg.cpu().numpy(), None, rg)
+            params = np.zeros((n, 6), np.float32)
+            params[:, 0] = prev["alpha"]; params[:, 1] = prev["sx"]; params[:, 2] = prev["sy"]; params[:, 3] = prev["mirror"]
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, x, y, t, (0, 0), d, params, nthreads=16)
+            flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02, alpha_outlier_frac=0.03)
+            _log_flips("stage %d it %d" % (stage, it), n, flips)
+    al.close()
+    # the driver walks the stages itself
+    seen = []
+    ali2d_base_gpu(parts, ou, [2, 1], [2, 1], [1, 0.5], maxit=2, on_iteration=lambda i, a, c: seen.append((i, a.stage, a.engine.num_shifts)))
+    assert seen == [(1, 0, 25), (2, 0, 25), (3, 1, 25), (4, 1, 25)]
+
+
+def test_auto_stop_at_maxit_zero():
+    """maxit = 0: ten iterations at most, and a stage ends with the first iteration whose criterion falls below the
+    best one so far (test_reffree_gpu_align.py:224-229, :392-396, :422-432)"""
+    from cryo_ralib_amd.mref import ali2d_base_gpu
+    nx, ou, xr, n = 32, 12, 2, 150
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    crit = []
+    _, _, criteria = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=0, on_iteration=lambda i, a, c: crit.append(c))
+    assert crit == criteria and 1 <= len(crit) <= 10
+    best = -1.0e22
+    for i, c in enumerate(crit):
+        if c < best:
+            assert i == len(crit) - 1, "went on after the criterion decreased"
+        else:
+            best = c
+    if len(crit) < 10:
+        assert crit[-1] < max(crit[:-1])
+    # a fixed count ignores the criterion
+    _, _, c5 = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=5)
+    assert len(c5) == 5
