@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
     "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
     "ref_free_alignment_2D_filter_references", "ra_isac_get_references", "ra_legacy_bytes",
-    "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_set_nomirror",
+    "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_set_nomirror", "ra_set_mask",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
@@ -93,6 +93,7 @@ def load_library(path=None):
     L.ra_lcirc.argtypes = [vp]
     L.ra_search_path.argtypes = [vp]
     L.ra_set_nomirror.argtypes = [vp, ctypes.c_int]
+    L.ra_set_mask.argtypes = [vp, vp]
     L.ra_reset_shifts.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     L.ra_set_references.argtypes = [vp, vp]
     L.ra_get_prepared_references.argtypes = [vp, vp]
@@ -244,6 +245,11 @@ class Engine:
     # -- API
     def reset_shifts(self, xrng, yrng, step):
         _check(self.lib.ra_reset_shifts(self.handle, xrng, yrng, step), "ra_reset_shifts")
+
+    def set_mask(self, mask):
+        """user mask [nx][nx] (CUDA tensor) in place of model_circle(last_ring)"""
+        assert mask.shape == (self.nx, self.nx)
+        _check(self.lib.ra_set_mask(self.handle, self._ptr(mask, self.torch.float32)), "ra_set_mask")
 
     def set_nomirror(self, flag):
         """--nomirror: search the straight orientation only (ormq -> Util.Crosrng_ns)"""

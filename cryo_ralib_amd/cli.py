@@ -11,8 +11,9 @@ reference's `mpirun -np N`; particles are sharded with MPI_start_end, class sums
 RCCL all-reduce.  Outputs: per iteration `aqm%03d.<ext>` class averages (reference :519,564), at the end
 `params.txt` rows `idx angle_psi shift_x shift_y mirror class` / `initial2Dparams.txt` rows
 `alpha sx sy mirror`.  --function=ref_ali2d (the default) runs the FSC-fitted tangent filter and the
-centring on the device; any other name is rejected.  Flags the engine does not implement (--CTF, a
-mask file, the --MPI CPU path) are accepted and reported, not silently ignored.
+centring on the device; any other name is rejected.  An optional mask file replaces model_circle(ou); with an
+.hdf input stack the parameters are also written back into its headers (EMAN.xform.align2d / assign / ID).
+Flags the engine does not implement (--CTF, the --MPI CPU path) are accepted and reported, not silently ignored.
 """
 import argparse
 import os
@@ -36,6 +37,7 @@ def _common(p):
     p.add_argument("--MPI", action="store_true")
     p.add_argument("--EQ", action="store_true")
     p.add_argument("--ext", default="hdf", help="format of the written stacks: hdf (EMAN2 MDF, as the reference) | mrcs | npy")
+    p.add_argument("--no_header_writeback", action="store_true", help="do not write xform.align2d / assign / ID into an HDF input stack")
 
 
 def _first(v):
@@ -80,16 +82,16 @@ def main_mref(argv=None):
     rank, local, world = _setup(args)
     from . import stackio, dist as rdist
     from .mref import MrefAligner
-    if args.maskfile and rank == 0:
-        print("warning: mask files are not supported, using model_circle(ou)", file=sys.stderr)
-    data = stackio.read_stack(args.stack)
-    refs = stackio.read_stack(args.refstack)
-    total, nx = data.shape[0], data.shape[-1]
-    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2            # last_ring default (:311)
+    total = stackio.stack_size(args.stack)
     lo, hi = rdist.shard_range(total, world, rank)
+    data = stackio.read_stack(args.stack, lo, hi)                # every rank reads its own slice only (:1358-1375)
+    refs = stackio.read_stack(args.refstack)
+    nx = data.shape[-1]
+    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2            # last_ring default (:311)
+    mask = stackio.read_stack(args.maskfile)[0] if args.maskfile else None      # get_image(maskfile) (:317-319)
     xr, yr, ts = _first(args.xr), _first(args.yr), _first(args.ts)
-    al = MrefAligner(data[lo:hi], refs, ou, xr, yr, ts, int(args.ir), int(args.rs), device=local, index0=lo,
-                     total_nima=total, rand_seed=args.rand_seed, preprocess=True)
+    al = MrefAligner(data, refs, ou, xr, yr, ts, int(args.ir), int(args.rs), device=local, index0=lo,
+                     total_nima=total, rand_seed=args.rand_seed, preprocess=True, mask=mask)
     if rank == 0:
         os.makedirs(args.outdir, exist_ok=True)
     maxit = int(args.maxit) if int(args.maxit) > 0 else 10
@@ -113,6 +115,13 @@ def main_mref(argv=None):
     if rank == 0:
         stackio.write_text_rows(os.path.join(args.outdir, "params.txt"), rows)
         stackio.write_stack(os.path.join(args.outdir, "multi_ref.%s" % args.ext), al.refs.cpu().numpy())
+        if os.path.splitext(args.stack)[1].lower() in (".hdf", ".h5") and not args.no_header_writeback:
+            # xform.align2d / assign / ID into the stack's headers (set_params2D :588; output_attr / write_attr of
+            # test_mref_cheng_yu_bdb_cuda.py:114-203)
+            from . import mdfio
+            rows.sort(key=lambda x: x[0])
+            mdfio.write_alignment_headers(args.stack, args.stack, [x[1:5] for x in rows], assign=[x[5] for x in rows],
+                                          ids=[x[0] for x in rows])
     al.close()
     return 0
 
@@ -130,13 +139,15 @@ def main_reffree(argv=None):
     rank, local, world = _setup(args)
     from . import stackio, dist as rdist
     from .mref import RefFreeAligner
-    data = stackio.read_stack(args.stack)
-    total, nx = data.shape[0], data.shape[-1]
-    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2
+    total = stackio.stack_size(args.stack)
     lo, hi = rdist.shard_range(total, world, rank)
+    data = stackio.read_stack(args.stack, lo, hi)
+    nx = data.shape[-1]
+    ou = int(args.ou) if args.ou > 0 else nx // 2 - 2
+    mask = stackio.read_stack(args.maskfile)[0] if args.maskfile else None
     # "--xr '4 2 1 1' --ts '2 1 0.5 0.25'": one stage per entry, --maxit iterations each; --maxit 0 = 10 with auto-stop
-    al = RefFreeAligner(data[lo:hi], ou, args.xr, args.yr, args.ts, int(args.ir), int(args.rs), device=local, index0=lo,
-                        total_nima=total, nomirror=args.nomirror)
+    al = RefFreeAligner(data, ou, args.xr, args.yr, args.ts, int(args.ir), int(args.rs), device=local, index0=lo,
+                        total_nima=total, nomirror=args.nomirror, mask=mask)
     max_iter, auto_stop = (10, True) if int(args.maxit) == 0 else (int(args.maxit), False)
     a0, it = -1.0e22, 0
     for n_step in range(len(al.stages)):
@@ -162,5 +173,8 @@ def main_reffree(argv=None):
         os.makedirs(args.outdir, exist_ok=True)
         stackio.write_text_rows(os.path.join(args.outdir, "initial2Dparams.txt"), rows)
         stackio.write_stack(os.path.join(args.outdir, "aqfinal.%s" % args.ext), al.tavg.cpu().numpy())
+        if os.path.splitext(args.stack)[1].lower() in (".hdf", ".h5") and not args.no_header_writeback:
+            from . import mdfio        # set_params2D(img, [angle, shift_x, shift_y, mirror, 1.0], "xform.align2d") (test_reffree.py:453)
+            mdfio.write_alignment_headers(args.stack, args.stack, rows)
     al.close()
     return 0

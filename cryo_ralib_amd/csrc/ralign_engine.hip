@@ -559,6 +559,13 @@ extern "C" int ra_set_stream(ra_engine *e, void *hip_stream)
     return RA_OK;
 }
 
+extern "C" int ra_set_mask(ra_engine *e, const float *d_mask)
+{
+    if (!e || !d_mask) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    RA_HIP(hipMemcpyAsync((void *)e->dg.mask, d_mask, (size_t)e->geo.nx * e->geo.nx * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return RA_OK;
+}
+
 extern "C" int ra_set_nomirror(ra_engine *e, int flag)
 {
     if (!e) return RA_ERR_ARG;

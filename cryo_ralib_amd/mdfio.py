@@ -221,9 +221,19 @@ class _File:
         return out
 
 
-def read_mdf_stack(path, with_attrs=False):
+def mdf_image_count(path):
+    """number of images of an EMAN2 MDF stack without touching the pixel data"""
+    buf = np.memmap(path, dtype=np.uint8, mode="r")
+    f = _File(memoryview(buf))
+    imgs = f.children(f.children(f.children(f.root)["MDF"])["images"])
+    return sum(1 for k in imgs if k.isdigit())
+
+
+def read_mdf_stack(path, with_attrs=False, first=0, last=None):
     """float32 [n][ny][nx] (images in numerical order of their group names); optionally the per-image
-    attribute dictionaries (EMAN.* header items)"""
+    attribute dictionaries (EMAN.* header items).  first / last select images [first, last) -- the file is
+    memory-mapped and only the selected datasets are read (each rank reads its own slice,
+    test_mref_gpu_align.py:1358-1375)."""
     buf = np.memmap(path, dtype=np.uint8, mode="r")
     f = _File(memoryview(buf))
     root = f.children(f.root)
@@ -234,6 +244,7 @@ def read_mdf_stack(path, with_attrs=False):
         raise HDF5FormatError("%s: no /MDF/images group" % path)
     imgs = f.children(mdf["images"])
     ids = sorted(int(k) for k in imgs if k.isdigit())
+    ids = ids[first:last]
     out, attrs = [], []
     for i in ids:
         g = f.children(imgs[str(i)])
@@ -294,10 +305,11 @@ class _Writer:
         raise ValueError(dt)
 
     def attribute(self, name, value):
+        """scalar or 1-D array attribute (EMAN2 stores a Transform, e.g. xform.align2d, as 12 floats)"""
         value = np.asarray(value)
         dt = np.dtype("<f4") if value.dtype.kind == "f" else np.dtype("<i4")
         nm = name.encode() + b"\0"
-        ty, sp = self.datatype(dt), self.dataspace([])
+        ty, sp = self.datatype(dt), self.dataspace(list(value.shape))
         pad = lambda x: x + bytes((-len(x)) % 8)
         body = struct.pack("<BBHHH", 1, 0, len(nm), len(ty), len(sp)) + pad(nm) + pad(ty) + pad(sp) + value.astype(dt).tobytes()
         return self._msg(0x000C, body)
@@ -367,8 +379,50 @@ class _Writer:
         return ohdr, True, bt, heap_hdr
 
 
+def transform2d_matrix(alpha, sx, sy, mirror, scale=1.0):
+    """the 12 floats (3 x 4, row-major) EMAN2 keeps for Transform({"type": "2d", alpha, tx, ty, mirror, scale}):
+    x' = M R(alpha) x + t with R(alpha) = [[cos, sin], [-sin, cos]] and the mirror an x-flip of the rotated
+    coordinates (pinned by the combine_params2 / inverse_transform2 known answers of
+    cuda/EMAN2_test.ipynb cells 23-25 as far as rotation and translation go)"""
+    a = np.deg2rad(float(alpha))
+    c, s = np.cos(a) * scale, np.sin(a) * scale
+    m = -1.0 if mirror else 1.0
+    return np.array([m * c, m * s, 0.0, sx, -s, c, 0.0, sy, 0.0, 0.0, scale, 0.0], np.float32)
+
+
+def params_from_matrix(m12):
+    """(alpha, sx, sy, mirror) of a 2-D transform stored as 12 floats (inverse of transform2d_matrix)"""
+    m = np.asarray(m12, np.float64).reshape(3, 4)
+    mirror = int(m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0] < 0)
+    sgn = -1.0 if mirror else 1.0
+    alpha = np.rad2deg(np.arctan2(sgn * m[0, 1], sgn * m[0, 0])) % 360.0
+    return float(alpha), float(m[0, 3]), float(m[1, 3]), mirror
+
+
+def write_alignment_headers(src, dst, params, assign=None, ids=None):
+    """header write-back of the reference's drivers (test_mref_cheng_yu_bdb_cuda.py:114-203: output_attr /
+    write_attr with list_params ["xform.align2d", "assign", "ID"]; set_params2D at test_mref_gpu_align.py:588):
+    copy stack `src` to `dst` (may be the same path) with, per image, EMAN.xform.align2d (12 floats), EMAN.assign
+    and EMAN.ID next to the attributes the stack already has.  params: rows (alpha, sx, sy, mirror)."""
+    arr, attrs = read_mdf_stack(src, with_attrs=True)
+    n = arr.shape[0]
+    assert len(params) == n
+    out = []
+    for i in range(n):
+        a = {k[5:]: v for k, v in attrs[i].items() if k.startswith("EMAN.") and k[5:] not in ("nx", "ny", "nz") and np.ndim(v) <= 1}
+        a["xform.align2d"] = transform2d_matrix(params[i][0], params[i][1], params[i][2], int(params[i][3]))
+        if assign is not None:
+            a["assign"] = np.int32(assign[i])
+        a["ID"] = np.int32(ids[i] if ids is not None else i)
+        out.append(a)
+    tmp = dst + ".tmp"
+    write_mdf_stack(tmp, np.array(arr), out)
+    import os
+    os.replace(tmp, dst)
+
+
 def write_mdf_stack(path, arr, extra_attrs=None):
-    """write float32 images [n][ny][nx] as an EMAN2 MDF stack; extra_attrs: optional list of {name: int | float}
+    """write float32 images [n][ny][nx] as an EMAN2 MDF stack; extra_attrs: optional list of {name: int | float | 1-D array}
     per image, written as EMAN.<name> next to EMAN.nx / ny / nz"""
     arr = np.asarray(arr, np.float32)
     if arr.ndim == 2:

@@ -22,7 +22,7 @@ from . import api, dist, geometry
 
 class MrefAligner:
     def __init__(self, particles, refs, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0):
+                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None):
         """particles: [n][nx][nx] float32 numpy array or CUDA tensor holding THIS rank's shard;
         refs: [R][nx][nx]; index0 = global index of particles[0] (even/odd split)."""
         self.dev = torch.device("cuda", device)
@@ -38,7 +38,11 @@ class MrefAligner:
         self.engine = api.Engine(self.nx, self.ou, self.xr, self.yr, self.ts, self.nref, api.RA_MODE_MREF,
                                  first_ring=ir, ring_skip=rs, device=device, chunk=chunk)
         self.engine.use_current_stream()
-        self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        if mask is None:        # "mask = model_circle(last_ring, nx, nx)" unless a mask file was given (:317-321)
+            self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        else:
+            self.mask = self._to_dev(mask).reshape(self.nx, self.nx)
+            self.engine.set_mask(self.mask)
         self.state = self.engine.new_state(self.n)
         self.result = self.engine.new_result(self.n)
         self.buf = dist.ClassSumBuffer(self.nref, self.nx, self.dev)
@@ -182,7 +186,7 @@ class RefFreeAligner:
     The engine is sized once for the stage with the most search offsets and the widest range."""
 
     def __init__(self, particles, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 preprocess=False, chunk=0, nomirror=False):
+                 preprocess=False, chunk=0, nomirror=False, mask=None):
         self.dev = torch.device("cuda", device)
         if isinstance(particles, np.ndarray):
             particles = torch.from_numpy(np.ascontiguousarray(particles, np.float32))
@@ -209,7 +213,13 @@ class RefFreeAligner:
         self.set_stage(0)
         if nomirror:
             self.engine.set_nomirror(True)
-        self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        if mask is None:
+            self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
+        else:
+            if isinstance(mask, np.ndarray):
+                mask = torch.from_numpy(np.ascontiguousarray(mask, np.float32))
+            self.mask = mask.to(self.dev, dtype=torch.float32).reshape(self.nx, self.nx).contiguous()
+            self.engine.set_mask(self.mask)
         if preprocess:
             self.engine.normalize_particles(self.particles)
         self.state = self.engine.new_state(self.n)

@@ -17,18 +17,20 @@ import struct
 import numpy as np
 
 
-def _read_mrc(path):
+def _read_mrc(path, first=0, last=None):
     with open(path, "rb") as f:
         hdr = f.read(1024)
         nx, ny, nz, mode = struct.unpack("<4i", hdr[:16])
         nsymbt = struct.unpack("<i", hdr[92:96])[0]
         if mode != 2:
             raise ValueError("%s: only MRC mode 2 (float32) stacks are supported, got mode %d" % (path, mode))
-        f.seek(1024 + nsymbt)
-        data = np.fromfile(f, dtype="<f4", count=nx * ny * nz)
-    if data.size != nx * ny * nz:
+        first = max(0, first); last = nz if last is None else min(last, nz)
+        cnt = max(0, last - first)
+        f.seek(1024 + nsymbt + 4 * nx * ny * first)
+        data = np.fromfile(f, dtype="<f4", count=nx * ny * cnt)
+    if data.size != nx * ny * cnt:
         raise ValueError("%s: truncated MRC file" % path)
-    return data.reshape(nz, ny, nx).astype(np.float32)
+    return data.reshape(cnt, ny, nx).astype(np.float32)
 
 
 def _write_mrc(path, arr):
@@ -51,9 +53,9 @@ def _write_mrc(path, arr):
         arr.tofile(f)
 
 
-def _read_hdf(path):
+def _read_hdf(path, first=0, last=None):
     from . import mdfio
-    return mdfio.read_mdf_stack(path)
+    return mdfio.read_mdf_stack(path, first=first, last=last)
 
 
 def _write_hdf(path, arr):
@@ -61,17 +63,34 @@ def _write_hdf(path, arr):
     mdfio.write_mdf_stack(path, arr)
 
 
-def read_stack(path):
-    """float32 [n][ny][nx]"""
+def stack_size(path):
+    """number of images without reading the pixel data"""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
-        a = np.load(path)
-        a = a[None] if a.ndim == 2 else a
-        return np.ascontiguousarray(a, np.float32)
+        a = np.load(path, mmap_mode="r")
+        return 1 if a.ndim == 2 else a.shape[0]
     if ext in (".mrc", ".mrcs", ".st"):
-        return _read_mrc(path)
+        with open(path, "rb") as f:
+            nx, ny, nz = np.frombuffer(f.read(12), "<i4")
+        return int(nz)
     if ext in (".hdf", ".h5"):
-        return _read_hdf(path)
+        from . import mdfio
+        return mdfio.mdf_image_count(path)
+    raise ValueError("unsupported stack format: %s" % path)
+
+
+def read_stack(path, first=0, last=None):
+    """float32 [n][ny][nx]; first / last select images [first, last): a rank reads only its MPI_start_end slice
+    (test_mref_gpu_align.py:1358-1375), through a memory map, not the whole file"""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        a = np.load(path, mmap_mode="r")
+        a = a[None] if a.ndim == 2 else a
+        return np.ascontiguousarray(a[first:last], np.float32)
+    if ext in (".mrc", ".mrcs", ".st"):
+        return _read_mrc(path, first, last)
+    if ext in (".hdf", ".h5"):
+        return _read_hdf(path, first, last)
     raise ValueError("unsupported stack format: %s" % path)
 
 

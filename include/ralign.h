@@ -148,6 +148,10 @@ int  ra_search_path(const ra_engine *e);
  * offsets may not grow beyond what ra_create sized */
 int  ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step);
 
+/* a user mask [nx][nx] (device) instead of model_circle(last_ring) for normalize.mask and the masked statistics
+ * (the drivers' optional maskfile argument, test_mref_gpu_align.py:317-321): pixels > 0.5 are inside */
+int  ra_set_mask(ra_engine *e, const float *d_mask);
+
 /* --nomirror (test_reffree_gpu_align.py:921, passed to ali2d_single_iter -> ormq): only the straight half of
  * Crosrng_ms takes part in the search (Util.Crosrng_ns); flag != 0 switches it on for subsequent ra_align calls */
 int  ra_set_nomirror(ra_engine *e, int flag);

@@ -315,3 +315,38 @@ def test_bench_gpus_flag_never_runs_a_single_rank_silently():
     env["WORLD_SIZE"] = "4"; env["RANK"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "launcher started 4 ranks" in (r.stderr + r.stdout)
+
+
+def test_header_write_back_and_slice_reads(tmp_path):
+    """xform.align2d / assign / ID land in the MDF headers (test_mref_cheng_yu_bdb_cuda.py:114-203) and a rank can
+    read its MPI_start_end slice without the rest of the file"""
+    from cryo_ralib_amd import mdfio, stackio
+    rng = np.random.default_rng(5)
+    imgs = rng.normal(size=(23, 16, 16)).astype(np.float32)
+    path = str(tmp_path / "stack.hdf")
+    mdfio.write_mdf_stack(path, imgs, [{"ptcl_source_coord": np.int32(i * 7)} for i in range(23)])
+    assert stackio.stack_size(path) == 23
+    for lo, hi in [(0, 23), (5, 11), (22, 23), (7, 8)]:
+        np.testing.assert_array_equal(stackio.read_stack(path, lo, hi), imgs[lo:hi])
+    params = [(float(rng.uniform(0, 360)), float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), int(rng.integers(0, 2))) for _ in range(23)]
+    assign = list(rng.integers(0, 5, 23))
+    mdfio.write_alignment_headers(path, path, params, assign=assign, ids=list(range(100, 123)))
+    arr, attrs = mdfio.read_mdf_stack(path, with_attrs=True)
+    np.testing.assert_array_equal(arr, imgs)
+    for i in range(23):
+        a = attrs[i]
+        assert int(a["EMAN.assign"]) == assign[i] and int(a["EMAN.ID"]) == 100 + i and int(a["EMAN.ptcl_source_coord"]) == 7 * i
+        m = a["EMAN.xform.align2d"]
+        assert m.shape == (12,)
+        al, sx, sy, mir = mdfio.params_from_matrix(m)
+        assert mir == params[i][3] and abs(sx - params[i][1]) < 1e-5 and abs(sy - params[i][2]) < 1e-5
+        assert abs(((al - params[i][0]) + 180) % 360 - 180) < 1e-4
+    # the matrix follows the transform the oracle's parameter algebra uses: R(alpha) = [[c, s], [-s, c]]
+    m = mdfio.transform2d_matrix(30.0, 1.5, -2.0, 0).reshape(3, 4)
+    np.testing.assert_allclose(m[:2, :2], [[np.cos(np.pi / 6), 0.5], [-0.5, np.cos(np.pi / 6)]], atol=1e-6)
+    # other formats slice as well
+    mrc = str(tmp_path / "s.mrcs"); npy = str(tmp_path / "s.npy")
+    stackio.write_stack(mrc, imgs); stackio.write_stack(npy, imgs)
+    for pth in (mrc, npy):
+        assert stackio.stack_size(pth) == 23
+        np.testing.assert_array_equal(stackio.read_stack(pth, 3, 9), imgs[3:9])
