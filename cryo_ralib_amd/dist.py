@@ -55,16 +55,31 @@ class ClassSumBuffer:
         self.counts_f = self.flat[self.nsum:self.nsum + nref]
         self.extra_f = self.flat[self.nsum + nref:]
         self.counts_i = torch.zeros(nref, dtype=torch.int32, device=device)
+        self._gather = None
 
     def zero_(self):
         self.flat.zero_()
         self.counts_i.zero_()
 
     def all_reduce(self):
-        """sum over ranks; afterwards counts_i holds the global member counts on every rank."""
+        """sum over ranks; afterwards counts_i holds the global member counts on every rank.
+
+        Default ("ordered"): all-gather the per-rank buffers (648 KB each at R = 10 / 90^2) and add them in rank order,
+        ((S0 + S1) + S2) + ... -- every rank performs the same additions in the same order, so the result is bitwise
+        identical on all ranks and does not depend on which algorithm (ring, tree, direct) RCCL picks for the message
+        size or on the xGMI topology.  RALIGN_ORDERED_REDUCE=0 selects a plain RCCL all-reduce (sum)."""
         self.counts_f.copy_(self.counts_i.to(torch.float32))
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            world = dist.get_world_size()
+            if os.environ.get("RALIGN_ORDERED_REDUCE", "1") != "0" and world <= 64:
+                if self._gather is None or self._gather.shape[0] != world:
+                    self._gather = torch.empty((world,) + self.flat.shape, dtype=self.flat.dtype, device=self.flat.device)
+                dist.all_gather_into_tensor(self._gather.view(-1), self.flat)
+                self.flat.copy_(self._gather[0])
+                for r in range(1, world):
+                    self.flat.add_(self._gather[r])
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.counts_i.copy_(self.counts_f.round().to(torch.int32))
         return self
 

@@ -56,3 +56,36 @@ def test_class_sum_allreduce_world2(tmp_path):
         np.testing.assert_array_equal(o["counts"], cnt)
         assert o["extra"][0] == total and o["t"] == 2.0 and o["s"] == 2.0
     np.testing.assert_array_equal(outs[0]["sums"], outs[1]["sums"])      # every rank holds identical sums
+
+
+def _worker_ordered(rank, world, port, out_dir, ordered):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), RALIGN_ORDERED_REDUCE="1" if ordered else "0")
+    from cryo_ralib_amd import dist as rdist
+    rdist.init_from_env("gloo")
+    buf = rdist.ClassSumBuffer(2, 6, torch.device("cpu"))
+    g = torch.Generator().manual_seed(77 + rank)
+    buf.flat[:buf.nsum] = torch.randn(buf.nsum, generator=g) * (10.0 ** rank)      # magnitudes that make the order matter
+    buf.counts_i[:] = torch.tensor([rank + 1, 2 * rank])
+    buf.all_reduce()
+    np.savez(os.path.join(out_dir, "o%d_%d.npz" % (int(ordered), rank)), flat=buf.flat.numpy(), counts=buf.counts_i.numpy())
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_ordered_reduction_is_rank_order_sum_on_every_rank(tmp_path):
+    """the default cross-rank reduction adds the per-rank class sums in rank order, ((S0 + S1) + S2): bitwise the
+    same on every rank and independent of the collective's algorithm"""
+    world = 3
+    port = 29900 + (os.getpid() % 400)
+    mp.spawn(_worker_ordered, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    parts = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(77 + r)
+        parts.append(torch.randn(2 * 2 * 6 * 6, generator=g) * (10.0 ** r))
+    want = ((parts[0] + parts[1]) + parts[2]).numpy()
+    for r in range(world):
+        o = np.load(tmp_path / ("o1_%d.npz" % r))
+        np.testing.assert_array_equal(o["flat"][:want.size], want)
+        np.testing.assert_array_equal(o["counts"], [6, 6])
