@@ -71,15 +71,20 @@ class ClassSumBuffer:
         self.counts_f.copy_(self.counts_i.to(torch.float32))
         if dist.is_initialized() and dist.get_world_size() > 1:
             world = dist.get_world_size()
+            # gloo rehearsal of several ranks on one GPU (RALIGN_DIST_BACKEND=gloo): the collective runs on a host copy
+            staged = self.flat.is_cuda and dist.get_backend() == "gloo"
+            work = self.flat.cpu() if staged else self.flat
             if os.environ.get("RALIGN_ORDERED_REDUCE", "1") != "0" and world <= 64:
-                if self._gather is None or self._gather.shape[0] != world:
-                    self._gather = torch.empty((world,) + self.flat.shape, dtype=self.flat.dtype, device=self.flat.device)
-                dist.all_gather_into_tensor(self._gather.view(-1), self.flat)
-                self.flat.copy_(self._gather[0])
+                if self._gather is None or self._gather.shape[0] != world or self._gather.device != work.device:
+                    self._gather = torch.empty((world,) + work.shape, dtype=work.dtype, device=work.device)
+                dist.all_gather_into_tensor(self._gather.view(-1), work)
+                work.copy_(self._gather[0])
                 for r in range(1, world):
-                    self.flat.add_(self._gather[r])
+                    work.add_(self._gather[r])
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                dist.all_reduce(work, op=dist.ReduceOp.SUM)
+            if staged:
+                self.flat.copy_(work)
         self.counts_i.copy_(self.counts_f.round().to(torch.int32))
         return self
 

@@ -12,13 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir, nx, ou, nref, xr, n):
+def _worker(rank, world, port, out_dir, nx, ou, nref, xr, n, backend=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from cryo_ralib_amd import dist as rdist, synth
     from cryo_ralib_amd.mref import MrefAligner
-    r, local, w = rdist.init_from_env()          # nccl == RCCL
+    r, local, w = rdist.init_from_env(backend)          # default: nccl == RCCL
+    local = local % torch.cuda.device_count()
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5)
     lo, hi = rdist.shard_range(n, w, r)
@@ -35,14 +36,17 @@ def _worker(rank, world, port, out_dir, nx, ou, nref, xr, n):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_rccl_class_sum_exchange(tmp_path):
-    if torch.cuda.device_count() < 2:
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_class_sum_exchange(tmp_path, backend):
+    """backend nccl = RCCL over xGMI (needs two GPUs); gloo = the same two ranks rehearsed on one GPU, the collective
+    staged through host memory"""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU node)")
     from cryo_ralib_amd import synth
     from cryo_ralib_amd.mref import MrefAligner
     nx, ou, nref, xr, n = 90, 36, 6, 3, 400
-    port = 29700 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), nx, ou, nref, xr, n), nprocs=2, join=True)
+    port = 29700 + (os.getpid() % 200) + (0 if backend == "nccl" else 200)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), nx, ou, nref, xr, n, backend), nprocs=2, join=True)
     a, b = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
     np.testing.assert_array_equal(a["sums"], b["sums"])
     np.testing.assert_array_equal(a["counts"], b["counts"])
