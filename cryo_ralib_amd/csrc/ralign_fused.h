@@ -165,6 +165,75 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
     }
 }
 
+// contraction of one pass for one wave: NH live reference pairs rp0 .. rp0 + NH - 1 of bin group xm, both offset pairs;
+// unit (h, op) accumulates in acc[2 h + op]
+template <int NRPW, int NH>
+__device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f, const float *bufs, const int *goff_s,
+                                            const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW])
+{
+    const int xb = ln >> 2, xj = ln & 3;
+    const int nq = f.grp_nq[xm];
+    const float *bp = Bf + f.grp_boff[xm] + ln * 4;
+    // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
+    const char *abase = reinterpret_cast<const char *>(bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
+    const int a1off = 8 * g.sbuf;
+    const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
+    float4 bA[NH], bB[NH];
+    float aA[8], aB[8];
+    auto load_b = [&](int rq, float4 (&b)[NH]) {
+#pragma unroll
+        for (int h = 0; h < NH; h++)      // a pair beyond the last one re-reads the last: its units are never stored
+            b[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : (min(rp0 + h, f.nrp - 1) * nq + rq) * 256));
+    };
+    auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
+        if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
+        a[0] = *reinterpret_cast<const float *>(abase + o.x); a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off);
+        a[2] = *reinterpret_cast<const float *>(abase + o.y); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
+        a[4] = *reinterpret_cast<const float *>(abase + o.z); a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off);
+        a[6] = *reinterpret_cast<const float *>(abase + o.w); a[7] = *reinterpret_cast<const float *>(abase + o.w + a1off);
+    };
+    auto mul_rq = [&](const float (&a)[8], const float4 (&b)[NH]) {
+        if (RA_DBG(g, 128)) {        // profiling: operands stay live, no matrix instructions
+#pragma unroll
+            for (int c = 0; c < 8; c++) asm volatile("" :: "v"(a[c]));
+#pragma unroll
+            for (int h = 0; h < NH; h++) asm volatile("" :: "v"(b[h].x), "v"(b[h].y), "v"(b[h].z), "v"(b[h].w));
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
+                acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+            }
+    };
+    // modulo schedule over the ring quads: while quad rq is multiplied, the A operands of quad rq + 1 are on
+    // their way from LDS, its B operands from L2, and the ring offsets of quad rq + 2 from the LDS table
+    // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  In-situ
+    // measurements (scripts/fused_phases.sh): the phase is paced by the B stream through the vector memory
+    // path (283 KB per pass and CU at 64 B/clk) plus the matrix instructions; deeper prefetch does not help.
+    const int ql = nq - 1;
+    int4 oA = gq[0], oB = gq[min(1, ql)];
+    load_b(0, bA);
+    read_a(oA, aA);
+#pragma unroll 1
+    for (int rq = 0; rq < nq; rq += 2) {
+        load_b(min(rq + 1, ql), bB);
+        read_a(oB, aB);
+        oA = gq[min(rq + 2, ql)];
+        __builtin_amdgcn_sched_barrier(0);
+        mul_rq(aA, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(min(rq + 2, ql), bA);
+        read_a(oA, aA);
+        oB = gq[min(rq + 3, ql)];
+        __builtin_amdgcn_sched_barrier(0);
+        if (rq + 1 < nq) mul_rq(aB, bB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int N, int NRPW>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
@@ -229,14 +298,14 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     }
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
+    if (tid < 4) {                              // sampling centres of pass 0 (those of pass g + 1 are written at the end of pass g)
+        const int si = min((int)tid, g.nshift - 1);
+        red[16 + 2 * tid] = cxf + g.shift_x[si];
+        red[17 + 2 * tid] = cyf + g.shift_y[si];
+        red[7] = 0.f;
+    }
+    __syncthreads();
     for (int grp = 0; grp < ngroup; grp++) {
-        if (tid < 4) {
-            const int si = min(grp * 4 + tid, g.nshift - 1);
-            red[16 + 2 * tid] = cxf + g.shift_x[si];
-            red[17 + 2 * tid] = cyf + g.shift_y[si];
-            red[7] = 0.f;
-        }
-        __syncthreads();
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
         if (!RA_DBG(g, 16)) {
 #pragma unroll 1
@@ -281,66 +350,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
 #pragma unroll
         for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
-            const int nq = f.grp_nq[xm];
-            const float *bp = Bf + f.grp_boff[xm] + ln * 4;
-            // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
-            const char *abase = reinterpret_cast<const char *>(bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
-            const int a1off = 8 * g.sbuf;
-            const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
-            float4 bA[NRPW], bB[NRPW];
-            float aA[8], aB[8];
-            auto load_b = [&](int rq, float4 (&b)[NRPW]) {
-#pragma unroll
-                for (int h = 0; h < NRPW; h++)      // a pair beyond the last one re-reads the last: its units are never stored
-                    b[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : (min(rp0 + h, f.nrp - 1) * nq + rq) * 256));
-            };
-            auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
-                if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
-                a[0] = *reinterpret_cast<const float *>(abase + o.x); a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off);
-                a[2] = *reinterpret_cast<const float *>(abase + o.y); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
-                a[4] = *reinterpret_cast<const float *>(abase + o.z); a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off);
-                a[6] = *reinterpret_cast<const float *>(abase + o.w); a[7] = *reinterpret_cast<const float *>(abase + o.w + a1off);
-            };
-            auto mul_rq = [&](const float (&a)[8], const float4 (&b)[NRPW]) {
-                if (RA_DBG(g, 128)) {        // profiling: operands stay live, no matrix instructions
-#pragma unroll
-                    for (int c = 0; c < 8; c++) asm volatile("" :: "v"(a[c]));
-#pragma unroll
-                    for (int h = 0; h < NRPW; h++) asm volatile("" :: "v"(b[h].x), "v"(b[h].y), "v"(b[h].z), "v"(b[h].w));
-                    return;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-#pragma unroll
-                    for (int h = 0; h < NRPW; h++) {
-                        acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
-                        acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
-                    }
-            };
-            // modulo schedule over the ring quads: while quad rq is multiplied, the A operands of quad rq + 1 are on
-            // their way from LDS, its B operands from L2, and the ring offsets of quad rq + 2 from the LDS table
-            // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  In-situ
-            // measurements (scripts/fused_phases.sh): the phase is paced by the B stream through the vector memory
-            // path (283 KB per pass and CU at 64 B/clk) plus the matrix instructions; deeper prefetch does not help.
-            const int ql = nq - 1;
-            int4 oA = gq[0], oB = gq[min(1, ql)];
-            load_b(0, bA);
-            read_a(oA, aA);
-#pragma unroll 1
-            for (int rq = 0; rq < nq; rq += 2) {
-                load_b(min(rq + 1, ql), bB);
-                read_a(oB, aB);
-                oA = gq[min(rq + 2, ql)];
-                __builtin_amdgcn_sched_barrier(0);
-                mul_rq(aA, bA);
-                __builtin_amdgcn_sched_barrier(0);
-                load_b(min(rq + 2, ql), bA);
-                read_a(oA, aA);
-                oB = gq[min(rq + 3, ql)];
-                __builtin_amdgcn_sched_barrier(0);
-                if (rq + 1 < nq) mul_rq(aB, bB);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
+            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc);
+            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc);
         }
         __syncthreads();                       // every wave has finished reading the ring buffers
         // ---- CCF spectra -> LDS (over the ring buffers), inverse FFT, argmax: rounds of f.rz references
@@ -397,6 +409,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
             if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
             reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + grp * 4 + o)[wd] = word;
+        }
+        if (tid >= 64 && tid < 68 && grp + 1 < ngroup) {      // another wave than the one writing the records
+            const int t4 = tid - 64, si = min((grp + 1) * 4 + t4, g.nshift - 1);
+            red[16 + 2 * t4] = cxf + g.shift_x[si];
+            red[17 + 2 * t4] = cyf + g.shift_y[si];
+            red[7] = 0.f;
         }
         __syncthreads();
     }
