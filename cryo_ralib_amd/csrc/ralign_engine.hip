@@ -115,6 +115,14 @@ static bool fft_plan(int h, int &R1, int &R2)
     }
 }
 
+// the particle-resident kernel is planned for this engine (decided before the LDS layout, which differs slightly)
+static bool fused_wanted(const ra_engine *e)
+{
+    if (e->generic || e->cfg.nref > RF_MAXREF) return false;
+    if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
+    return e->geo.maxrin == 256 || e->geo.maxrin == 128;
+}
+
 static int build_device_geometry(ra_engine *e)
 {
     Geometry &g = e->geo;
@@ -130,7 +138,10 @@ static int build_device_geometry(ra_engine *e)
 #else
     d.dbg = 0;
 #endif
-    int sbuf = (g.lring + 31) / 32 * 32 + 8;    // == 8 (mod 32): the 4 offsets of an entry hit disjoint banks
+    // ring-buffer stride.  Kernel pair: == 8 (mod 32), the 4 offsets of an entry hit disjoint banks in the write-out gather.
+    // Fused kernel: == 16 (mod 32), the two offsets a 4x4x1 MFMA A operand reads (16 bins x Re/Im each) sit in disjoint
+    // halves of the 32 banks (RALIGN_SBUF_PAD overrides: experiments)
+    int sbuf = (g.lring + 31) / 32 * 32 + (getenv("RALIGN_SBUF_PAD") ? atoi(getenv("RALIGN_SBUF_PAD")) : (fused_wanted(e) ? 16 : 8));
     d.sbuf = sbuf;
     d.a_blk = g.LBP * 8 + 64;
     // classes of bins with equal ring-slot count
