@@ -219,16 +219,23 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=512):
     return out
 
 
-def committed_traffic(kernel_substr):
-    """HBM bytes per particle of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
-    gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); PMC counters cannot be read from inside this process."""
+def committed_traffic(kernel_substr, workload):
+    """HBM bytes per particle of the dominant kernel from the committed rocprofv3 --pmc passes of this workload
+    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; scripts/profile.sh); PMC counters cannot be
+    read from inside this process."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 pm = json.load(f)
+            wl = "mref"
+            for w in WORKLOADS:
+                if "--workload " + w in pm.get("bench_args", ""):
+                    wl = w
+            if wl != workload or not pm.get("particles_per_dispatch"):
+                continue
             for k, v in pm["kernels"].items():
-                if kernel_substr in k and "hbm_bytes_per_dispatch_corrected" in v:
+                if kernel_substr in k and "pack" not in k and "hbm_bytes_per_dispatch_corrected" in v:
                     return v["hbm_bytes_per_dispatch_corrected"] / pm["particles_per_dispatch"], os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
@@ -313,7 +320,7 @@ def main():
             k["frac"] = k["achieved_tflops"] / PEAK_F32_TFLOPS
         dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         kern_ms = sum(k["avg_launch_ms"] * k["launches"] for k in kernels.values())
-        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0])
+        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0], args.workload)
         whole = (polar_f + ccf_f) * total / world / dt / 1e12
         what = ("%s: %d synthetic %dx%d particles per GPU, %s, xr=yr=%g, ts=1, ou=%d; step = one %s iteration (search + rot_shift2D + "
                 "class sums + all-reduce + reference update with --function=%s)") % (

@@ -24,8 +24,11 @@ for k, e in acc.items():
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads (MI355X_MICROARCH.md, HBM section)
         e["hbm_bytes_per_dispatch_corrected"] = (2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
-out = {"_what": "rocprofv3 --pmc summaries (scripts/profile.sh, one counter group per pass): averages per dispatch; "
+bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
+out = {"bench_args": bench_args, "_what": "rocprofv3 --pmc summaries (scripts/profile.sh, one counter group per pass): averages per dispatch; "
                 "bench.py --steps 1 --warmup 0 --particles 14000 (7000 particles per dispatch of the hot kernels); "
                 "FETCH_SIZE / WRITE_SIZE in KB as reported", "particles_per_dispatch": 7000, "kernels": acc}
+if "largebox" in bench_args:
+    out["particles_per_dispatch"] = None
 json.dump(out, open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1)
 print("kernels:", list(acc))

@@ -19,7 +19,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
 done
 # condense on the box (the raw counter CSVs exceed what gpurun copies back) and drop the raw files
 mkdir -p $root/gpurun_out/profiles_$tag
-python3 $root/scripts/pmc_summary.py $tag $tag $root/gpurun_out/profiles_$tag
+python3 $root/scripts/pmc_summary.py $tag $tag $root/gpurun_out/profiles_$tag "$*"
 find $out -name "*counter_collection.csv" -delete
 find $out -name "*kernel_trace.csv" -delete
 echo done
