@@ -1156,3 +1156,24 @@ def test_auto_stop_at_maxit_zero():
     # a fixed count ignores the criterion
     _, _, c5 = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=5)
     assert len(c5) == 5
+
+
+@pytest.mark.parametrize("nref,nx,ou", [(13, 90, 36), (16, 90, 36), (12, 32, 12), (16, 48, 20)])
+def test_fused_kernel_with_two_spectra_rounds(nref, nx, ou):
+    """11 < nref <= 16: the accumulators of a pass feed two inverse-FFT rounds (the spectra of 4 offsets x nref references
+    do not fit the ring-buffer space at once); also the widest unit count per wave"""
+    xr, n = 2, 96
+    refs = synth.make_references(nref, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, 0.25, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == 1
+    r = api.Engine.result_to_numpy(res)
+    flips = compare_search(r, st.cpu().numpy(), params, infos, d)
+    _log_flips("nref=%d nx=%d" % (nref, nx), n, flips)
+    assert flips == 0
+    if nx >= 48:         # 12 references in a 32 x 32 box are too alike for the planted class to win every time (the oracle agrees)
+        assert (r["ref_id"] == truth["cls"]).all()
+    eng.close()
