@@ -64,6 +64,8 @@ struct ra_engine {
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
+    float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
+    float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic path)
     int g_nblk = 0, g_P = 0;
     size_t lds_gpolar = 0, lds_gccf = 0;
     // reference-update workspace (ralign_refine.h), allocated on first use
@@ -545,7 +547,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         ra_destroy(e);
         return rc;
     }
-    if (e->generic) e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
+    if (e->generic) {
+        e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
+        if ((rc = dev_alloc(e, &e->d_gstats, (size_t)wp.chunk * g.nshift_pad + 8, true)) ||
+            (rc = dev_alloc(e, &e->d_gcdc, (size_t)cfg->nref, true))) { ra_destroy(e); return rc; }
+    }
     if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
@@ -627,7 +633,7 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     const Geometry &g = e->geo;
     if (e->generic)
         hipLaunchKernelGGL(polar_generic_kernel<true>, dim3(e->cfg.nref), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
-                           d_refs, (const float *)nullptr, e->cfg.nref, e->d_refspec);
+                           d_refs, (const float *)nullptr, e->cfg.nref, e->d_refspec, (float2 *)nullptr);
     else
         hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(e->cfg.nref), dim3(256), e->lds_ref, e->stream, e->dg, d_refs,
                            e->cfg.nref, e->d_refspec);
@@ -643,6 +649,10 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
                                e->d_refspec, e->cfg.nref, e->d_Bf);
             RA_HIP(hipGetLastError());
         }
+    }
+    if (e->generic) {
+        hipLaunchKernelGGL(ref_dc_weights_kernel, dim3((e->cfg.nref + 63) / 64), dim3(64), 0, e->stream, e->dg, e->d_refspec, e->cfg.nref, e->d_gcdc);
+        RA_HIP(hipGetLastError());
     }
     e->refs_ready = true;
     return RA_OK;
@@ -743,7 +753,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (evp) RA_HIP(hipEventRecord(evp->first, sp));
         if (e->generic)
             hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
-                               part, (const float *)st, cn, Abuf);
+                               part, (const float *)st, cn, Abuf, e->d_gstats);
         else
             hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
@@ -752,7 +762,8 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
         if (e->generic)
             hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
-                               Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P);
+                               Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
+                               (const float *)e->d_gcdc);
         else
             hipLaunchKernelGGL(ccf, dim3(n_mtile), dim3(RA_CCF_THREADS), e->lds_ccf, sp, e->dg, Abuf, e->d_B, n_mtile,
                                e->nrtile, e->cfg.nref, Cbuf);
@@ -776,14 +787,15 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
     }
     if (e->generic)
         hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
-                           e->dg, d_particles, d_state, n, e->d_A);
+                           e->dg, d_particles, d_state, n, e->d_A, e->d_gstats);
     else
         hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);
     RA_HIP(hipGetLastError());
     float *d_out = nullptr;
     const size_t cnt = (size_t)n * g.nshift * g.lcirc;
     RA_HIP(hipMalloc((void **)&d_out, cnt * sizeof(float)));
-    hipLaunchKernelGGL(unpack_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, e->d_A, n, e->d_numr, d_out);
+    hipLaunchKernelGGL(unpack_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, e->d_A, n, e->d_numr, d_out,
+                       e->generic ? (const float2 *)e->d_gstats : (const float2 *)nullptr);
     hipError_t he = hipStreamSynchronize(e->stream);
     if (he == hipSuccess) he = hipMemcpy(h_out, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d_out);

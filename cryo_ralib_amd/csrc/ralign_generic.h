@@ -90,10 +90,13 @@ __device__ __forceinline__ float2 split_bin(const float2 *Z, int k, int h, float
 //   REFS = true : references; workgroup = reference, waves share the rings; output natural
 //                 padded ring layout [lring] (what ref_polar_fft_kernel writes).
 // (reference call sites: test_mref_gpu_align.py:1015-1016, 1043-1044)
+// Normalize_ring is linear, and at these sizes a second sampling pass for its statistics costs as much as the
+// transform itself: the particle spectra are written RAW, the statistics {avg, 1/sigma} of every (particle, offset) go to
+// `stats`, and the contraction applies them (DC bin: a -= avg * sum_r n_r C_r(0); peak records: * 1/sigma).
 template <bool REFS>
 __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g, const float *__restrict__ images,
                                                                       const float *__restrict__ state, int n,
-                                                                      float *__restrict__ out)
+                                                                      float *__restrict__ out, float2 *__restrict__ stats)
 {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,55 +137,51 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     const int slot = wave, si = min(grp * 4 + slot, g.nshift - 1);
     const float cx = ((float)g.cnx + w.sxi) + g.shift_x[si], cy = ((float)g.cnx + w.syi) + g.shift_y[si];
 
-    // Normalize_ring statistics (multi-reference mode): one sampling pass, ring partials added in ring order
-    float avg = 0.f, rsg = 1.f;
-    if (g.mode == RA_MODE_MREF) {
-        float av = 0.f, sq = 0.f;
-        for (int i = 0; i < g.nring; i++) {
-            const int4 ri = g.ringinfo[i];
-            const int nlen = ri.z, kc = ri.x - kRingPad * i;
-            const float wt = g.ringw[i];
-            float a = 0.f, q = 0.f;
-            for (int j = lane; j < nlen; j += 64) {
-                const float s = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
-                a += s * wt; q += s * s * wt;
-            }
-            av += wave_sum(a); sq += wave_sum(q);
-        }
-        const float nn = g.nn_weight;
-        avg = av / nn;
-        rsg = 1.0f / sqrtf((sq - av * av / nn) / nn);
-    }
-
+    // one sampling pass: ring FFTs and, in multi-reference mode, the Normalize_ring partial sums (added in ring order)
+    float av = 0.f, sq = 0.f;
     float *blk = out + ((size_t)p * ngroup + grp) * g.a_blk;
     for (int i = 0; i < g.nring; i++) {
         const int4 ri = g.ringinfo[i];
         const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
+        const float wt = g.ringw[i];
         float *xr = reinterpret_cast<float *>(bx);
-        for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+        float a = 0.f, q = 0.f;
+        for (int j = lane; j < nlen; j += 64) {
+            const float sv = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+            xr[j] = sv;
+            a += sv * wt; q += sv * sv * wt;
+        }
+        av += wave_sum(a); sq += wave_sum(q);
         wave_lds_sync();
         const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
-        const float dc = avg * (float)nlen;
         for (int k = lane; k <= h; k += 64) {
-            float2 X = split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]);
-            // Normalize_ring after the (linear) FFT: X_0 -= avg * n, then the common scale 1/sigma
-            if (k == 0) X.x -= dc;
-            X.x *= rsg; X.y *= rsg;
+            const float2 X = split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]);
             const int2 ap = g.ent_apos[g.bin_off[k] + (i - g.bin_first[k])];
             blk[ap.x + (2 * slot) * ap.y] = X.x;
             blk[ap.x + (2 * slot + 1) * ap.y] = X.y;
         }
         wave_lds_sync();
     }
+    if (lane == 0) {
+        float avg = 0.f, rsg = 1.f;
+        if (g.mode == RA_MODE_MREF) {
+            const float nn = g.nn_weight;
+            avg = av / nn;
+            rsg = 1.0f / sqrtf((sq - av * av / nn) / nn);
+        }
+        stats[((size_t)p * ngroup + grp) * 4 + slot] = make_float2(avg, rsg);
+    }
 }
 
 // Crosrng_ms for an 8 (particle-offset) x 8 (reference) tile at any maxrin; persistent workgroups
 // walk the m-tiles.  zscr: [gridDim.x][N][64] complex scratch (stays in L2 / Infinity Cache);
 // P = pairs transformed per LDS batch (power of two, 2 * P * (N + 1) complex fit the dynamic LDS).
+// stats [n_mtile * 8] {avg, 1/sigma} of every particle-offset (polar_generic_kernel), cdc [nref] = sum_r n_r C_r(0).
 __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
-                                                                      float2 *__restrict__ zscr, int P)
+                                                                      float2 *__restrict__ zscr, int P,
+                                                                      const float2 *__restrict__ stats, const float *__restrict__ cdc)
 {
     extern __shared__ __align__(16) float lds[];
     __shared__ CandT pc[64];
@@ -207,6 +206,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                 const float *Bt = B + (size_t)rtile * g.LBP * 16;
                 const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);      // offset-in-tile * 8 + reference slot
                 const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
+                // Normalize_ring mean of this lane's particle-offset times the DC weight of its reference (bin 0 only)
+                const float dcw = stats[(size_t)mtile * 8 + (pair >> 3)].x * cdc[min(ref0 + (pair & 7), nref - 1)];
                 for (int k = wave; k < g.nbins; k += NW) {
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
                     const float *pa = Ablk + (size_t)e0 * 8, *pb = Bt + (size_t)e0 * 16;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                     // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
                     const float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
                     const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                    const float ca = odd ? r0 : acc[0], cb = odd ? r1 : acc[1];
+                    const float ca = (odd ? r0 : acc[0]) - (k == 0 ? dcw : 0.f), cb = odd ? r1 : acc[1];
                     const float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
                     const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                     zs[(size_t)k * 64 + pair] = make_float2(apd + bpc, cmb + amd);
@@ -314,11 +315,29 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
                     const float v = pc[o * 8 + rr].val;
                     if (v >= bv) { bv = v; br = rr; }
                 }
-                reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
+                int word = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
+                if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * stats[(size_t)mtile * 8 + o].y);     // val, t7[] * 1/sigma
+                reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = word;
             }
             __syncthreads();
         }
     }
+}
+
+// DC weights of the references: cdc[ref] = sum over rings of n_r * (prepared reference, bin 0) -- what subtracting the
+// Normalize_ring mean from every sample of the particle does to the CCF spectrum
+__global__ void ref_dc_weights_kernel(DevGeom g, const float *__restrict__ refspec, int nref, float *__restrict__ cdc)
+{
+    const int ref = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ref >= nref) return;
+    const float inv = 1.0f / (float)g.maxrin;
+    float s = 0.f;
+    for (int r = 0; r < g.nring; r++) {
+        const int4 ri = g.ringinfo[r];
+        const int e = g.bin_off[0] + (r - g.bin_first[0]);
+        s += (float)ri.z * refspec[(size_t)ref * g.lring + ri.x] * g.ent_wgt[e] * inv;
+    }
+    cdc[ref] = s;
 }
 
 // rot_shift2D for images that do not fit LDS: quadri_background reads global memory

@@ -571,8 +571,9 @@ __global__ void unpack_refs_kernel(DevGeom g, const float *__restrict__ refspec,
 
 // diagnostic: A panels -> ring spectra in EMAN2 packing [n][nshift][lcirc] (what Frngs leaves in
 // `cimage` inside Util.multiref_polar_ali_2d), for bin-for-bin tests of the polar kernel
+// stats (generic path only): {avg, 1/sigma} per particle-offset; the generic polar kernel writes raw spectra
 __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, int n, const int *__restrict__ numr,
-                                      float *__restrict__ out)
+                                      float *__restrict__ out, const float2 *__restrict__ stats)
 {
     const int m = blockIdx.x;                  // particle * nshift + shift
     const int p = m / g.nshift, sft = m - p * g.nshift;
@@ -587,7 +588,13 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
             const int k = (j == 0) ? 0 : (j == 1 ? nlen / 2 : j >> 1), comp = (j < 2) ? 0 : (j & 1);
             const int e = g.bin_off[k] + (i - g.bin_first[k]);
             const int2 ap = g.ent_apos[e];
-            dst[o + j] = blk[ap.x + (row0 + comp) * ap.y];
+            float v = blk[ap.x + (row0 + comp) * ap.y];
+            if (stats) {
+                const float2 st = stats[(size_t)p * g.nshift_pad + sft];
+                if (j == 0) v -= st.x * (float)nlen;
+                v *= st.y;
+            }
+            dst[o + j] = v;
         }
     }
 }
