@@ -13,11 +13,37 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
 __device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
 
-// a * b (complex)
+// The swaps and sign flips of complex arithmetic ride on the operand modifiers of the packed instructions (op_sel picks
+// the half of each source that feeds the low / high result, neg_lo / neg_hi negate it): hipcc only folds broadcasts
+// into op_sel and spends a v_mov + v_xor on every swap, hence the three one-instruction forms below.
+
+// a + (SIGN * i) * b
+template <int SIGN> __device__ __forceinline__ v2f vadd_rot(v2f a, v2f b)
+{
+    v2f r;
+    if constexpr (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// t + a.y * (i * b) = (t.x - a.y b.y, t.y + a.y b.x): the second half of a complex product (fused multiply-add)
+__device__ __forceinline__ v2f vfma_rot_y(v2f a, v2f b, v2f t)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// t + (i * a) * s.x = (t.x - a.y s.x, t.y + a.x s.x); s is a wave-uniform constant (scalar register pair)
+__device__ __forceinline__ v2f vfma_irot_s(v2f a, v2f s, v2f t)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(s), "v"(t));
+    return r;
+}
+
+// a * b (complex): (a.x b.x, a.x b.y) + a.y * (-b.y, b.x)
 __device__ __forceinline__ v2f vmul(v2f a, v2f b)
 {
-    const v2f t = a.xx * b;
-    return __builtin_elementwise_fma(a.yy, (v2f){-b.y, b.x}, t);
+    return vfma_rot_y(a, b, a.xx * b);
 }
 // a * (SIGN * i)
 template <int SIGN> __device__ __forceinline__ v2f vmuli(v2f a)
@@ -36,14 +62,14 @@ template <int SIGN, int NUM, int DEN> __device__ __forceinline__ v2f vtw(v2f a)
         constexpr double ang = 6.283185307179586476925286766559 * (double)n / (double)DEN;
         const float c = (float)__builtin_cos(ang);
         const float s = (float)(SIGN * __builtin_sin(ang));
-        return __builtin_elementwise_fma((v2f){-a.y, a.x}, (v2f){s, s}, a * (v2f){c, c});
+        return vfma_irot_s(a, (v2f){s, s}, a * (v2f){c, c});
     }
 }
 
 template <int SIGN> __device__ __forceinline__ void vdft4(v2f &v0, v2f &v1, v2f &v2, v2f &v3)
 {
-    const v2f a = v0 + v2, b = v0 - v2, c = v1 + v3, d = vmuli<SIGN>(v1 - v3);
-    v0 = a + c; v1 = b + d; v2 = a - c; v3 = b - d;
+    const v2f a = v0 + v2, b = v0 - v2, c = v1 + v3, e = v1 - v3;
+    v0 = a + c; v1 = vadd_rot<SIGN>(b, e); v2 = a - c; v3 = vadd_rot<-SIGN>(b, e);
 }
 
 // float2 front end used by the kernels

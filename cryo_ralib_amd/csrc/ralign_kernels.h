@@ -125,6 +125,8 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
 // every tap of every search offset, including the zero-weight taps one past the image and the
 // taps of offsets outside the particle's window (masked later), stays inside the padded
 // array, so no clamping is needed.  `base` = img + (bd-1)*st + (bd-1) absorbs the 1-based origin.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float bilinear_pad(const float *base, int st, float xold, float yold)
 {
 #pragma clang fp contract(off)
@@ -132,7 +134,9 @@ __device__ __forceinline__ float bilinear_pad(const float *base, int st, float x
     // xold - (float)(int)xold bit for bit and saves the int -> float round trip
     const int ix = (int)xold, iy = (int)yold;
     const float ydif = __builtin_amdgcn_fractf(yold), xdif = __builtin_amdgcn_fractf(xold);
-    const float *p = base + (__mul24(iy, st) + ix);     // 24-bit multiply: full-rate VALU
+    int idx;                                            // iy * st + ix in ONE full-rate instruction (hipcc otherwise splits
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(idx) : "v"(iy), "s"(st), "v"(ix));    // it into mul24 + two shifts + add3)
+    const float *p = base + idx;
     const float f00 = p[0], f10 = p[1], f01 = p[st], f11 = p[st + 1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
@@ -310,11 +314,14 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     const float rad = (float)in.w, wt = instw_s[inst0 + sub];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
     const float2 *qt = qt_s + in.z;
-    float av = 0.f, sq = 0.f;
+    // Normalize_ring partial sums: plain sums of the lane's samples and their squares, two at a time (packed f32),
+    // weighted once per ring at the end
+    v2f av2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+    const v2f ctr2 = {cx, cy};
     float2 v[R1];
 #pragma unroll
     for (int a = 0; a < R1; a++) {
-        float val[2];
+        v2f val;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             // sample index on the ring j = 2*(LR*a + t) + u; when 2*LR <= LT the quadrant of j
@@ -323,23 +330,26 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
             if constexpr (2 * LR <= LT) { qd = (2 * LR * a) / LT; jt = (2 * LR * a) % LT + 2 * t + u; }
             else { const int j = 2 * (LR * a + t) + u; qd = j / LT; jt = j % LT; }
             const float2 sc = qt[jt];
-            float x, y;
+            v2f o;
             {
 #pragma clang fp contract(off)
-                x = sc.x * rad; y = sc.y * rad;
+                // both coordinates in one packed multiply and one packed add (the same IEEE operations as the scalar
+                // form); alrl_ms quadrant mirroring (x,y), (y,-x), (-x,-y), (-y,x) rides on the operand modifiers
+                const v2f xy = v2f{sc.x, sc.y} * rad;
+                v2f m = (qd & 1) ? v2f{xy.y, xy.x} : xy;
+                m.x = (qd & 2) ? -m.x : m.x;
+                m.y = ((qd + 1) & 2) ? -m.y : m.y;
+                o = m + ctr2;
             }
-            // alrl_ms quadrant mirroring: (x,y), (y,-x), (-x,-y), (-y,x)
-            float ox = (qd & 1) ? y : x, oy = (qd & 1) ? x : y;
-            ox = (qd & 2) ? -ox : ox;
-            oy = ((qd + 1) & 2) ? -oy : oy;
-            const float s = bilinear_pad(imgb, g.pst, ox + cx, oy + cy);
-            val[u] = s;
-            av += s * wt;
-            sq += s * s * wt;
+            const float s = bilinear_pad(imgb, g.pst, o.x, o.y);
+            if (u == 0) val.x = s; else val.y = s;
         }
-        v[a] = make_float2(val[0], val[1]);
+        av2 += val;
+        sq2 += val * val;
+        v[a] = make_float2(val.x, val.y);
         if (NYQ1 || (a & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 (fused kernel: 2) samples' taps in flight (VGPR budget)
     }
+    float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
     if (RA_DBG(g, 256)) {   // diagnostic: leave the raw samples in natural order, no FFT
 #pragma unroll
         for (int a = 0; a < R1; a++) *reinterpret_cast<float2 *>(buf + 2 * (LR * a + t)) = v[a];
