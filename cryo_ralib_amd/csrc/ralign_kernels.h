@@ -310,7 +310,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (sub >= count) return;
     const int4 in = inst_s[inst0 + sub];
     const int slot = in.x & 255, ring = in.x >> 8;
-    float *buf = bufs + slot * sbuf + in.y;
+    float *buf = bufs + (__mul24(slot, sbuf) + in.y);
     const float rad = (float)in.w, wt = instw_s[inst0 + sub];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
     const float2 *qt = qt_s + in.z;
@@ -319,35 +319,61 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     v2f av2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
     const v2f ctr2 = {cx, cy};
     float2 v[R1];
+    // Sample j = 2*(LR*a + t) + u of the ring sits in quadrant j / LT at table entry j % LT.  When 2*LR <= LT (QCT) the
+    // quadrant depends on `a` alone: a = qd * NB + b with NB = R1 / 4 table positions per lane, and the four quadrants
+    // of one position share the table read and the radius multiply -- the loop runs position-major, the alrl_ms
+    // mirroring (x,y), (y,-x), (-x,-y), (-y,x) is an operand modifier of the packed add of the centre.
+    // The (sin, cos) pairs of the next step are requested before the current one is interpolated: their LDS latency
+    // hides behind the taps instead of heading the dependent chain table -> position -> taps -> interpolation.
+    constexpr bool QCT = (2 * LR <= LT) && (R1 >= 4);
+    constexpr int NB = QCT ? R1 / 4 : R1;
+    auto table_index = [&](int step, int u, int &qd) {
+        if constexpr (QCT) { qd = 0; return 2 * LR * step + 2 * t + u; }
+        else { const int j = 2 * (LR * step + t) + u; qd = j / LT; return j % LT; }
+    };
+    int qdn[2];
+    float2 scn[2];
 #pragma unroll
-    for (int a = 0; a < R1; a++) {
-        v2f val;
+    for (int u = 0; u < 2; u++) scn[u] = qt[table_index(0, u, qdn[u])];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            // sample index on the ring j = 2*(LR*a + t) + u; when 2*LR <= LT the quadrant of j
-            // depends on `a` alone and is resolved at compile time
-            int qd, jt;
-            if constexpr (2 * LR <= LT) { qd = (2 * LR * a) / LT; jt = (2 * LR * a) % LT + 2 * t + u; }
-            else { const int j = 2 * (LR * a + t) + u; qd = j / LT; jt = j % LT; }
-            const float2 sc = qt[jt];
-            v2f o;
-            {
+    for (int b = 0; b < NB; b++) {
+        const int qdc[2] = {qdn[0], qdn[1]};
+        v2f xy[2];
+        {
 #pragma clang fp contract(off)
-                // both coordinates in one packed multiply and one packed add (the same IEEE operations as the scalar
-                // form); alrl_ms quadrant mirroring (x,y), (y,-x), (-x,-y), (-y,x) rides on the operand modifiers
-                const v2f xy = v2f{sc.x, sc.y} * rad;
-                v2f m = (qd & 1) ? v2f{xy.y, xy.x} : xy;
-                m.x = (qd & 2) ? -m.x : m.x;
-                m.y = ((qd + 1) & 2) ? -m.y : m.y;
-                o = m + ctr2;
-            }
-            const float s = bilinear_pad(imgb, g.pst, o.x, o.y);
-            if (u == 0) val.x = s; else val.y = s;
+            // both coordinates in one packed multiply and one packed add: the same IEEE operations as the scalar form
+            xy[0] = v2f{scn[0].x, scn[0].y} * rad;
+            xy[1] = v2f{scn[1].x, scn[1].y} * rad;
         }
-        av2 += val;
-        sq2 += val * val;
-        v[a] = make_float2(val.x, val.y);
-        if (NYQ1 || (a & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 (fused kernel: 2) samples' taps in flight (VGPR budget)
+        if (b + 1 < NB) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) scn[u] = qt[table_index(b + 1, u, qdn[u])];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < (QCT ? 4 : 1); q++) {
+            const int a = QCT ? q * NB + b : b;
+            v2f val;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                v2f o;
+                if constexpr (QCT) {
+                    o = q == 0 ? ctr2 + xy[u] : q == 1 ? vadd_rot<-1>(ctr2, xy[u]) : q == 2 ? ctr2 - xy[u] : vadd_rot<1>(ctr2, xy[u]);
+                } else {
+                    const int qd = qdc[u];
+                    v2f m = (qd & 1) ? v2f{xy[u].y, xy[u].x} : xy[u];
+                    m.x = (qd & 2) ? -m.x : m.x;
+                    m.y = ((qd + 1) & 2) ? -m.y : m.y;
+                    o = m + ctr2;
+                }
+                const float s = bilinear_pad(imgb, g.pst, o.x, o.y);
+                if (u == 0) val.x = s; else val.y = s;
+            }
+            av2 += val;
+            sq2 += val * val;
+            v[a] = make_float2(val.x, val.y);
+            if (NYQ1 || ((QCT ? q : b) & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 (fused kernel: 2) samples' taps in flight (VGPR budget)
+        }
     }
     float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
     if (RA_DBG(g, 256)) {   // diagnostic: leave the raw samples in natural order, no FFT
@@ -356,11 +382,12 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         return;
     }
     Dft<-1, R1>::run(v);
+    const int tstep = __mul24(t, g.maxrin / H);
     // element (row c, column t) is parked at LR*c + ((t + c) mod LR): conflict-free both ways
 #pragma unroll
     for (int c = 0; c < R1; c++) {
         float2 o = v[c];
-        if (c > 0) o = cmul(o, tw_s[(t * c * (g.maxrin / H)) & (g.maxrin - 1)]);
+        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c) & (g.maxrin - 1)]);      // 24-bit multiplies are full rate, v_mul_lo_u32 is not
         *reinterpret_cast<float2 *>(buf + 2 * (LR * c + ((t + c) & (LR - 1)))) = o;
     }
     RA_WAVE_SYNC();
@@ -401,7 +428,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
             float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
             float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
             float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-            float2 w = tw_s[k * (g.maxrin / NR)];
+            float2 w = tw_s[__mul24(k, g.maxrin / NR)];
             float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
             *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
             if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
