@@ -391,47 +391,98 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         *reinterpret_cast<float2 *>(buf + 2 * (LR * c + ((t + c) & (LR - 1)))) = o;
     }
     RA_WAVE_SYNC();
-    // second pass: the R1 rows of the LR-point transforms are dealt to the LR lanes of the ring
-    // (one row per lane when R1 <= LR, R1/LR rows per lane otherwise: no idle half-groups)
-    constexpr int NROW = (R1 + LR - 1) / LR;
-    float2 z[NROW][LR];
+    // real-FFT split step of one pair: X_k and X_{H-k} from Z_k, Z_{H-k} (k = 0 gives X_0 and the Nyquist term X_H)
+    auto split_pair = [&](float2 zk, float2 zm, int k, float2 &xk, float2 &xm) {
+        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+        const float2 w = tw_s[__mul24(k, g.maxrin / NR)];
+        const float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+        xk = make_float2(er + tr, ei + ti);
+        xm = make_float2(er - tr, -(ei - ti));
+    };
+    if constexpr (R1 == 2 * LR) {
+        // Two rows per lane, chosen so that the split step stays inside the lane: lane t transforms rows t and R1 - t
+        // (lane 0: rows 0 and R1/2), and Z_{H-k} of every k = row + R1 e of one row is element LR-1-e of the other
+        // (rows 0 and R1/2 pair with themselves).  The second-pass output never goes back to LDS: one write and one
+        // read of every element and one wave hand-off less than the generic schedule below.
+        const int rowA = t, rowB = t ? R1 - t : R1 / 2;
+        float2 z[2][LR];
 #pragma unroll
-    for (int m = 0; m < NROW; m++) {
-        const int row = t + LR * m;
-        if (row < R1) {
+        for (int b = 0; b < LR; b++) z[0][b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * rowA + ((b + rowA) & (LR - 1))));
 #pragma unroll
-            for (int b = 0; b < LR; b++) z[m][b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * row + ((b + row) & (LR - 1))));
-            Dft<-1, LR>::run(z[m]);
+        for (int b = 0; b < LR; b++) z[1][b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * rowB + ((b + rowB) & (LR - 1))));
+        Dft<-1, LR>::run(z[0]);
+        Dft<-1, LR>::run(z[1]);
+        RA_WAVE_SYNC();                  // every lane of the ring has its rows: the buffer may be overwritten
+        const bool l0 = t == 0;
+#pragma unroll
+        for (int i = 0; i < LR; i++) {
+            // lane t > 0: (Z[t + R1 i], Z[R1 - t + R1 (LR-1-i)]); lane 0: row R1/2 for i < LR/2, then row 0 (e = 1 .. LR/2)
+            const int e0 = i < LR / 2 ? i : i - LR / 2 + 1;
+            const float2 zk0 = i < LR / 2 ? z[1][e0] : z[0][e0];
+            const float2 zm0 = i < LR / 2 ? z[1][LR - 1 - e0] : z[0][(LR - e0) & (LR - 1)];
+            const int k0 = i < LR / 2 ? LR + R1 * e0 : R1 * e0;
+            float2 zk, zm;
+            zk.x = l0 ? zk0.x : z[0][i].x; zk.y = l0 ? zk0.y : z[0][i].y;
+            zm.x = l0 ? zm0.x : z[1][LR - 1 - i].x; zm.y = l0 ? zm0.y : z[1][LR - 1 - i].y;
+            const int k = l0 ? k0 : t + R1 * i;
+            float2 xk, xm;
+            split_pair(zk, zm, k, xk, xm);
+            *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = xm;      // lane 0, last step: k = H/2 = H - k, X_k lands last
+            *reinterpret_cast<float2 *>(buf + 2 * k) = xk;
         }
-    }
-    RA_WAVE_SYNC();
-#pragma unroll
-    for (int m = 0; m < NROW; m++) {
-        const int row = t + LR * m;
-        if (row < R1) {
-#pragma unroll
-            for (int e = 0; e < LR; e++) *reinterpret_cast<float2 *>(buf + 2 * (row + R1 * e)) = z[m][e];
-        }
-    }
-    RA_WAVE_SYNC();
-    // split step X_k <- (Z_k, Z_{H-k}), k = 0..H/2, in place; X_0 and X_H are real
-    for (int k = t; k <= H / 2; k += LR) {
-        float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
-        if (k == 0) {
+        if (l0) {
+            const float2 zk = z[0][0];
             if (NYQ1 && NR == g.maxrin) {
                 *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, zk.x - zk.y);
             } else {
                 *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
                 *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
             }
-        } else {
-            float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
-            float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-            float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-            float2 w = tw_s[__mul24(k, g.maxrin / NR)];
-            float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
-            *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
-            if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+        }
+    } else {
+        // second pass: the R1 rows of the LR-point transforms are dealt to the LR lanes of the ring
+        // (one row per lane when R1 <= LR, R1/LR rows per lane otherwise: no idle half-groups)
+        constexpr int NROW = (R1 + LR - 1) / LR;
+        float2 z[NROW][LR];
+#pragma unroll
+        for (int m = 0; m < NROW; m++) {
+            const int row = t + LR * m;
+            if (row < R1) {
+#pragma unroll
+                for (int b = 0; b < LR; b++) z[m][b] = *reinterpret_cast<const float2 *>(buf + 2 * (LR * row + ((b + row) & (LR - 1))));
+                Dft<-1, LR>::run(z[m]);
+            }
+        }
+        RA_WAVE_SYNC();
+#pragma unroll
+        for (int m = 0; m < NROW; m++) {
+            const int row = t + LR * m;
+            if (row < R1) {
+#pragma unroll
+                for (int e = 0; e < LR; e++) *reinterpret_cast<float2 *>(buf + 2 * (row + R1 * e)) = z[m][e];
+            }
+        }
+        RA_WAVE_SYNC();
+        // split step X_k <- (Z_k, Z_{H-k}), k = 0..H/2, in place; X_0 and X_H are real
+        for (int k = t; k <= H / 2; k += LR) {
+            float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
+            if (k == 0) {
+                if (NYQ1 && NR == g.maxrin) {
+                    *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, zk.x - zk.y);
+                } else {
+                    *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
+                    *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+                }
+            } else {
+                float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
+                float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+                float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+                float2 w = tw_s[__mul24(k, g.maxrin / NR)];
+                float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+                *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
+                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+            }
         }
     }
     // Normalize_ring partial sums of this ring -> its own slot (summed in ring order later)
