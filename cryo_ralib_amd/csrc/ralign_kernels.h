@@ -372,7 +372,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
             av2 += val;
             sq2 += val * val;
             v[a] = make_float2(val.x, val.y);
-            if (NYQ1 || ((QCT ? q : b) & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 (fused kernel: 2) samples' taps in flight (VGPR budget)
+            if ((NYQ1 && (QCT ? 4 * b + q : b) >= R1 / 2) || ((QCT ? q : b) & 1)) __builtin_amdgcn_sched_barrier(0);   // at most 4 samples' taps in flight (fused kernel: 2 once half of the samples are held in registers)
         }
     }
     float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
