@@ -65,7 +65,7 @@ struct ra_engine {
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
-    float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic path)
+    float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic and fused paths)
     int g_nblk = 0, g_P = 0;
     size_t lds_gpolar = 0, lds_gccf = 0;
     // reference-update workspace (ralign_refine.h), allocated on first use
@@ -424,7 +424,8 @@ static int setup_fused(ra_engine *e)
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
     if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true))) return rc;
-    fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = nullptr;
+    if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
+    fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
     hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     e->fused = true;
@@ -650,7 +651,7 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
             RA_HIP(hipGetLastError());
         }
     }
-    if (e->generic) {
+    if (e->generic || e->fused) {
         hipLaunchKernelGGL(ref_dc_weights_kernel, dim3((e->cfg.nref + 63) / 64), dim3(64), 0, e->stream, e->dg, e->d_refspec, e->cfg.nref, e->d_gcdc);
         RA_HIP(hipGetLastError());
     }

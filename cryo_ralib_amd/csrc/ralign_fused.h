@@ -50,7 +50,7 @@ struct FusedGeom {
     const int *bsrc;               // [b_floats] (entry << 5 | reference << 1 | imaginary part), -1 = 0
     int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's)
     int gstr;                      // ints per group in the LDS table of ring offsets (quads of 4, padded by one quad)
-    const float *cdc_w;            // unused by the kernel (the DC correction happens in the ring buffer); kept for diagnostics
+    const float *cdc_w;            // [nref] DC weights of the references: sum over rings of n_r * B_r(bin 0) (ref_dc_weights_kernel)
 };
 
 struct FusedPlanHost {
@@ -324,8 +324,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             }
         }
         __syncthreads();
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn); X_0 -= avg*n in the ring buffer, 1/sigma later.
-        // Wave s (< 4) reduces the ring partials of offset s with a fixed butterfly (reproducible) and corrects its DC bins.
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  Wave s (< 4) reduces the ring partials of offset s
+        // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
+        // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
+        // (a -= avg * sum_r n_r B_r(0), store_round) and 1/sigma to the peak record.
         if (wave < 4) {
             float a = 0.f, q = 0.f;
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
@@ -335,14 +337,15 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const float nn = g.nn_weight;
                 avg = a / nn;
                 rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
-                for (int i = lane; i < g.nring; i += 64) {
-                    const int ro = f.roff[i], nlen = (i + 1 < g.nring ? f.roff[i + 1] : g.lring) - ro - kRingPad;
-                    bufs[wave * g.sbuf + ro] -= avg * (float)nlen;
-                }
             }
             if (lane == 0) { red[8 + wave] = avg; red[12 + wave] = rsg; }
+        } else if (wave == 4 && lane < 4 && grp + 1 < ngroup) {
+            // sampling centres of the next pass: this pass's ring jobs are done with the current ones
+            const int si = min((grp + 1) * 4 + (int)lane, g.nshift - 1);
+            red[16 + 2 * lane] = cxf + g.shift_x[si];
+            red[17 + 2 * lane] = cyf + g.shift_y[si];
+            red[7] = 0.f;
         }
-        __syncthreads();
         // ---- contraction: accumulate this wave's units over the rings that have bins of its group
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
@@ -369,8 +372,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const float r0x = swap_lane_pair(s0), r1x = swap_lane_pair(s1);
                 const float ca = odd ? r0x : c4[0], cb = odd ? r1x : c4[1];
                 const float cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
-                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz)
-                    rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca, cb, cc, cd);
+                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz) {
+                    float cdc = 0.f;
+                    if (xm == 0 && xb == 0) cdc = red[8 + o] * f.cdc_w[ref];       // Normalize_ring mean: the DC term only
+                    rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca - cdc, cb, cc, cd);
+                }
             }
         };
         auto ifft_round = [&](int ref_lo, int nrz) {
@@ -410,13 +416,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
             reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + grp * 4 + o)[wd] = word;
         }
-        if (tid >= 64 && tid < 68 && grp + 1 < ngroup) {      // another wave than the one writing the records
-            const int t4 = tid - 64, si = min((grp + 1) * 4 + t4, g.nshift - 1);
-            red[16 + 2 * t4] = cxf + g.shift_x[si];
-            red[17 + 2 * t4] = cyf + g.shift_y[si];
-            red[7] = 0.f;
-        }
-        __syncthreads();
+        // no barrier here: the next pass's ring jobs touch the ring buffers (free since the barrier after the inverse
+        // FFTs), the ring partials (read before the contraction barrier) and the centres (written after the first
+        // barrier of this pass); `pc` and red[12..15] are next written two and one barriers into the next pass
     }
     }
 }
