@@ -307,30 +307,36 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     __syncthreads();
     for (int grp = 0; grp < ngroup; grp++) {
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
+        const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
         if (!RA_DBG(g, 16)) {
 #pragma unroll 1
-            for (int job = wave; job < g.n_job; job += RF_WAVES) {
+            for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
+                // the jobs are sorted longest first: rounds alternate direction, so the waves that drew the long jobs
+                // of round 0 get the short ones (or none) of round 1
+                const int job = jr * RF_WAVES + ((jr & 1) ? RF_WAVES - 1 - wave : wave);
+                if (job >= g.n_job) continue;
                 const int4 jd = jobs_s[job];
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
-                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
                 }
             }
         }
         __syncthreads();
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  Wave s (< 4) reduces the ring partials of offset s
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One of the last four waves per offset reduces its ring partials
         // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
         // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
         // (a -= avg * sum_r n_r B_r(0), store_round) and 1/sigma to the peak record.
-        if (wave < 4) {
+        if (wave >= RF_WAVES - 4) {              // the waves of the highest bin groups have the shortest contraction
+            const int os = wave - (RF_WAVES - 4);
             float a = 0.f, q = 0.f;
-            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (wave * g.nring + i)]; q += red[25 + 2 * (wave * g.nring + i)]; }
+            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum(a); q = wave_sum(q);
             float avg = 0.f, rsg = 1.f;
             if (g.mode == RA_MODE_MREF) {
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 avg = a / nn;
                 rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
             }
-            if (lane == 0) { red[8 + wave] = avg; red[12 + wave] = rsg; }
+            if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
         } else if (wave == 4 && lane < 4 && grp + 1 < ngroup) {
             // sampling centres of the next pass: this pass's ring jobs are done with the current ones
             const int si = min((grp + 1) * 4 + (int)lane, g.nshift - 1);
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const float r0x = swap_lane_pair(s0), r1x = swap_lane_pair(s1);
                 const float ca = odd ? r0x : c4[0], cb = odd ? r1x : c4[1];
                 const float cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
-                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz) {
+                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz && o < nlive) {
                     float cdc = 0.f;
                     if (xm == 0 && xb == 0) cdc = red[8 + o] * f.cdc_w[ref];       // Normalize_ring mean: the DC term only
                     rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca - cdc, cb, cc, cd);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
             const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
             const int rr = zs % f.rz, o = zs / f.rz;
-            if (zs < 4 * f.rz && rr < nrz && !RA_DBG(g, 1))      // uniform over the 16-lane group
+            if (zs < 4 * f.rz && rr < nrz && o < nlive && !RA_DBG(g, 1))      // uniform over the 16-lane group
                 ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
         };
         if (!RA_DBG(g, 4)) {
@@ -404,9 +410,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             }
         }
         // best reference per offset of the pass (ascending reference, ">=": later wins), scaled by 1/sigma
-        if (tid < 4 * (int)(sizeof(CandT) / 4)) {
+        // (by the last wave: the first ones head for the longest ring jobs of the next pass)
+        if (wave == RF_WAVES - 1 && lane < nlive * (int)(sizeof(CandT) / 4)) {
             constexpr int W = sizeof(CandT) / 4;
-            const int o = tid / W, wd = tid - o * W;
+            const int o = lane / W, wd = lane - o * W;
             float bv = pc[o * nref].val; int br = 0;
             for (int q3 = 1; q3 < nref; q3++) {
                 const float v = pc[o * nref + q3].val;

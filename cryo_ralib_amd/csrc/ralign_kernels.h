@@ -293,13 +293,14 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
     } while (0)
 
+// `nlive`: offset slots >= nlive are padding and skipped.
 // `part` receives the Normalize_ring partial sums {sum w x, sum w x^2} of every (offset slot, ring).  NYQ1 (fused
 // search kernel): the Nyquist coefficient of a full-length ring (n == maxrin) is stored in the imaginary slot of
 // bin 0, EMAN2's own packing, so that the contraction sees bins 0 .. maxrin/2 - 1 only.
 template <int R1, int LR, bool NYQ1 = false>
 __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                          const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
-                                         const float *instw_s, int inst0, int count, int zero, int sbuf)
+                                         const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4)
 {
     // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
     // inside the job instead of hoisted out of the pass loop for all six variants (VGPR spills)
@@ -310,6 +311,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (sub >= count) return;
     const int4 in = inst_s[inst0 + sub];
     const int slot = in.x & 255, ring = in.x >> 8;
+    if (slot >= nlive) return;          // padding offsets of the last pass (the instances of a slot are contiguous: whole jobs drop out)
     float *buf = bufs + (__mul24(slot, sbuf) + in.y);
     const float rad = (float)in.w, wt = instw_s[inst0 + sub];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
