@@ -169,7 +169,8 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
 // unit (h, op) accumulates in acc[2 h + op]
 template <int NRPW, int NH>
 __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f, const float *bufs, const int *goff_s,
-                                            const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW])
+                                            const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW],
+                                            const float4 (&b0)[NRPW])
 {
     const int xb = ln >> 2, xj = ln & 3;
     const int nq = f.grp_nq[xm];
@@ -215,7 +216,8 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // path (283 KB per pass and CU at 64 B/clk) plus the matrix instructions; deeper prefetch does not help.
     const int ql = nq - 1;
     int4 oA = gq[0], oB = gq[min(1, ql)];
-    load_b(0, bA);
+#pragma unroll
+    for (int h = 0; h < NH; h++) bA[h] = b0[h];      // quad 0 was requested before the barrier that ends the ring jobs
     read_a(oA, aA);
 #pragma unroll 1
     for (int rq = 0; rq < nq; rq += 2) {
@@ -233,6 +235,15 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// workgroup barrier that orders LDS traffic only: global requests (the B stream, the record stores) stay in flight
+// across it (__syncthreads() drains them with s_waitcnt vmcnt(0))
+#define RF_LDS_BARRIER()                                                   \
+    do {                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    \
+        __builtin_amdgcn_s_barrier();                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
+    } while (0)
 
 template <int N, int NRPW>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     const int ngroup = g.nshift_pad / 4;
 #pragma unroll 1
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
-    __syncthreads();                           // the previous particle's last pass has left the image and `red`
+    RF_LDS_BARRIER();                           // the previous particle's last pass has left the image and `red`
     const float *src = particles + (size_t)p * g.nx * g.nx;
     for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
         const int y = row - g.bd;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         red[17 + 2 * tid] = cyf + g.shift_y[si];
         red[7] = 0.f;
     }
-    __syncthreads();
+    RF_LDS_BARRIER();
     for (int grp = 0; grp < ngroup; grp++) {
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
         const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
@@ -328,7 +339,18 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 }
             }
         }
-        __syncthreads();
+        // lane roles of the contraction (see above), and its first B quad: requested here, it travels while the last ring
+        // jobs finish and the barrier is crossed (the barrier does not drain global requests)
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
+        float4 b0[NRPW];
+        {
+            const float *bp = Bf + f.grp_boff[xm] + ln * 4;
+            const int nq = f.grp_nq[xm];
+#pragma unroll
+            for (int h = 0; h < NRPW; h++)
+                b0[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : min(rp0 + h, f.nrp - 1) * nq * 256));
+        }
+        RF_LDS_BARRIER();
         // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One of the last four waves per offset reduces its ring partials
         // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
         // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
@@ -353,17 +375,16 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             red[7] = 0.f;
         }
         // ---- contraction: accumulate this wave's units over the rings that have bins of its group
-        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
         f32x4 acc[NU];
 #pragma unroll
         for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
             // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
-            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc);
-            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc);
+            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
+            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
         }
-        __syncthreads();                       // every wave has finished reading the ring buffers
+        RF_LDS_BARRIER();                       // every wave has finished reading the ring buffers
         // ---- CCF spectra -> LDS (over the ring buffers), inverse FFT, argmax: rounds of f.rz references
         if (RA_DBG(g, ~0) && tid < 4 * nref) {   // profiling builds that skip a phase still emit in-range records
             pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = tid % nref;
@@ -396,16 +417,16 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         if (!RA_DBG(g, 4)) {
             if (f.nzr == 1) {                  // the accumulators die before the inverse FFT: no register pressure from them
                 store_round(0, nref);
-                __syncthreads();
+                RF_LDS_BARRIER();
                 ifft_round(0, nref);
-                __syncthreads();
+                RF_LDS_BARRIER();
             } else {
                 for (int zr = 0; zr < f.nzr; zr++) {
                     const int ref_lo = zr * f.rz, nrz = min(f.rz, nref - ref_lo);
                     store_round(ref_lo, nrz);
-                    __syncthreads();
+                    RF_LDS_BARRIER();
                     ifft_round(ref_lo, nrz);
-                    __syncthreads();
+                    RF_LDS_BARRIER();
                 }
             }
         }
