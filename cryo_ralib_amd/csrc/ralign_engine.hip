@@ -725,7 +725,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             float *st = d_state + (size_t)start * 2;
             std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
             if (evc) RA_HIP(hipEventRecord(evc->first, sp));
-            // one workgroup per CU (LDS-bound); each walks over its share of the chunk
+            // one workgroup per CU (its LDS plan fills the CU); each walks over its share of the chunk
             hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
                                (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand);
             RA_HIP(hipGetLastError());
