@@ -63,7 +63,7 @@ struct ra_engine {
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
-    float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64] CCF spectra scratch of ccf_generic_kernel
+    float2 *d_zscr = nullptr;           // [g_nblk][maxrin][256] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
     float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic and fused paths)
     int g_nblk = 0, g_P = 0;
@@ -353,7 +353,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.refspec_floats = (size_t)cfg.nref * g.lring;
     w.b_floats = (size_t)nrtile * g.LBP * 16;
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
-    w.zscr_recs = generic ? (size_t)512 * 64 * g.maxrin : 0;
+    w.zscr_recs = generic ? (size_t)512 * RA_GCCF_ZPAIRS * g.maxrin : 0;
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
@@ -518,8 +518,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->xf_generic = e->lds_xf > lds_max;
     // generic contraction: P pairs per inverse-FFT batch, two N-point buffers per pair
     e->g_P = 64;
-    while (e->g_P > 1 && (size_t)e->g_P * (2 * g.maxrin + 1) * sizeof(float2) > 128 * 1024) e->g_P >>= 1;
-    e->lds_gccf = ((size_t)e->g_P * (2 * g.maxrin + 1) + g.maxrin) * sizeof(float2);      // pair buffers + twiddle table
+    while (e->g_P > 1 && (size_t)e->g_P * (g.maxrin + 1) * sizeof(float2) > 66 * 1024) e->g_P >>= 1;      // two workgroups per CU
+    e->lds_gccf = ((size_t)e->g_P * (g.maxrin + 1) + g.maxrin) * sizeof(float2);      // pair buffers (in-place transforms) + twiddle table
     e->lds_gpolar = (size_t)(RA_GEN_THREADS / 64 + 1) * g.maxrin * sizeof(float2);      // per-wave ring buffers + twiddle table
     hipError_t he = hipSuccess;
     if (!e->generic) {
@@ -762,7 +762,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
         if (e->generic)
-            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
+            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);
         else

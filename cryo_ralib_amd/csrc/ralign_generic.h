@@ -72,6 +72,85 @@ __device__ __forceinline__ float2 *wave_fft(float2 *x, float2 *y, int h, const f
     return x;
 }
 
+// LDS slot of element i of a wave_fft_dif buffer: an XOR swizzle inside aligned blocks of 32 that makes the stride-4,
+// stride-16 and stride-64 butterflies of the last radix-4 stages bank-conflict free for ds_read_b64 (a 32-lane group maps
+// one-to-one onto the 32 complex slots of a bank row; without it those stages run 4-way conflicted)
+__device__ __forceinline__ int dif_slot(int i) { return i ^ (((i >> 5) & 3) * 5) ^ (((i >> 6) & 1) << 4); }
+
+// Wave-level in-place FFT of h complex points (h a power of two >= 4), decimation in frequency: one radix-2 stage when
+// log2 h is odd, then radix-4 stages; a single buffer (half the LDS of the Stockham form above).  The output is digit
+// reversed: position p = d1 (h/r1) + d2 (h/(r1 r2)) + ... holds X[d1 + r1 d2 + r1 r2 d3 + ...] for the stage radices
+// r1, r2, ... = [2,] 4, 4, ... (dif_index_of_pos / dif_pos_of_index), and element i lives in LDS slot dif_slot(i).  tw[m] = e^{-2 pi i m / T}, T >= h.
+template <int SIGN>
+__device__ __forceinline__ void wave_fft_dif(float2 *x, int h, const float2 *__restrict__ tw, int T, int lane)
+{
+    const int lg = 31 - __clz(h);
+    int L = h;
+    if (lg & 1) {
+        const int q = h >> 1, ts = T / h;
+        for (int j = lane; j < q; j += 64) {
+            const int s0 = dif_slot(j), s1 = dif_slot(j + q);
+            const float2 a = x[s0], b = x[s1];
+            float2 w = tw[j * ts];
+            if (SIGN > 0) w.y = -w.y;
+            x[s0] = cadd(a, b);
+            x[s1] = cmul(csub(a, b), w);
+        }
+        wave_lds_sync();
+        L = q;
+    }
+    for (; L >= 4; L >>= 2) {
+        const int q = L >> 2, ts = T / L;
+        // four butterflies per lane at a time: their 16 reads (and 12 twiddles) are in flight together
+        for (int idx0 = lane; idx0 < (h >> 2); idx0 += 256) {
+            int sl[4][4], jj[4];
+            float2 v[4][4], w[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = min(idx0 + 64 * u, (h >> 2) - 1);       // a transform shorter than 1024: duplicates, stored once
+                const int j = idx & (q - 1), base = ((idx - j) << 2) + j;
+                jj[u] = j;
+#pragma unroll
+                for (int m = 0; m < 4; m++) { sl[u][m] = dif_slot(base + m * q); v[u][m] = x[sl[u][m]]; }
+#pragma unroll
+                for (int m = 1; m < 4; m++) w[u][m - 1] = tw[m * j * ts];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dft4<SIGN>(v[u][0], v[u][1], v[u][2], v[u][3]);
+#pragma unroll
+                for (int m = 1; m < 4; m++) {
+                    float2 ww = w[u][m - 1];
+                    if (SIGN > 0) ww.y = -ww.y;
+                    v[u][m] = cmul(v[u][m], ww);          // j = 0: ww = 1
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (idx0 + 64 * u < (h >> 2)) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) x[sl[u][m]] = v[u][m];
+                }
+            (void)jj;
+        }
+        wave_lds_sync();
+    }
+}
+// frequency index held at position p of a wave_fft_dif output of h points, and its inverse
+__device__ __forceinline__ int dif_index_of_pos(int p, int h)
+{
+    int bits = 31 - __clz(h), k = 0, sh = 0;
+    if (bits & 1) { bits--; k = (p >> bits) & 1; sh = 1; }
+    while (bits > 0) { bits -= 2; k |= ((p >> bits) & 3) << sh; sh += 2; }
+    return k;
+}
+__device__ __forceinline__ int dif_pos_of_index(int k, int h)
+{
+    int bits = 31 - __clz(h), p = 0;
+    if (bits & 1) { bits--; p = (k & 1) << bits; k >>= 1; }
+    while (bits > 0) { bits -= 2; p |= (k & 3) << bits; k >>= 2; }
+    return p;
+}
 // real-FFT split step: bin k (0..h) of the n = 2h point real transform from the h-point complex
 // transform Z of the packed sequence z_m = x_2m + i x_2m+1
 __device__ __forceinline__ float2 split_bin(const float2 *Z, int k, int h, float2 w)
@@ -173,11 +252,14 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     }
 }
 
-// Crosrng_ms for an 8 (particle-offset) x 8 (reference) tile at any maxrin; persistent workgroups
-// walk the m-tiles.  zscr: [gridDim.x][N][64] complex scratch (stays in L2 / Infinity Cache);
-// P = pairs transformed per LDS batch (power of two, 2 * P * (N + 1) complex fit the dynamic LDS).
+// Crosrng_ms at any maxrin.  A workgroup contracts a 2 x 2 block of 8 (particle-offset) x 8 (reference) tiles at a time:
+// every A and B operand it fetches feeds two 16x16x4 MFMA tiles (the kernel is bound by the operand stream from HBM /
+// Infinity Cache, so the block size sets its speed); persistent workgroups walk the blocks.
+// zscr: [gridDim.x][N][256] complex scratch for the CCF spectra of the block (they do not fit LDS at maxrin >= 512);
+// P = pairs transformed per LDS batch (power of two, P * (N + 1) complex fit the dynamic LDS), in place.
 // stats [n_mtile * 8] {avg, 1/sigma} of every particle-offset (polar_generic_kernel), cdc [nref] = sum_r n_r C_r(0).
-__global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
+#define RA_GCCF_ZPAIRS 256
+__global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
                                                                       float2 *__restrict__ zscr, int P,
@@ -188,138 +270,186 @@ __global__ __launch_bounds__(RA_GCCF_THREADS) void ccf_generic_kernel(DevGeom g,
     const int N = g.maxrin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_GCCF_THREADS / 64;
-    float2 *zs = zscr + (size_t)blockIdx.x * 64 * N;
+    float2 *zs = zscr + (size_t)blockIdx.x * RA_GCCF_ZPAIRS * N;
     float2 *xb = reinterpret_cast<float2 *>(lds);
-    const int pstride = 2 * N + 1;          // complex slots per pair: two N-point buffers + 1 (bank skew)
+    const int pstride = N + 1;              // complex slots per pair: one N-point buffer (in-place transform) + 1 (bank skew)
     float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
     for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
     __syncthreads();
 
-    for (int mtile = blockIdx.x; mtile < n_mtile; mtile += gridDim.x) {
-        for (int rtile = 0; rtile < nrtile; rtile++) {
-            const int ref0 = rtile * g.rpt;
-            const int nvalid = min(g.rpt, nref - ref0);
-            // ---- phase 1: contraction per Fourier bin (same operand layout as ccf_kernel)
+    const int n_mt2 = (n_mtile + 1) >> 1, n_rt2 = (nrtile + 1) >> 1;
+    for (int mt2 = blockIdx.x; mt2 < n_mt2; mt2 += gridDim.x) {
+        for (int rt2 = 0; rt2 < n_rt2; rt2++) {
+            // ---- phase 1: contraction per Fourier bin (operand layout of ccf_kernel), 2 x 2 tiles per operand fetch
             if (!RA_DBG(g, 2)) {
                 const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
-                const float *Ablk = A + (size_t)(2 * mtile + (r16 >> 3)) * g.a_blk;
-                const float *Bt = B + (size_t)rtile * g.LBP * 16;
                 const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);      // offset-in-tile * 8 + reference slot
                 const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
+                const float *Ab[2], *Bb[2];
+                float dcw[2][2];
+#pragma unroll
+                for (int ai = 0; ai < 2; ai++)          // a tile past the end repeats the last one: its spectra are never transformed
+                    Ab[ai] = A + (size_t)(2 * min(2 * mt2 + ai, n_mtile - 1) + (r16 >> 3)) * g.a_blk;
+#pragma unroll
+                for (int bi = 0; bi < 2; bi++) Bb[bi] = B + (size_t)min(2 * rt2 + bi, nrtile - 1) * g.LBP * 16;
                 // Normalize_ring mean of this lane's particle-offset times the DC weight of its reference (bin 0 only)
-                const float dcw = stats[(size_t)mtile * 8 + (pair >> 3)].x * cdc[min(ref0 + (pair & 7), nref - 1)];
+#pragma unroll
+                for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+                    for (int bi = 0; bi < 2; bi++)
+                        dcw[ai][bi] = stats[(size_t)min(2 * mt2 + ai, n_mtile - 1) * 8 + (pair >> 3)].x *
+                                      cdc[min(min(2 * rt2 + bi, nrtile - 1) * g.rpt + (pair & 7), nref - 1)];
                 for (int k = wave; k < g.nbins; k += NW) {
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
-                    const float *pa = Ablk + (size_t)e0 * 8, *pb = Bt + (size_t)e0 * 16;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *pa0 = Ab[0] + (size_t)e0 * 8, *pa1 = Ab[1] + (size_t)e0 * 8;
+                    const float *pb0 = Bb[0] + (size_t)e0 * 16, *pb1 = Bb[1] + (size_t)e0 * 16;
+                    f32x4 acc[2][2];
+#pragma unroll
+                    for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+                        for (int bi = 0; bi < 2; bi++) acc[ai][bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     int oa = 0, ob = 0;
                     const int nq = ns >> 2;
                     if (nq > 0) {      // chunks of 4 ring steps, the next chunk's operands in flight while this one multiplies
-                        float4 va = *reinterpret_cast<const float4 *>(pa + la * 4);
-                        float4 vb = *reinterpret_cast<const float4 *>(pb + lb * 4);
+                        float4 va0 = *reinterpret_cast<const float4 *>(pa0 + la * 4), va1 = *reinterpret_cast<const float4 *>(pa1 + la * 4);
+                        float4 vb0 = *reinterpret_cast<const float4 *>(pb0 + lb * 4), vb1 = *reinterpret_cast<const float4 *>(pb1 + lb * 4);
                         for (int q = 0; q < nq; q++) {
-                            float4 na = va, nb = vb;
+                            float4 na0 = va0, na1 = va1, nb0 = vb0, nb1 = vb1;
                             if (q + 1 < nq) {
-                                na = *reinterpret_cast<const float4 *>(pa + oa + 128 + la * 4);
-                                nb = *reinterpret_cast<const float4 *>(pb + ob + 256 + lb * 4);
+                                na0 = *reinterpret_cast<const float4 *>(pa0 + oa + 128 + la * 4); na1 = *reinterpret_cast<const float4 *>(pa1 + oa + 128 + la * 4);
+                                nb0 = *reinterpret_cast<const float4 *>(pb0 + ob + 256 + lb * 4); nb1 = *reinterpret_cast<const float4 *>(pb1 + ob + 256 + lb * 4);
                             }
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc, 0, 0, 0);
-                            va = na; vb = nb;
+#define RA_G_STEP(C)                                                                                   \
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.C, vb0.C, acc[0][0], 0, 0, 0); \
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.C, vb1.C, acc[0][1], 0, 0, 0); \
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.C, vb0.C, acc[1][0], 0, 0, 0); \
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.C, vb1.C, acc[1][1], 0, 0, 0);
+                            RA_G_STEP(x) RA_G_STEP(y) RA_G_STEP(z) RA_G_STEP(w)
+#undef RA_G_STEP
+                            va0 = na0; va1 = na1; vb0 = nb0; vb1 = nb1;
                             oa += 128; ob += 256;
                         }
                     }
                     if (ns & 2) {
-                        const float2 va = *reinterpret_cast<const float2 *>(pa + oa + la * 2);
-                        const float2 vb = *reinterpret_cast<const float2 *>(pb + ob + lb * 2);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc, 0, 0, 0);
+                        const float2 wa0 = *reinterpret_cast<const float2 *>(pa0 + oa + la * 2), wa1 = *reinterpret_cast<const float2 *>(pa1 + oa + la * 2);
+                        const float2 wb0 = *reinterpret_cast<const float2 *>(pb0 + ob + lb * 2), wb1 = *reinterpret_cast<const float2 *>(pb1 + ob + lb * 2);
+#define RA_G_STEP(C)                                                                                   \
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.C, wb0.C, acc[0][0], 0, 0, 0); \
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.C, wb1.C, acc[0][1], 0, 0, 0); \
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.C, wb0.C, acc[1][0], 0, 0, 0); \
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.C, wb1.C, acc[1][1], 0, 0, 0);
+                        RA_G_STEP(x) RA_G_STEP(y)
+#undef RA_G_STEP
                         oa += 64; ob += 128;
                     }
-                    if (ns & 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[oa + la], pb[ob + lb], acc, 0, 0, 0);
+                    if (ns & 1) {
+                        const float sa0 = pa0[oa + la], sa1 = pa1[oa + la];
+                        const float sb0 = pb0[ob + lb], sb1 = pb1[ob + lb];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa0, sb0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa0, sb1, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa1, sb0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa1, sb1, acc[1][1], 0, 0, 0);
+                    }
                     // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
-                    const float s0 = odd ? acc[0] : acc[2], s1 = odd ? acc[1] : acc[3];
-                    const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                    const float ca = (odd ? r0 : acc[0]) - (k == 0 ? dcw : 0.f), cb = odd ? r1 : acc[1];
-                    const float cc = odd ? acc[2] : r0, cd = odd ? acc[3] : r1;
-                    const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
-                    zs[(size_t)k * 64 + pair] = make_float2(apd + bpc, cmb + amd);
-                    zs[(size_t)((N - k) & (N - 1)) * 64 + pair] = make_float2(apd - bpc, amd - cmb);
+#pragma unroll
+                    for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+                        for (int bi = 0; bi < 2; bi++) {
+                            const f32x4 c4 = acc[ai][bi];
+                            const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
+                            const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
+                            const float ca = (odd ? r0 : c4[0]) - (k == 0 ? dcw[ai][bi] : 0.f), cb = odd ? r1 : c4[1];
+                            const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
+                            const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                            const int zp = (2 * ai + bi) * 64 + pair;
+                            zs[(size_t)k * RA_GCCF_ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
+                            zs[(size_t)((N - k) & (N - 1)) * RA_GCCF_ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
+                        }
                 }
             }
             __syncthreads();
-            // ---- phase 2: inverse FFT + argmax, P pairs per batch, one wave per pair
-            if (RA_DBG(g, ~0) && tid < 64) {   // profiling builds that skip a phase still emit in-range records
-                pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
-                for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
-            }
-            if (!RA_DBG(g, 1))
-            for (int base = 0; base < 64; base += P) {
-                // scratch [k][64 pairs] -> LDS [pair][k]: 8 independent loads per thread in flight
-                for (int idx0 = tid; idx0 < P * N; idx0 += 8 * RA_GCCF_THREADS) {
-                    float2 t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int idx = idx0 + u * RA_GCCF_THREADS;
-                        if (idx < P * N) { const int k = idx / P, pp = idx - k * P; t[u] = zs[(size_t)k * 64 + base + pp]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int idx = idx0 + u * RA_GCCF_THREADS;
-                        if (idx < P * N) { const int k = idx / P, pp = idx - k * P; xb[(size_t)pp * pstride + k] = t[u]; }
-                    }
+            // ---- phase 2: inverse FFT + argmax tile by tile, P pairs per batch, one wave per pair
+            for (int sub = 0; sub < 4; sub++) {
+                const int mtile = 2 * mt2 + (sub >> 1), rtile = 2 * rt2 + (sub & 1);
+                if (mtile >= n_mtile || rtile >= nrtile) continue;          // uniform over the workgroup
+                const int ref0 = rtile * g.rpt;
+                const int nvalid = min(g.rpt, nref - ref0);
+                if (RA_DBG(g, ~0) && tid < 64) {   // profiling builds that skip a phase still emit in-range records
+                    pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = min(ref0 + (tid & 7), nref - 1);
+                    for (int k = 0; k < 7; k++) pc[tid].t7[k] = 0.f;
                 }
-                __syncthreads();
-                for (int pp = wave; pp < P; pp += NW) {
-                    const int pair = base + pp, slot = pair & 7;
-                    if (slot >= nvalid) continue;           // wave-uniform
-                    float2 *x = xb + (size_t)pp * pstride;
-                    const float2 *r = wave_fft<1>(x, x + N, N, tw_s, N, lane);
-                    float bq = -1.0e20f, bt = -1.0e20f;
-                    int iq = 0, it = 0;
-                    for (int j = lane; j < N; j += 64) {     // ascending: ">=" keeps the last maximum
-                        const float2 v = r[j];
-                        if (v.x >= bq) { bq = v.x; iq = j; }
-                        if (v.y >= bt) { bt = v.y; it = j; }
-                    }
+                if (!RA_DBG(g, 1))
+                for (int base = 0; base < 64; base += P) {
+                    // scratch [k][256 pairs] -> LDS [pair][k]: 8 independent loads per thread in flight
+                    for (int idx0 = tid; idx0 < P * N; idx0 += 8 * RA_GCCF_THREADS) {
+                        float2 t[8];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float oq = __shfl_xor(bq, o); const int oiq = __shfl_xor(iq, o);
-                        const float ot = __shfl_xor(bt, o); const int oit = __shfl_xor(it, o);
-                        if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
-                        if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
-                    }
-                    {
-                        const bool mir = !g.nomirror && !(bq >= bt);        // qn >= qm keeps the straight match; nomirror: straight only
-                        const int jt = mir ? it : iq;
-                        CandT *dst = pc + pair;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
-                        if (lane < 7) {
-                            const float2 zz = r[(jt + lane - 3 + N) & (N - 1)];
-                            dst->t7[lane] = mir ? zz.y : zz.x;
+                        for (int u = 0; u < 8; u++) {
+                            const int idx = idx0 + u * RA_GCCF_THREADS;
+                            if (idx < P * N) { const int k = idx / P, pp = idx - k * P; t[u] = zs[(size_t)k * RA_GCCF_ZPAIRS + sub * 64 + base + pp]; }
                         }
-                        if (lane == 0) {
-                            dst->val = mir ? bt : bq; dst->jtot = jt + 1; dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + slot);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int idx = idx0 + u * RA_GCCF_THREADS;
+                            if (idx < P * N) { const int k = idx / P, pp = idx - k * P; xb[(size_t)pp * pstride + dif_slot(k)] = t[u]; }
                         }
                     }
+                    __syncthreads();
+                    for (int pp = wave; pp < P; pp += NW) {
+                        const int pair = base + pp, slot = pair & 7;
+                        if (slot >= nvalid) continue;           // wave-uniform
+                        float2 *x = xb + (size_t)pp * pstride;
+                        wave_fft_dif<1>(x, N, tw_s, N, lane);
+                        // position p = 64 i + lane holds angle index khi(i) + (N / 64) * klane (N >= 64: the low six bits of
+                        // p are three radix-4 digits); the scan order is arbitrary, so ties go by the index: the last wins
+                        const int klane = ((lane >> 4) & 3) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+                        float bq = -1.0e20f, bt = -1.0e20f;
+                        int iq = -1, it = -1;
+                        for (int p0 = 0; p0 < N; p0 += 64) {
+                            if (p0 + lane < N) {
+                                const float2 v = x[dif_slot(p0 + lane)];
+                                const int kx = N >= 64 ? dif_index_of_pos(p0, N) + (N >> 6) * klane : dif_index_of_pos(p0 + lane, N);
+                                if (v.x > bq || (v.x == bq && kx > iq)) { bq = v.x; iq = kx; }
+                                if (v.y > bt || (v.y == bt && kx > it)) { bt = v.y; it = kx; }
+                            }
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const float oq = __shfl_xor(bq, o); const int oiq = __shfl_xor(iq, o);
+                            const float ot = __shfl_xor(bt, o); const int oit = __shfl_xor(it, o);
+                            if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
+                            if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
+                        }
+                        {
+                            const bool mir = !g.nomirror && !(bq >= bt);        // qn >= qm keeps the straight match; nomirror: straight only
+                            const int jt = mir ? it : iq;
+                            CandT *dst = pc + pair;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
+                            if (lane < 7) {
+                                const float2 zz = x[dif_slot(dif_pos_of_index((jt + lane - 3 + N) & (N - 1), N))];
+                                dst->t7[lane] = mir ? zz.y : zz.x;
+                            }
+                            if (lane == 0) {
+                                dst->val = mir ? bt : bq; dst->jtot = jt + 1; dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + slot);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins), dword-wise copy
+                if (tid < 8 * (int)(sizeof(CandT) / 4)) {
+                    constexpr int W = sizeof(CandT) / 4;
+                    const int o = tid / W, wd = tid - o * W;
+                    float bv = pc[o * 8].val; int br = 0;
+                    for (int rr = 1; rr < nvalid; rr++) {
+                        const float v = pc[o * 8 + rr].val;
+                        if (v >= bv) { bv = v; br = rr; }
+                    }
+                    int word = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
+                    if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * stats[(size_t)mtile * 8 + o].y);     // val, t7[] * 1/sigma
+                    reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = word;
                 }
                 __syncthreads();
             }
-            // ---- best reference of the tile per particle-offset (ascending ref, ">=": later wins), dword-wise copy
-            if (tid < 8 * (int)(sizeof(CandT) / 4)) {
-                constexpr int W = sizeof(CandT) / 4;
-                const int o = tid / W, wd = tid - o * W;
-                float bv = pc[o * 8].val; int br = 0;
-                for (int rr = 1; rr < nvalid; rr++) {
-                    const float v = pc[o * 8 + rr].val;
-                    if (v >= bv) { bv = v; br = rr; }
-                }
-                int word = reinterpret_cast<const int *>(pc + o * 8 + br)[wd];
-                if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * stats[(size_t)mtile * 8 + o].y);     // val, t7[] * 1/sigma
-                reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[wd] = word;
-            }
-            __syncthreads();
         }
     }
 }
