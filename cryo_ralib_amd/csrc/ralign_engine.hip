@@ -63,7 +63,7 @@ struct ra_engine {
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
-    float2 *d_zscr = nullptr;           // [g_nblk][maxrin][256] CCF spectra scratch of ccf_generic_kernel
+    float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
     float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic and fused paths)
     int g_nblk = 0, g_P = 0;
@@ -762,7 +762,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
         if (e->generic)
-            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
+            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min((n_mtile + RA_GCCF_TM - 1) / RA_GCCF_TM, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);
         else

@@ -22,6 +22,8 @@
 namespace ralign {
 
 #define RA_GEN_THREADS 256
+
+__device__ __forceinline__ float rf4(const float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 #define RA_GCCF_THREADS 512
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -252,13 +254,15 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     }
 }
 
-// Crosrng_ms at any maxrin.  A workgroup contracts a 2 x 2 block of 8 (particle-offset) x 8 (reference) tiles at a time:
-// every A and B operand it fetches feeds two 16x16x4 MFMA tiles (the kernel is bound by the operand stream from HBM /
+// Crosrng_ms at any maxrin.  A workgroup contracts a TM x TR block of 8 (particle-offset) x 8 (reference) tiles at a time:
+// every A operand it fetches feeds TR and every B operand TM 16x16x4 MFMA tiles (the kernel is bound by the operand stream from HBM /
 // Infinity Cache, so the block size sets its speed); persistent workgroups walk the blocks.
-// zscr: [gridDim.x][N][256] complex scratch for the CCF spectra of the block (they do not fit LDS at maxrin >= 512);
+// zscr: [gridDim.x][N][64 TM TR] complex scratch for the CCF spectra of the block (they do not fit LDS at maxrin >= 512);
 // P = pairs transformed per LDS batch (power of two, P * (N + 1) complex fit the dynamic LDS), in place.
 // stats [n_mtile * 8] {avg, 1/sigma} of every particle-offset (polar_generic_kernel), cdc [nref] = sum_r n_r C_r(0).
-#define RA_GCCF_ZPAIRS 256
+#define RA_GCCF_TM 2        // tiles of 8 particle-offsets per block
+#define RA_GCCF_TR 2        // tiles of 8 references per block (4: contraction 25 instead of 28 ms at 100 references, twice the scratch)
+#define RA_GCCF_ZPAIRS (64 * RA_GCCF_TM * RA_GCCF_TR)
 __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
@@ -277,91 +281,108 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
     for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
     __syncthreads();
 
-    const int n_mt2 = (n_mtile + 1) >> 1, n_rt2 = (nrtile + 1) >> 1;
+    constexpr int TM = RA_GCCF_TM, TR = RA_GCCF_TR;
+    const int n_mt2 = (n_mtile + TM - 1) / TM, n_rt2 = (nrtile + TR - 1) / TR;
     for (int mt2 = blockIdx.x; mt2 < n_mt2; mt2 += gridDim.x) {
         for (int rt2 = 0; rt2 < n_rt2; rt2++) {
-            // ---- phase 1: contraction per Fourier bin (operand layout of ccf_kernel), 2 x 2 tiles per operand fetch
+            // ---- phase 1: contraction per Fourier bin (operand layout of ccf_kernel), TM x TR tiles per operand fetch
             if (!RA_DBG(g, 2)) {
                 const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
                 const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);      // offset-in-tile * 8 + reference slot
                 const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
-                const float *Ab[2], *Bb[2];
-                float dcw[2][2];
+                const float *Ab[TM], *Bb[TR];
+                float dcw[TM][TR];
 #pragma unroll
-                for (int ai = 0; ai < 2; ai++)          // a tile past the end repeats the last one: its spectra are never transformed
-                    Ab[ai] = A + (size_t)(2 * min(2 * mt2 + ai, n_mtile - 1) + (r16 >> 3)) * g.a_blk;
+                for (int ai = 0; ai < TM; ai++)          // a tile past the end repeats the last one: its spectra are never transformed
+                    Ab[ai] = A + (size_t)(2 * min(TM * mt2 + ai, n_mtile - 1) + (r16 >> 3)) * g.a_blk;
 #pragma unroll
-                for (int bi = 0; bi < 2; bi++) Bb[bi] = B + (size_t)min(2 * rt2 + bi, nrtile - 1) * g.LBP * 16;
+                for (int bi = 0; bi < TR; bi++) Bb[bi] = B + (size_t)min(TR * rt2 + bi, nrtile - 1) * g.LBP * 16;
                 // Normalize_ring mean of this lane's particle-offset times the DC weight of its reference (bin 0 only)
 #pragma unroll
-                for (int ai = 0; ai < 2; ai++)
+                for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                    for (int bi = 0; bi < 2; bi++)
-                        dcw[ai][bi] = stats[(size_t)min(2 * mt2 + ai, n_mtile - 1) * 8 + (pair >> 3)].x *
-                                      cdc[min(min(2 * rt2 + bi, nrtile - 1) * g.rpt + (pair & 7), nref - 1)];
+                    for (int bi = 0; bi < TR; bi++)
+                        dcw[ai][bi] = stats[(size_t)min(TM * mt2 + ai, n_mtile - 1) * 8 + (pair >> 3)].x *
+                                      cdc[min(min(TR * rt2 + bi, nrtile - 1) * g.rpt + (pair & 7), nref - 1)];
                 for (int k = wave; k < g.nbins; k += NW) {
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
-                    const float *pa0 = Ab[0] + (size_t)e0 * 8, *pa1 = Ab[1] + (size_t)e0 * 8;
-                    const float *pb0 = Bb[0] + (size_t)e0 * 16, *pb1 = Bb[1] + (size_t)e0 * 16;
-                    f32x4 acc[2][2];
+                    const float *pa[TM], *pb[TR];
 #pragma unroll
-                    for (int ai = 0; ai < 2; ai++)
+                    for (int ai = 0; ai < TM; ai++) pa[ai] = Ab[ai] + (size_t)e0 * 8;
 #pragma unroll
-                        for (int bi = 0; bi < 2; bi++) acc[ai][bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int bi = 0; bi < TR; bi++) pb[bi] = Bb[bi] + (size_t)e0 * 16;
+                    f32x4 acc[TM][TR];
+#pragma unroll
+                    for (int ai = 0; ai < TM; ai++)
+#pragma unroll
+                        for (int bi = 0; bi < TR; bi++) acc[ai][bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     int oa = 0, ob = 0;
                     const int nq = ns >> 2;
                     if (nq > 0) {      // chunks of 4 ring steps, the next chunk's operands in flight while this one multiplies
-                        float4 va0 = *reinterpret_cast<const float4 *>(pa0 + la * 4), va1 = *reinterpret_cast<const float4 *>(pa1 + la * 4);
-                        float4 vb0 = *reinterpret_cast<const float4 *>(pb0 + lb * 4), vb1 = *reinterpret_cast<const float4 *>(pb1 + lb * 4);
+                        float4 va[TM], vb[TR], na[TM], nb[TR];
+#pragma unroll
+                        for (int ai = 0; ai < TM; ai++) va[ai] = *reinterpret_cast<const float4 *>(pa[ai] + la * 4);
+#pragma unroll
+                        for (int bi = 0; bi < TR; bi++) vb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + lb * 4);
                         for (int q = 0; q < nq; q++) {
-                            float4 na0 = va0, na1 = va1, nb0 = vb0, nb1 = vb1;
-                            if (q + 1 < nq) {
-                                na0 = *reinterpret_cast<const float4 *>(pa0 + oa + 128 + la * 4); na1 = *reinterpret_cast<const float4 *>(pa1 + oa + 128 + la * 4);
-                                nb0 = *reinterpret_cast<const float4 *>(pb0 + ob + 256 + lb * 4); nb1 = *reinterpret_cast<const float4 *>(pb1 + ob + 256 + lb * 4);
-                            }
-#define RA_G_STEP(C)                                                                                   \
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.C, vb0.C, acc[0][0], 0, 0, 0); \
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.C, vb1.C, acc[0][1], 0, 0, 0); \
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.C, vb0.C, acc[1][0], 0, 0, 0); \
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.C, vb1.C, acc[1][1], 0, 0, 0);
-                            RA_G_STEP(x) RA_G_STEP(y) RA_G_STEP(z) RA_G_STEP(w)
-#undef RA_G_STEP
-                            va0 = na0; va1 = na1; vb0 = nb0; vb1 = nb1;
+                            const int step = q + 1 < nq ? 1 : 0;       // the last chunk re-requests itself (discarded)
+#pragma unroll
+                            for (int ai = 0; ai < TM; ai++) na[ai] = *reinterpret_cast<const float4 *>(pa[ai] + oa + step * 128 + la * 4);
+#pragma unroll
+                            for (int bi = 0; bi < TR; bi++) nb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + ob + step * 256 + lb * 4);
+#pragma unroll
+                            for (int c = 0; c < 4; c++)
+#pragma unroll
+                                for (int ai = 0; ai < TM; ai++)
+#pragma unroll
+                                    for (int bi = 0; bi < TR; bi++)
+                                        acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf4(va[ai], c), rf4(vb[bi], c), acc[ai][bi], 0, 0, 0);
+#pragma unroll
+                            for (int ai = 0; ai < TM; ai++) va[ai] = na[ai];
+#pragma unroll
+                            for (int bi = 0; bi < TR; bi++) vb[bi] = nb[bi];
                             oa += 128; ob += 256;
                         }
                     }
                     if (ns & 2) {
-                        const float2 wa0 = *reinterpret_cast<const float2 *>(pa0 + oa + la * 2), wa1 = *reinterpret_cast<const float2 *>(pa1 + oa + la * 2);
-                        const float2 wb0 = *reinterpret_cast<const float2 *>(pb0 + ob + lb * 2), wb1 = *reinterpret_cast<const float2 *>(pb1 + ob + lb * 2);
-#define RA_G_STEP(C)                                                                                   \
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.C, wb0.C, acc[0][0], 0, 0, 0); \
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0.C, wb1.C, acc[0][1], 0, 0, 0); \
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.C, wb0.C, acc[1][0], 0, 0, 0); \
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1.C, wb1.C, acc[1][1], 0, 0, 0);
-                        RA_G_STEP(x) RA_G_STEP(y)
-#undef RA_G_STEP
+                        float2 wa[TM], wb[TR];
+#pragma unroll
+                        for (int ai = 0; ai < TM; ai++) wa[ai] = *reinterpret_cast<const float2 *>(pa[ai] + oa + la * 2);
+#pragma unroll
+                        for (int bi = 0; bi < TR; bi++) wb[bi] = *reinterpret_cast<const float2 *>(pb[bi] + ob + lb * 2);
+#pragma unroll
+                        for (int ai = 0; ai < TM; ai++)
+#pragma unroll
+                            for (int bi = 0; bi < TR; bi++) {
+                                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ai].x, wb[bi].x, acc[ai][bi], 0, 0, 0);
+                                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ai].y, wb[bi].y, acc[ai][bi], 0, 0, 0);
+                            }
                         oa += 64; ob += 128;
                     }
                     if (ns & 1) {
-                        const float sa0 = pa0[oa + la], sa1 = pa1[oa + la];
-                        const float sb0 = pb0[ob + lb], sb1 = pb1[ob + lb];
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa0, sb0, acc[0][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa0, sb1, acc[0][1], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa1, sb0, acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa1, sb1, acc[1][1], 0, 0, 0);
+                        float sa[TM], sb[TR];
+#pragma unroll
+                        for (int ai = 0; ai < TM; ai++) sa[ai] = pa[ai][oa + la];
+#pragma unroll
+                        for (int bi = 0; bi < TR; bi++) sb[bi] = pb[bi][ob + lb];
+#pragma unroll
+                        for (int ai = 0; ai < TM; ai++)
+#pragma unroll
+                            for (int bi = 0; bi < TR; bi++)
+                                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ai], sb[bi], acc[ai][bi], 0, 0, 0);
                     }
                     // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
 #pragma unroll
-                    for (int ai = 0; ai < 2; ai++)
+                    for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                        for (int bi = 0; bi < 2; bi++) {
+                        for (int bi = 0; bi < TR; bi++) {
                             const f32x4 c4 = acc[ai][bi];
                             const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
                             const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
                             const float ca = (odd ? r0 : c4[0]) - (k == 0 ? dcw[ai][bi] : 0.f), cb = odd ? r1 : c4[1];
                             const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
                             const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
-                            const int zp = (2 * ai + bi) * 64 + pair;
+                            const int zp = (TR * ai + bi) * 64 + pair;
                             zs[(size_t)k * RA_GCCF_ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
                             zs[(size_t)((N - k) & (N - 1)) * RA_GCCF_ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
                         }
@@ -369,8 +390,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
             }
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax tile by tile, P pairs per batch, one wave per pair
-            for (int sub = 0; sub < 4; sub++) {
-                const int mtile = 2 * mt2 + (sub >> 1), rtile = 2 * rt2 + (sub & 1);
+            for (int sub = 0; sub < TM * TR; sub++) {
+                const int mtile = TM * mt2 + sub / TR, rtile = TR * rt2 + sub % TR;
                 if (mtile >= n_mtile || rtile >= nrtile) continue;          // uniform over the workgroup
                 const int ref0 = rtile * g.rpt;
                 const int nvalid = min(g.rpt, nref - ref0);
