@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
@@ -322,6 +323,10 @@ def main():
         kern_ms = sum(k["avg_launch_ms"] * k["launches"] for k in kernels.values())
         traffic_pp, traffic_src = committed_traffic(dom.split("<")[0], args.workload)
         whole = (polar_f + ccf_f) * total / world / dt / 1e12
+        # measured HBM rate of the dominant kernel (committed PMC bytes per particle / live launch time) beside its flop rate:
+        # whichever fraction of its peak is larger names the bound (the large-box contraction streams operand panels)
+        hbm_gbps = traffic_pp * per_launch / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9 if traffic_pp is not None else None
+        hbm_frac = hbm_gbps / PEAK_HBM_GBPS if hbm_gbps is not None else None
         what = ("%s: %d synthetic %dx%d particles per GPU, %s, xr=yr=%g, ts=1, ou=%d; step = one %s iteration (search + rot_shift2D + "
                 "class sums + all-reduce + reference update with --function=%s)") % (
                    "BASELINE " + args.config_name if (args.nx, args.ou, args.xr, args.nref) == WORKLOADS[args.workload][1:5] else "custom",
@@ -334,8 +339,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world,
                        "search_path": {0: "kernel pair", 1: "fused", 2: "generic"}[path]},
-            "roofline": {"bound": "mfma", "achieved": kernels[dom]["achieved_tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kernels[dom]["frac"],
+            "roofline": {"bound": "hbm" if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else "mfma",
+                         "achieved": hbm_gbps if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else kernels[dom]["achieved_tflops"],
+                         "peak": PEAK_HBM_GBPS if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else PEAK_F32_TFLOPS,
+                         "unit": "GB/s" if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else "TFLOP/s",
+                         "frac": max(kernels[dom]["frac"], hbm_frac or 0.0),
+                         "mfma_frac": kernels[dom]["frac"], "hbm_gbps": hbm_gbps, "hbm_frac": hbm_frac,
                          "traffic": traffic_pp * per_launch if traffic_pp is not None else None,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE per particle x particles per launch)",
                          "traffic_per_particle": traffic_pp, "traffic_source": traffic_src,
