@@ -121,7 +121,7 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     if (g.nring > 64) return false;
     for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
     f.gstr = 4 * ((g.nring + 3) / 4) + 4;
-    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + 8 * (g.nring + 8) + 64;
+    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + 8 * (g.nring + 8) + RF_MAXREF + 64;
     out.lds_bytes = fl * sizeof(float);
     f.on = out.lds_bytes <= 160 * 1024 && 4 * f.rz * zstride <= 4 * sbuf;
     return f.on != 0;
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     float2 *tws = reinterpret_cast<float2 *>(red + 24 + 8 * g.nring + ((g.n_inst + 8 * g.nring) & 1));   // [R1*R2] inverse-FFT twiddles
     CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);              // [4][nref] records of the pass
     int *goff_s = reinterpret_cast<int *>(pc + 4 * RF_MAXREF + 4);     // [ng][gstr] ring offsets (bytes) of every group's ring quads
+    float *cdc_s = reinterpret_cast<float *>(goff_s + f.ng * f.gstr);      // [RF_MAXREF] DC weights of the references
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // tables and the ring-buffer slack are set up once per workgroup; the workgroup then walks over its particles
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         tws[i] = make_float2(t.x, -t.y);
     }
     for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;      // slack between rings must hold finite values
+    for (int i = tid; i < RF_MAXREF; i += RF_THREADS) cdc_s[i] = i < nref ? f.cdc_w[i] : 0.f;
     for (int i = tid; i < f.ng * f.gstr; i += RF_THREADS) {
         const int m = i / f.gstr, j = i - m * f.gstr;
         goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const float cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
                 if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz && o < nlive) {
                     float cdc = 0.f;
-                    if (xm == 0 && xb == 0) cdc = red[8 + o] * f.cdc_w[ref];       // Normalize_ring mean: the DC term only
+                    if (xm == 0 && xb == 0) cdc = red[8 + o] * cdc_s[ref];       // Normalize_ring mean: the DC term only
                     rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca - cdc, cb, cc, cd);
                 }
             }
