@@ -939,7 +939,15 @@ extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_coun
         RA_HIP(hipGetLastError());
     }
     if ((rc = forward_dft(e, d_sums, 2 * R, masked ? e->dg.mask : nullptr, masked ? e->d_rfmean : nullptr))) return rc;
-    hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(64), 0, e->stream, nx, e->d_rfF, e->d_rffsc);
+    {
+        // as many row parts per shell as 1024 threads and 60 KB of LDS allow
+        const int len = nx / 2 + 1;
+        int nparts = std::max(1, RA_FSC_THREADS / len);
+        while (nparts > 1 && (size_t)nparts * len * 4 * sizeof(double) > 60 * 1024) nparts--;
+        const int threads = std::min(RA_FSC_THREADS, nparts * len);
+        const size_t lds = (size_t)nparts * len * 4 * sizeof(double);
+        hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(threads), lds, e->stream, nx, e->d_rfF, e->d_rffsc);
+    }
     RA_HIP(hipGetLastError());
     std::vector<float> all((size_t)R * 2 * len);
     std::vector<int> counts(R);

@@ -93,17 +93,26 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(int npix, const float 
     }
 }
 
-// Fourier shell correlation of image pairs (2c, 2c+1): thread r owns shell r.
+// Fourier shell correlation of image pairs (2c, 2c+1).
 // EMData::calc_fourier_shell_correlation, w = 1: shell = round(inc * sqrt((kx/nx2)^2 + (ky/ny2)^2)),
 // inc = nx/2; the kx = 0 column counts ky >= 0 only.  out[c][0][r] = fsc, out[c][1][r] = points.
-__global__ void fsc_kernel(int nx, const double2 *__restrict__ F, float *__restrict__ out)
+// Thread (part, r) sums shell r over the rows of its part in row order, the parts are added in part order: fixed
+// summation order (bitwise reproducible), blockDim / (inc + 1) times shorter than one thread per shell.
+#define RA_FSC_THREADS 1024
+__global__ __launch_bounds__(RA_FSC_THREADS) void fsc_kernel(int nx, const double2 *__restrict__ F, float *__restrict__ out)
 {
+    extern __shared__ double fsc_part[];        // [nparts][len][4]
     const int nxh = nx / 2 + 1, c = blockIdx.x, inc = nx / 2, len = inc + 1;
     const double2 *f = F + (size_t)(2 * c) * nx * nxh, *g = f + (size_t)nx * nxh;
     const float d2 = 1.0f / (float)inc / (float)inc;
-    for (int r = threadIdx.x; r < len; r += blockDim.x) {
+    const int nparts = max(1, (int)blockDim.x / len);
+    const int part = nparts > 1 ? threadIdx.x / len : 0, r0 = threadIdx.x - part * len;
+    const int rstep = nparts > 1 ? len : blockDim.x;        // a single part: the threads stride over the shells
+    if (part < nparts)
+    for (int r = r0; r < len; r += rstep) {
         double ret = 0, n1 = 0, n2 = 0, lr = 0;
-        for (int ky = 0; ky < nx; ky++) {
+        const int ky0 = (int)((long)nx * part / nparts), ky1 = (int)((long)nx * (part + 1) / nparts);
+        for (int ky = ky0; ky < ky1; ky++) {
             const int kys = ky > inc ? ky - nx : ky;
             for (int kx = 0; kx < nxh; kx++) {
                 if (kx == 0 && kys < 0) continue;
@@ -113,6 +122,17 @@ __global__ void fsc_kernel(int nx, const double2 *__restrict__ F, float *__restr
                 const double2 a = f[ky * nxh + kx], b = g[ky * nxh + kx];
                 ret += a.x * b.x + a.y * b.y; n1 += a.x * a.x + a.y * a.y; n2 += b.x * b.x + b.y * b.y; lr += 2;
             }
+        }
+        double *dst = fsc_part + ((size_t)part * len + r) * 4;
+        dst[0] = ret; dst[1] = n1; dst[2] = n2; dst[3] = lr;
+    }
+    __syncthreads();
+    if (part == 0)
+    for (int r = r0; r < len; r += rstep) {
+        double ret = 0, n1 = 0, n2 = 0, lr = 0;
+        for (int q = 0; q < nparts; q++) {
+            const double *src = fsc_part + ((size_t)q * len + r) * 4;
+            ret += src[0]; n1 += src[1]; n2 += src[2]; lr += src[3];
         }
         out[((size_t)c * 2) * len + r] = (lr > 0 && n1 > 0 && n2 > 0) ? (float)(ret / sqrt(n1 * n2)) : 0.f;
         out[((size_t)c * 2 + 1) * len + r] = (float)lr;
