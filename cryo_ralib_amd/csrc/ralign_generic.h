@@ -390,6 +390,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
             }
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax tile by tile, P pairs per batch, one wave per pair
+            const int lgp = 31 - __clz(P);
             for (int sub = 0; sub < TM * TR; sub++) {
                 const int mtile = TM * mt2 + sub / TR, rtile = TR * rt2 + sub % TR;
                 if (mtile >= n_mtile || rtile >= nrtile) continue;          // uniform over the workgroup
@@ -401,18 +402,19 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                 }
                 if (!RA_DBG(g, 1))
                 for (int base = 0; base < 64; base += P) {
-                    // scratch [k][256 pairs] -> LDS [pair][k]: 8 independent loads per thread in flight
+                    // scratch [k][pairs] -> LDS [pair][k]: 8 independent loads per thread in flight (P is a power of two)
+                    const float2 *src = zs + sub * 64 + base;
                     for (int idx0 = tid; idx0 < P * N; idx0 += 8 * RA_GCCF_THREADS) {
                         float2 t[8];
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const int idx = idx0 + u * RA_GCCF_THREADS;
-                            if (idx < P * N) { const int k = idx / P, pp = idx - k * P; t[u] = zs[(size_t)k * RA_GCCF_ZPAIRS + sub * 64 + base + pp]; }
+                            if (idx < P * N) t[u] = src[(size_t)(idx >> lgp) * RA_GCCF_ZPAIRS + (idx & (P - 1))];
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const int idx = idx0 + u * RA_GCCF_THREADS;
-                            if (idx < P * N) { const int k = idx / P, pp = idx - k * P; xb[(size_t)pp * pstride + dif_slot(k)] = t[u]; }
+                            if (idx < P * N) xb[(size_t)(idx & (P - 1)) * pstride + dif_slot(idx >> lgp)] = t[u];
                         }
                     }
                     __syncthreads();

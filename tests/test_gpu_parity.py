@@ -890,7 +890,20 @@ def test_large_box_hundred_references_config4():
     eng.transform_accumulate(tp, res, 0, None, gs, gc)
     eng.sync()
     assert (gc.cpu().numpy() == counts).all()
-    assert_images_close(gs.cpu().numpy(), sums, mask, 2e-5 * np.abs(sums).max() + 1e-4)
+    # class sums: (i) against the oracle's rot_shift2D of the engine's own parameters -- the transform and the
+    # accumulation, free of the conditioning of the sub-bin angle; (ii) against the oracle's sums: with 4 images in
+    # 100 classes a 6e-5 degree difference of one angle (2 ulp of its f32 value) moves a few pixels across quadri's
+    # cell borders, so the bar is the quantile part of assert_images_close
+    got = gs.cpu().numpy()
+    want = np.zeros_like(sums)
+    for i in range(n):
+        want[int(r["ref_id"][i]), i & 1] += orc.rot_shift2d(parts[i], float(r["alpha"][i]), float(r["sx"][i]), float(r["sy"][i]),
+                                                            int(r["mirror"][i]))
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    diff = np.abs(got - sums)
+    sel = np.broadcast_to(mask > 0.5, diff.shape)
+    assert np.quantile(diff[sel], 0.999) < 2e-5 * np.abs(sums).max() + 1e-4
+    assert np.abs(((r["alpha"] - params[:, 0] + 180.0) % 360.0) - 180.0).max() < 2e-3
     eng.close()
 
 
