@@ -393,18 +393,37 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             for (int k7 = 0; k7 < 7; k7++) pc[tid].t7[k7] = 0.f;
         }
         auto store_round = [&](int ref_lo, int nrz) {
+            // Z_k = Q_k + i T_k and Z_{N-k} of rf_store_z for this lane's bin k of every unit; the lane's part of the addresses
+            // (its bin, its offset parity, its first reference) is formed once, a unit adds a wave-uniform stride
+            typedef ZLayout<N> ZL;
+            const int k = 16 * xm + xb, km = k ? N - k : N / 2;          // bin 0: DC term -> slot 0, Nyquist term -> slot N/2
+            const int ref_b = 2 * rp0 + (xj >> 1);
+            float *zk = bufs + (odd * f.rz + ref_b - ref_lo) * ZL::kPairStride + 2 * (k + (k >> 4));
+            const int dkm = 2 * (km + (km >> 4)) - 2 * (k + (k >> 4));
 #pragma unroll
             for (int i = 0; i < NU; i++) {
-                const int rp = rp0 + (i >> 1), ref = 2 * rp + (xj >> 1), o = 2 * (i & 1) + odd, rr = ref - ref_lo;
+                const int h = i >> 1, op = i & 1, ref = ref_b + 2 * h, o = 2 * op + odd, rr = ref - ref_lo;
                 const f32x4 c4 = acc[i];
                 const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
                 const float r0x = swap_lane_pair(s0), r1x = swap_lane_pair(s1);
-                const float ca = odd ? r0x : c4[0], cb = odd ? r1x : c4[1];
-                const float cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
-                if (rp < f.nrp && ref < nref && rr >= 0 && rr < nrz && o < nlive) {
-                    float cdc = 0.f;
-                    if (xm == 0 && xb == 0) cdc = red[8 + o] * cdc_s[ref];       // Normalize_ring mean: the DC term only
-                    rf_store_z<N>(bufs, o * f.rz + rr, 16 * xm + xb, ca - cdc, cb, cc, cd);
+                float ca = odd ? r0x : c4[0];
+                const float cb = odd ? r1x : c4[1], cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
+                const bool live = ref < nref && rr >= 0 && rr < nrz && o < nlive;      // ref < nref implies a real reference pair
+                float2 vk, vm;
+                if (xm == 0) {                                            // wave-uniform: the group that holds bin 0
+                    if (xb == 0 && live) ca -= red[8 + o] * cdc_s[ref];  // Normalize_ring mean: the DC term only
+                    const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                    vk = xb == 0 ? make_float2(ca, ca) : make_float2(apd + bpc, cmb + amd);
+                    vm = xb == 0 ? make_float2(cd, cd) : make_float2(apd - bpc, amd - cmb);
+                } else {
+                    const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                    vk = make_float2(apd + bpc, cmb + amd);
+                    vm = make_float2(apd - bpc, amd - cmb);
+                }
+                if (live) {
+                    float *z = zk + (2 * op * f.rz + 2 * h) * ZL::kPairStride;
+                    *reinterpret_cast<float2 *>(z) = vk;
+                    *reinterpret_cast<float2 *>(z + dkm) = vm;
                 }
             }
         };
