@@ -42,7 +42,7 @@ struct FusedGeom {
     int wpg;                       // waves per group = 16 / ng
     int nrp;                       // reference pairs
     int nrpw;                      // reference pairs per wave = ceil(nrp / wpg): template parameter of the kernel
-    int rz, nzr;                   // references per inverse-FFT round, rounds
+    int rz, nzr, rz_inv;           // references per inverse-FFT round, rounds, ceil(2^16 / rz) (division by multiply-shift)
     int b_floats;
     int grp_ring0[8];              // first ring that has bins of group m (rings are sorted by length)
     int grp_boff[8];               // float offset of group m's B block: [pair][ring quad][lane][4 rings]
@@ -92,6 +92,7 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     rzmax = std::max(1, rzmax);
     f.nzr = (nref + rzmax - 1) / rzmax;
     f.rz = (nref + f.nzr - 1) / f.nzr;
+    f.rz_inv = (65536 + f.rz - 1) / f.rz;
     int boff = 0;
     for (int m = 0; m < f.ng; m++) {
         int r0 = 0;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             // lane groups (sub, sub ^ 1) of a half-wave take spectrum slots zs and zs + 16: their LDS images are 32 banks apart
             const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
             const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
-            const int rr = zs % f.rz, o = zs / f.rz;
+            const int o = __mul24(zs, f.rz_inv) >> 16, rr = zs - __mul24(o, f.rz);      // zs / rz, zs % rz (zs < 64, rz <= 16: exact)
             if (zs < 4 * f.rz && rr < nrz && o < nlive && !RA_DBG(g, 1))      // uniform over the 16-lane group
                 ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
         };
