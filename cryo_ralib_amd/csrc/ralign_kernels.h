@@ -1075,11 +1075,13 @@ __global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__r
     extern __shared__ __align__(16) float img[];
     const int p = blockIdx.x, tid = threadIdx.x, npix = nx * nx;
     if (p >= n) return;
+    __shared__ float trig[2];
     const float *src = particles + (size_t)p * npix;
     for (int i = tid; i < npix; i += blockDim.x) img[i] = src[i];
     const ra_result r = res[p];
-    __syncthreads();
     const float ang = r.alpha * (float)M_PI / 180.0f;
+    if (tid == 0) { trig[0] = (float)cos((double)ang); trig[1] = (float)sin((double)ang); }     // once per particle, not per thread
+    __syncthreads();
     float delx = r.sx, dely = r.sy;
     while (delx >= (float)nx) delx -= nx;
     while (delx <= -(float)nx) delx += nx;
@@ -1087,12 +1089,13 @@ __global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__r
     while (dely <= -(float)nx) dely += nx;
     const int xc = nx / 2, yc = nx / 2;
     const float shiftxc = xc + delx, shiftyc = yc + dely;
-    const float cang = (float)cos((double)ang), sang = (float)sin((double)ang);
+    const float cang = trig[0], sang = trig[1];
     float *dsum = sums ? sums + ((size_t)r.ref_id * 2 + ((index0 + p) & 1)) * npix : nullptr;
     float *dal = aligned ? aligned + (size_t)p * npix : nullptr;
     const int mstart = 1 - nx % 2;
+    const unsigned nx_rcp = 0xFFFFFFFFu / (unsigned)nx + 1u;      // i / nx = (i * nx_rcp) >> 32, exact for i * nx < 2^32
     for (int i = tid; i < npix; i += blockDim.x) {
-        const int iy = i / nx, ix = i - iy * nx;
+        const int iy = (int)__umulhi((unsigned)i, nx_rcp), ix = i - iy * nx;
         float y = (float)iy - shiftyc;
         float ycang = y * cang + yc;
         float ysang = -y * sang + xc;
