@@ -65,6 +65,7 @@ struct ra_engine {
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
+    unsigned long long *d_timeline = nullptr;      // profiling builds only (RALIGN_TIMELINE)
     float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic and fused paths)
     int g_nblk = 0, g_P = 0;
     size_t lds_gpolar = 0, lds_gccf = 0;
@@ -137,8 +138,15 @@ static int build_device_geometry(ra_engine *e)
     d.nn_weight = g.nn_weight; d.mode = e->cfg.mode; d.nomirror = 0;
 #ifdef RALIGN_PROFILE_SWITCHES
     d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
+    d.timeline = nullptr;
+    if (getenv("RALIGN_TIMELINE")) {          // 64 passes x 16 waves x 16 stamps, written by workgroup 0 for its first particle
+        if (!e->d_timeline && hipMalloc(&e->d_timeline, 64 * 16 * 16 * sizeof(unsigned long long)) != hipSuccess) e->d_timeline = nullptr;
+        if (e->d_timeline) (void)hipMemset(e->d_timeline, 0, 64 * 16 * 16 * sizeof(unsigned long long));
+        d.timeline = e->d_timeline;
+    }
 #else
     d.dbg = 0;
+    d.timeline = nullptr;
 #endif
     // ring-buffer stride.  Kernel pair: == 8 (mod 32), the 4 offsets of an entry hit disjoint banks in the write-out gather.
     // Fused kernel: == 16 (mod 32), the two offsets a 4x4x1 MFMA A operand reads (16 bins x Re/Im each) sit in disjoint
@@ -564,6 +572,16 @@ extern "C" void ra_destroy(ra_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+#ifdef RALIGN_PROFILE_SWITCHES
+    if (e->d_timeline && getenv("RALIGN_TIMELINE")) {      // profiling builds: dump the wave timeline of the last launch
+        std::vector<unsigned long long> h(64 * 16 * 16);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(h.data(), e->d_timeline, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *fp = fopen(getenv("RALIGN_TIMELINE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
+        }
+        (void)hipFree(e->d_timeline);
+    }
+#endif
     for (void *p : e->owned) (void)hipFree(p);
     for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

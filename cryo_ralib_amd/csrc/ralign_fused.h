@@ -320,6 +320,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     }
     RF_LDS_BARRIER();
     for (int grp = 0; grp < ngroup; grp++) {
+        const bool tl = p == (int)blockIdx.x && blockIdx.x == 0;      // timeline: first particle of workgroup 0
+        RA_STAMP(g, tl, grp, wave, 0);
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
         const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
         if (!RA_DBG(g, 16)) {
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 }
             }
         }
+        RA_STAMP(g, tl, grp, wave, 1);
         // lane roles of the contraction (see above), and its first B quad: requested here, it travels while the last ring
         // jobs finish and the barrier is crossed (the barrier does not drain global requests)
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 b0[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : min(rp0 + h, f.nrp - 1) * nq * 256));
         }
         RF_LDS_BARRIER();
+        RA_STAMP(g, tl, grp, wave, 2);
         // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One of the last four waves per offset reduces its ring partials
         // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
         // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
@@ -387,7 +391,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
             else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
         }
+        RA_STAMP(g, tl, grp, wave, 3);
         RF_LDS_BARRIER();                       // every wave has finished reading the ring buffers
+        RA_STAMP(g, tl, grp, wave, 4);
         // ---- CCF spectra -> LDS (over the ring buffers), inverse FFT, argmax: rounds of f.rz references
         if (RA_DBG(g, ~0) && tid < 4 * nref) {   // profiling builds that skip a phase still emit in-range records
             pc[tid].val = 0.f; pc[tid].jtot = 1; pc[tid].refmir = tid % nref;
@@ -439,9 +445,13 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         if (!RA_DBG(g, 4)) {
             if (f.nzr == 1) {                  // the accumulators die before the inverse FFT: no register pressure from them
                 store_round(0, nref);
+                RA_STAMP(g, tl, grp, wave, 5);
                 RF_LDS_BARRIER();
+                RA_STAMP(g, tl, grp, wave, 6);
                 ifft_round(0, nref);
+                RA_STAMP(g, tl, grp, wave, 7);
                 RF_LDS_BARRIER();
+                RA_STAMP(g, tl, grp, wave, 8);
             } else {
                 for (int zr = 0; zr < f.nzr; zr++) {
                     const int ref_lo = zr * f.rz, nrz = min(f.rz, nref - ref_lo);

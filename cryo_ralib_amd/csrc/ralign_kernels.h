@@ -28,8 +28,12 @@
 // environment variable can make a production kernel skip work.
 #ifdef RALIGN_PROFILE_SWITCHES
 #define RA_DBG(g, bits) (((g).dbg & (bits)) != 0)
+// wave timeline of the fused search kernel (profiling builds, RALIGN_TIMELINE=<file>): stamp s of pass `grp`
+#define RA_STAMP(g, cond, grp, wave, s)                                                                         \
+    do { if ((g).timeline && (cond) && threadIdx.x % 64 == 0) (g).timeline[((grp) * 16 + (wave)) * 16 + (s)] = clock64(); } while (0)
 #else
 #define RA_DBG(g, bits) false
+#define RA_STAMP(g, cond, grp, wave, s) do { } while (0)
 #endif
 
 namespace ralign {
@@ -46,6 +50,7 @@ struct DevGeom {
     int mode;                     // RA_MODE_*
     int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
     int dbg;                      // phase-skip mask of profiling builds (-DRALIGN_PROFILE_SWITCHES); unused otherwise
+    unsigned long long *timeline; // profiling builds: [pass][wave][stamp] clock values of workgroup 0's first particle, or null
     int sbuf;                     // LDS stride of one ring buffer (floats)
     int a_blk;                    // floats per A block of 4 particle-offsets: LBP*8 + slack
     int n_itemA, n_itemB, n_itemC;
@@ -131,14 +136,24 @@ __device__ __forceinline__ float bilinear_pad(const float *base, int st, float x
 {
 #pragma clang fp contract(off)
     // coordinates are >= 1 inside the padded image: x - floor(x) (v_fract_f32, exact) equals the CPU path's
-    // xold - (float)(int)xold bit for bit and saves the int -> float round trip
+    // xold - (float)(int)xold bit for bit and saves the int -> float round trip (positions, taps and fractions are
+    // the oracle's; only the evaluation order of the interpolant below differs)
     const int ix = (int)xold, iy = (int)yold;
     const float ydif = __builtin_amdgcn_fractf(yold), xdif = __builtin_amdgcn_fractf(xold);
     int idx;                                            // iy * st + ix in ONE full-rate instruction (hipcc otherwise splits
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(idx) : "v"(iy), "s"(st), "v"(ix));    // it into mul24 + two shifts + add3)
     const float *p = base + idx;
+#ifdef RALIGN_BILINEAR_EXACT_ORDER
+    // Util::bilinear's own operation order, no contraction: bit-identical samples (11 instructions)
     const float f00 = p[0], f10 = p[1], f01 = p[st], f11 = p[st + 1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+#else
+    // the same interpolant as two fused lerps, row pair first: both rows in one packed subtract and one packed fma, then
+    // the column lerp (4 instructions; differs from Util::bilinear's operation order by rounding only, < 1 ulp of the taps)
+    const v2f r0 = {p[0], p[1]}, r1 = {p[st], p[st + 1]};
+    const v2f g = __builtin_elementwise_fma((v2f){ydif, ydif}, r1 - r0, r0);
+    return __builtin_fmaf(xdif, g.y - g.x, g.x);
+#endif
 }
 
 // search window of one particle: the reset/clamp rule and search_range

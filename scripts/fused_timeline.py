@@ -1,0 +1,22 @@
+"""prints the wave timeline recorded by scripts/fused_timeline.sh: per pass, the time every wave spent in each phase and
+at the barrier behind it (clock64 ticks -> ns at 100 MHz if the values look like the constant clock, else raw cycles)"""
+import sys
+import numpy as np
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(64, 16, 16).astype(np.int64)
+names = ["ring jobs", "wait b1", "contraction", "wait b3", "store", "wait b4", "ifft", "wait b5"]
+passes = [g for g in range(64) if t[g, :, 0].all()]
+print("passes recorded:", len(passes))
+t0 = t[passes[0], :, 0].min()
+tot = np.zeros((16, 8))
+for g in passes:
+    d = np.diff(t[g, :, :9], axis=1)          # [wave][8 phases]
+    tot += d
+avg = tot / len(passes)
+print("average ticks per pass, per wave (rows = waves 0..15):")
+print("wave " + " ".join("%12s" % n for n in names) + "   pass")
+for w in range(16):
+    print("%4d " % w + " ".join("%12.0f" % v for v in avg[w]) + "   %6.0f" % avg[w].sum())
+print("mean " + " ".join("%12.0f" % v for v in avg.mean(0)) + "   %6.0f" % avg.sum(1).mean())
+print("max  " + " ".join("%12.0f" % v for v in avg.max(0)))
+span = (t[passes[-1], :, 8].max() - t0)
+print("first pass start -> last pass end: %d ticks (%d passes)" % (span, len(passes)))
