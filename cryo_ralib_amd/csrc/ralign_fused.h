@@ -327,9 +327,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         if (!RA_DBG(g, 16)) {
 #pragma unroll 1
             for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
-                // the jobs are sorted longest first: rounds alternate direction, so the waves that drew the long jobs
-                // of round 0 get the short ones (or none) of round 1
-                const int job = jr * RF_WAVES + ((jr & 1) ? RF_WAVES - 1 - wave : wave);
+                // jobs sorted longest first, dealt round robin: the SIMDs issue oldest-wave-first, so the first waves finish
+                // their long jobs earliest (wave timeline, scripts/fused_timeline.sh) and take the short jobs of round 1
+                const int job = jr * RF_WAVES + wave;
                 if (job >= g.n_job) continue;
                 const int4 jd = jobs_s[job];
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
@@ -358,12 +358,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         }
         RF_LDS_BARRIER();
         RA_STAMP(g, tl, grp, wave, 2);
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One of the last four waves per offset reduces its ring partials
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One wave per offset (waves 1, 3, 5, 7) reduces its ring partials
         // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
         // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
         // (a -= avg * sum_r n_r B_r(0), store_round) and 1/sigma to the peak record.
-        if (wave >= RF_WAVES - 4) {              // the waves of the highest bin groups have the shortest contraction
-            const int os = wave - (RF_WAVES - 4);
+        if ((wave & 1) && wave < 8) {            // waves 1, 3, 5, 7: the odd wave of a bin group holds the smaller share of the
+            const int os = wave >> 1;            // reference pairs, and the oldest waves finish their contraction first
             float a = 0.f, q = 0.f;
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum(a); q = wave_sum(q);
@@ -463,8 +463,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             }
         }
         // best reference per offset of the pass (ascending reference, ">=": later wins), scaled by 1/sigma
-        // (by the last wave: the first ones head for the longest ring jobs of the next pass)
-        if (wave == RF_WAVES - 1 && lane < nlive * (int)(sizeof(CandT) / 4)) {
+        // (by wave 2: an old wave -- it gets through its ring job of the next pass first -- that is not the one with the
+        // extra short job)
+        if (wave == 2 && lane < nlive * (int)(sizeof(CandT) / 4)) {
             constexpr int W = sizeof(CandT) / 4;
             const int o = lane / W, wd = lane - o * W;
             float bv = pc[o * nref].val; int br = 0;
