@@ -243,7 +243,9 @@ static int build_device_geometry(ra_engine *e)
         // (4 lanes x 8 pairs).  Measured: polar stage 5.64 -> 5.2 ms per 7143 particles.
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
             const int lanes_of[8] = {16, 8, 8, 4, 4, 4, 8, 4};
-            for (int lg = 8; lg >= 3; lg--) {
+            // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
+            const bool mixed = nslot == 4 && !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0);
+            for (int lg = 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
                 const int code = (n == 256 && nslot == 4) ? 6 : ((n == 64 && nslot == 4) ? 7 : code_of(n));
                 std::vector<int4> cls;
@@ -260,6 +262,29 @@ static int build_device_geometry(ra_engine *e)
                     J.push_back(make_int4(code, (int)I.size(), cnt, 0));
                     for (int c = 0; c < cnt; c++) { I.push_back(cls[b + c]); W.push_back(clsw[b + c]); }
                 }
+            }
+            if (mixed) {
+                std::vector<int4> lanes;              // lane entries of the current job (aligned groups: 4-lane rings first)
+                std::vector<float> lanew;
+                auto flush = [&]() {
+                    if (lanes.empty()) return;
+                    J.push_back(make_int4(9, (int)I.size(), (int)lanes.size(), 0));
+                    for (size_t c = 0; c < lanes.size(); c++) { I.push_back(lanes[c]); W.push_back(lanew[c]); }
+                    lanes.clear(); lanew.clear();
+                };
+                for (int lg = 5; lg >= 3; lg--) {
+                    const int LR = 1 << (lg - 3);
+                    for (int sft = 0; sft < nslot; sft++)
+                        for (int i = 0; i < g.nring; i++)
+                            if (g.numr[3 * i + 2] == (1 << lg)) {
+                                if (lanes.size() + LR > 64) flush();
+                                for (int t = 0; t < LR; t++) {
+                                    lanes.push_back(make_int4(sft | (i << 8) | (lg << 16) | (t << 20), g.ring_off[i], qoff[lg], g.numr[3 * i]));
+                                    lanew.push_back(ringw[i]);
+                                }
+                            }
+                }
+                flush();
             }
         };
         if (!e->generic) make_jobs(4, jobs, inst, instw);

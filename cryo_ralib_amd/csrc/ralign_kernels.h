@@ -507,6 +507,113 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     if (t == 0) { part[2 * (slot * g.nring + ring)] = av; part[2 * (slot * g.nring + ring) + 1] = sq; }
 }
 
+// Rings of 8, 16 and 32 samples in ONE job (code 9): 4 sample pairs per lane and n / 8 lanes per ring (4 | 2 | 1), so all the
+// short rings of a pass fit the 64 lanes of one wave and every wave of the workgroup gets exactly one job -- as three jobs
+// (one per length) the two shortest cost a second round of ~3 k cycles each on the wave timeline.  The instance table holds
+// one entry per LANE: in.x = slot | ring << 8 | log2 n << 16 | lane-in-ring << 20.  Same arithmetic as ring_job<4, LR>.
+template <bool NYQ1>
+__device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
+                                             const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
+                                             const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4)
+{
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+    if (lane >= count) return;
+    const int4 in = inst_s[inst0 + lane];
+    const int slot = in.x & 255, ring = (in.x >> 8) & 255, lg = (in.x >> 16) & 15, t = in.x >> 20;
+    if (slot >= nlive) return;
+    const int lgLR = lg - 3, LR = 1 << lgLR, H = 4 << lgLR, lgLT = lg - 2, LTm = (1 << lgLT) - 1;
+    float *buf = bufs + (__mul24(slot, sbuf) + in.y);
+    const float rad = (float)in.w, wt = instw_s[inst0 + lane];
+    const v2f ctr2 = {ctr[2 * slot], ctr[2 * slot + 1]};
+    const float2 *qt = qt_s + in.z;
+    v2f av2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+    float2 v[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        v2f val;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = 2 * ((a << lgLR) + t) + u, qd = j >> lgLT;
+            const float2 sc = qt[j & LTm];
+            v2f o;
+            {
+#pragma clang fp contract(off)
+                const v2f xy = v2f{sc.x, sc.y} * rad;
+                v2f m = (qd & 1) ? v2f{xy.y, xy.x} : xy;         // alrl_ms quadrant mirroring (x,y), (y,-x), (-x,-y), (-y,x)
+                m.x = (qd & 2) ? -m.x : m.x;
+                m.y = ((qd + 1) & 2) ? -m.y : m.y;
+                o = m + ctr2;
+            }
+            const float sv = bilinear_pad(imgb, g.pst, o.x, o.y);
+            if (u == 0) val.x = sv; else val.y = sv;
+        }
+        av2 += val;
+        sq2 += val * val;
+        v[a] = make_float2(val.x, val.y);
+    }
+    Dft<-1, 4>::run(v);
+    const int tstep = __mul24(t, g.maxrin >> (lg - 1));          // maxrin / H
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float2 o = v[c];
+        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c) & (g.maxrin - 1)]);
+        *reinterpret_cast<float2 *>(buf + 2 * ((c << lgLR) + ((t + c) & (LR - 1)))) = o;
+    }
+    RA_WAVE_SYNC();
+    // second pass: every lane owns 4 elements -- one row of 4 (LR = 4), two rows of 2 (LR = 2), four rows of 1 (LR = 1)
+    int src[4], dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row2 = t + 2 * (i >> 1), b2 = i & 1;
+        src[i] = lgLR == 2 ? 4 * t + ((i + t) & 3) : lgLR == 1 ? 2 * row2 + ((b2 + row2) & 1) : i;
+        dst[i] = lgLR == 2 ? t + 4 * i : lgLR == 1 ? row2 + 4 * b2 : i;
+    }
+    float2 z[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) z[i] = *reinterpret_cast<const float2 *>(buf + 2 * src[i]);
+    if (lgLR == 2) Dft<-1, 4>::run(z);
+    if (lgLR == 1) { dft2<-1>(z[0], z[1]); dft2<-1>(z[2], z[3]); }
+    RA_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<float2 *>(buf + 2 * dst[i]) = z[i];
+    RA_WAVE_SYNC();
+    // split step X_k <- (Z_k, Z_{H-k}), k = t, t + LR, t + 2 LR while k <= H/2 = 2 LR
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int k = t + (m << lgLR);
+        if (k <= 2 * LR) {
+            const float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
+            if (k == 0) {
+                if (NYQ1 && 2 * H == g.maxrin) {
+                    *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, zk.x - zk.y);
+                } else {
+                    *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
+                    *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+                }
+            } else {
+                const float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
+                const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+                const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+                const float2 w = tw_s[__mul24(k, g.maxrin >> lg)];
+                const float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+                *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
+                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+            }
+        }
+    }
+    // Normalize_ring partial sums over the LR lanes of the ring (fixed pairing order)
+    float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
+    {
+        const float a2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(av), 0x4E, 0xF, 0xF, true));     // i ^ 2
+        const float q2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4E, 0xF, 0xF, true));
+        if (lgLR == 2) { av += a2; sq += q2; }
+        const float a1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(av), 0xB1, 0xF, 0xF, true));     // i ^ 1
+        const float q1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xB1, 0xF, 0xF, true));
+        if (lgLR >= 1) { av += a1; sq += q1; }
+    }
+    if (t == 0) { part[2 * (slot * g.nring + ring)] = av; part[2 * (slot * g.nring + ring) + 1] = sq; }
+}
+
 __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
                                                                      const float *__restrict__ state, int n,
                                                                      float *__restrict__ A)
@@ -563,6 +670,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
                 case 4: ring_job<2, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 case 6: ring_job<16, 8>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 case 7: ring_job<8, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
+                case 9: ring_job_mix<false>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 default: ring_job<1, 4>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf); break;
                 }
             }
