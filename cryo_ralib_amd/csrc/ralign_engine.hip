@@ -516,6 +516,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+        if (getenv("RALIGN_GRID") && atoi(getenv("RALIGN_GRID")) > 0) e->n_cu = atoi(getenv("RALIGN_GRID"));      // experiments: fewer persistent workgroups
     }
     if (!build_rings(e->geo, cfg->nx, cfg->first_ring, cfg->last_ring, cfg->ring_skip > 0 ? cfg->ring_skip : 1) ||
         !build_shifts(e->geo, cfg->xrng, cfg->yrng, cfg->step)) {

@@ -171,7 +171,7 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
 template <int NRPW, int NH>
 __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f, const float *bufs, const int *goff_s,
                                             const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW],
-                                            const float4 (&b0)[NRPW])
+                                            const float4 (&b0)[NRPW], bool tl = false, int tgrp = 0, int twave = 0)
 {
     const int xb = ln >> 2, xj = ln & 3;
     const int nq = f.grp_nq[xm];
@@ -214,7 +214,9 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // their way from LDS, its B operands from L2, and the ring offsets of quad rq + 2 from the LDS table
     // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  In-situ
     // measurements (scripts/fused_phases.sh): the phase is paced by the B stream through the vector memory
-    // path (283 KB per pass and CU at 64 B/clk) plus the matrix instructions; deeper prefetch does not help.
+    // path plus the matrix instructions.  The wave timeline (scripts/fused_timeline.sh) shows ~1000 cycles per ring quad
+    // for every wave whatever its share; three B buffers (requests two multiplies ahead), non-temporal loads and fewer
+    // active CUs change nothing: 235 KB per pass reach a CU at ~21 B/clk, the miss parallelism of its vector L1.
     const int ql = nq - 1;
     int4 oA = gq[0], oB = gq[min(1, ql)];
 #pragma unroll
@@ -222,6 +224,7 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     read_a(oA, aA);
 #pragma unroll 1
     for (int rq = 0; rq < nq; rq += 2) {
+        RA_STAMP(g, tl && rq < 12, tgrp, twave, 9 + (rq >> 1));      // profiling builds: iteration starts (stamps 9 .. 14)
         load_b(min(rq + 1, ql), bB);
         read_a(oB, aB);
         oA = gq[min(rq + 2, ql)];
@@ -389,8 +392,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
             // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
-            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
-            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0);
+            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, tl, grp, wave);
+            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, tl, grp, wave);
         }
         RA_STAMP(g, tl, grp, wave, 3);
         RF_LDS_BARRIER();                       // every wave has finished reading the ring buffers

@@ -20,3 +20,11 @@ print("mean " + " ".join("%12.0f" % v for v in avg.mean(0)) + "   %6.0f" % avg.s
 print("max  " + " ".join("%12.0f" % v for v in avg.max(0)))
 span = (t[passes[-1], :, 8].max() - t0)
 print("first pass start -> last pass end: %d ticks (%d passes)" % (span, len(passes)))
+
+# contraction loop: stamps 9.. = start of every second ring quad (rf_contract), relative to the barrier before it (stamp 2)
+it = t[passes, :, 9:15] - t[passes, :, 2:3]
+it = np.where(t[passes, :, 9:15] > 0, it, 0)
+print("contraction: start of loop iteration i after barrier 1 (mean over passes), then end of the phase:")
+for w in range(16):
+    row = it[:, w, :].mean(0)
+    print("%4d " % w + " ".join("%7.0f" % v for v in row) + "   end %7.0f" % (t[passes, w, 3] - t[passes, w, 2]).mean())
