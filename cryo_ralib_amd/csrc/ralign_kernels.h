@@ -137,7 +137,7 @@ __device__ __forceinline__ float bilinear_pad(const float *base, int st, float x
 #pragma clang fp contract(off)
     // coordinates are >= 1 inside the padded image: x - floor(x) (v_fract_f32, exact) equals the CPU path's
     // xold - (float)(int)xold bit for bit and saves the int -> float round trip (positions, taps and fractions are
-    // the oracle's; only the evaluation order of the interpolant below differs)
+    // the CPU path's; only the evaluation order of the interpolant below differs)
     const int ix = (int)xold, iy = (int)yold;
     const float ydif = __builtin_amdgcn_fractf(yold), xdif = __builtin_amdgcn_fractf(xold);
     int idx;                                            // iy * st + ix in ONE full-rate instruction (hipcc otherwise splits
