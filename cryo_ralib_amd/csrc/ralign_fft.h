@@ -40,11 +40,39 @@ __device__ __forceinline__ v2f vfma_irot_s(v2f a, v2f s, v2f t)
     return r;
 }
 
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ v2f vadd_conj(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f vsub_conj(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // a * b (complex): (a.x b.x, a.x b.y) + a.y * (-b.y, b.x)
 __device__ __forceinline__ v2f vmul(v2f a, v2f b)
 {
     return vfma_rot_y(a, b, a.xx * b);
 }
+// Real-FFT split step of one pair: X_k = E + W O and X_{H-k} = conj(E - W O) with E = (Z_k + conj Z_{H-k}) / 2,
+// O = -i (Z_k - conj Z_{H-k}) / 2, W = w = e^{-2 pi i k / n}: seven packed instructions (the halves and the -i ride on the
+// twiddle: wh = -i w / 2)
+__device__ __forceinline__ void vsplit_pair(v2f zk, v2f zm, v2f w, v2f &xk, v2f &xm)
+{
+    const v2f e2 = vadd_conj(zk, zm), o2 = vsub_conj(zk, zm);
+    const v2f hp = {0.5f, -0.5f};
+    v2f wh, t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(wh) : "v"(w), "v"(hp));      // (w.y / 2, -w.x / 2)
+    t = vmul(o2, wh);
+    xk = __builtin_elementwise_fma(e2, (v2f){0.5f, 0.5f}, t);
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1]" : "=v"(xm) : "v"(e2), "v"(hp), "v"(t));          // (e2.x / 2 - t.x, t.y - e2.y / 2)
+}
+
 // a * (SIGN * i)
 template <int SIGN> __device__ __forceinline__ v2f vmuli(v2f a)
 {

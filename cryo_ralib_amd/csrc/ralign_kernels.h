@@ -410,12 +410,9 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     RA_WAVE_SYNC();
     // real-FFT split step of one pair: X_k and X_{H-k} from Z_k, Z_{H-k} (k = 0 gives X_0 and the Nyquist term X_H)
     auto split_pair = [&](float2 zk, float2 zm, int k, float2 &xk, float2 &xm) {
-        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-        const float2 w = tw_s[__mul24(k, g.maxrin / NR)];
-        const float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
-        xk = make_float2(er + tr, ei + ti);
-        xm = make_float2(er - tr, -(ei - ti));
+        v2f a, b;
+        vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[__mul24(k, g.maxrin / NR)]), a, b);
+        xk = to_f2(a); xm = to_f2(b);
     };
     if constexpr (R1 == 2 * LR) {
         // Two rows per lane, chosen so that the split step stays inside the lane: lane t transforms rows t and R1 - t
@@ -493,12 +490,10 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
                 }
             } else {
                 float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
-                float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-                float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-                float2 w = tw_s[__mul24(k, g.maxrin / NR)];
-                float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
-                *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
-                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+                float2 xk, xm;
+                split_pair(zk, zm, k, xk, xm);
+                *reinterpret_cast<float2 *>(buf + 2 * k) = xk;
+                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = xm;
             }
         }
     }
@@ -592,12 +587,10 @@ __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb
                 }
             } else {
                 const float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
-                const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-                const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-                const float2 w = tw_s[__mul24(k, g.maxrin >> lg)];
-                const float tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
-                *reinterpret_cast<float2 *>(buf + 2 * k) = make_float2(er + tr, ei + ti);
-                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = make_float2(er - tr, -(ei - ti));
+                v2f xk, xm;
+                vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[__mul24(k, g.maxrin >> lg)]), xk, xm);
+                *reinterpret_cast<float2 *>(buf + 2 * k) = to_f2(xk);
+                if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = to_f2(xm);
             }
         }
     }
