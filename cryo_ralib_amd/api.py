@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
     "ref_free_alignment_2D_filter_references", "ra_isac_get_references", "ra_legacy_bytes",
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_set_nomirror", "ra_set_mask",
-    "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align",
+    "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
 ]
@@ -98,6 +98,8 @@ def load_library(path=None):
     L.ra_set_references.argtypes = [vp, vp]
     L.ra_get_prepared_references.argtypes = [vp, vp]
     L.ra_align.argtypes = [vp, vp, ctypes.c_int, vp, vp, float_ptr]
+    L.ra_set_class_references.argtypes = [vp, vp, ctypes.c_int]
+    L.ra_align_classes.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
     L.ra_transform_accumulate.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     L.ra_update_references.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.ra_normalize_particles.argtypes = [vp, vp, ctypes.c_int]
@@ -274,6 +276,20 @@ class Engine:
         _check(self.lib.ra_align(self.handle, self._ptr(particles, self.torch.float32), n,
                                  self._ptr(state, self.torch.float32), self._ptr(result, self.torch.int32), csp),
                "ra_align")
+
+    def set_class_references(self, refs):
+        """class-resident mode: one reference per class, [ncls][nx][nx] (ra_set_class_references)"""
+        assert refs.shape[1:] == (self.nx, self.nx)
+        _check(self.lib.ra_set_class_references(self.handle, self._ptr(refs, self.torch.float32), int(refs.shape[0])),
+               "ra_set_class_references")
+
+    def align_classes(self, particles, state, result, cls):
+        """every particle against the reference of its class cls[i] (int32, device), one launch (ra_align_classes)"""
+        n = particles.shape[0]
+        assert particles.shape[1:] == (self.nx, self.nx) and state.shape == (n, 2) and result.shape == (n, 8) and cls.shape == (n,)
+        _check(self.lib.ra_align_classes(self.handle, self._ptr(particles, self.torch.float32), n,
+                                         self._ptr(state, self.torch.float32), self._ptr(result, self.torch.int32),
+                                         self._ptr(cls, self.torch.int32)), "ra_align_classes")
 
     def transform_accumulate(self, particles, result, index0=0, aligned=None, sums=None, counts=None):
         n = particles.shape[0]

@@ -66,6 +66,8 @@ struct ra_engine {
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
     unsigned long long *d_timeline = nullptr;      // profiling builds only (RALIGN_TIMELINE)
+    float *d_cls_refspec = nullptr, *d_cls_Bf = nullptr;      // class-resident mode: [cls_cap][lring], [cls_cap][b_floats]
+    int cls_cap = 0, cls_ready = 0;
     float *d_gcdc = nullptr;            // [nref] DC weights of the references (generic and fused paths)
     int g_nblk = 0, g_P = 0;
     size_t lds_gpolar = 0, lds_gccf = 0;
@@ -412,7 +414,7 @@ static ccf_fn select_ccf(int maxrin)
     }
 }
 
-typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *);
+typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
 static fused_fn select_fused(int maxrin, int nref)
 {
     if (nref > RF_MAXREF) return nullptr;
@@ -608,6 +610,8 @@ extern "C" void ra_destroy(ra_engine *e)
         (void)hipFree(e->d_timeline);
     }
 #endif
+    if (e->d_cls_refspec) (void)hipFree(e->d_cls_refspec);
+    if (e->d_cls_Bf) (void)hipFree(e->d_cls_Bf);
     for (void *p : e->owned) (void)hipFree(p);
     for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -742,6 +746,61 @@ __global__ void apply_cs_kernel(int n, const float *__restrict__ cs, const ra_re
     state[2 * p + 1] = (float)((double)state[2 * p + 1] + s * u + c * v);
 }
 
+// Class-resident alignment (gpu_aln_noref.cu:559-782, the ISAC mode): every particle against the average of its own class, all
+// classes in ONE launch of the fused search kernel.  ra_set_class_references prepares ncls references (Polar2Dm, Frngs,
+// Applyws) and one B stream per class; ra_align_classes aligns particle i to reference d_cls[i].  Needs the fused kernel
+// with a single reference (RA_MODE_REFFREE, nref = 1); RA_ERR_STATE otherwise (callers then loop over the classes).
+extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int ncls)
+{
+    if (!e || !d_refs || ncls <= 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e->fused || e->cfg.nref != 1 || e->cfg.mode != RA_MODE_REFFREE) { g_last_error = "class-resident launch needs the fused kernel with one reference"; return RA_ERR_STATE; }
+    const FusedGeom f = e->fplan.f;
+    int rc;
+    if (ncls > e->cls_cap) {
+        if (e->d_cls_refspec) (void)hipFree(e->d_cls_refspec);
+        if (e->d_cls_Bf) (void)hipFree(e->d_cls_Bf);
+        e->d_cls_refspec = nullptr; e->d_cls_Bf = nullptr; e->cls_cap = 0;
+        if (hipMalloc((void **)&e->d_cls_refspec, (size_t)ncls * e->geo.lring * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&e->d_cls_Bf, (size_t)ncls * f.b_floats * sizeof(float)) != hipSuccess) {
+            g_last_error = "out of device memory (class references)";
+            return RA_ERR_NOMEM;
+        }
+        e->cls_cap = ncls;
+    }
+    (void)rc;
+    hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(ncls), dim3(256), e->lds_ref, e->stream, e->dg, d_refs, ncls, e->d_cls_refspec);
+    RA_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(64, (f.b_floats + 255) / 256), ncls), dim3(256), 0, e->stream, e->dg, f,
+                       (const float *)e->d_cls_refspec, 1, e->d_cls_Bf);
+    RA_HIP(hipGetLastError());
+    e->cls_ready = ncls;
+    return RA_OK;
+}
+
+extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, float *d_state, ra_result *d_result,
+                                const int *d_cls)
+{
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    if (!d_particles || !d_state || !d_result || !d_cls) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e->fused || e->cfg.nref != 1 || e->cls_ready <= 0) { g_last_error = "ra_set_class_references has not been called"; return RA_ERR_STATE; }
+    const Geometry &g = e->geo;
+    const int npix = g.nx * g.nx;
+    const FusedGeom f = e->fplan.f;
+    fused_fn fk = select_fused(g.maxrin, 1);
+    for (int start = 0; start < n; start += e->chunk) {
+        const int cn = std::min(e->chunk, n - start);
+        float *st = d_state + (size_t)start * 2;
+        hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f,
+                           d_particles + (size_t)start * npix, (const float *)st, cn, (const float *)e->d_cls_Bf, 1, e->d_fcand, d_cls + start);
+        RA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, e->d_fcand, 1, cn, st,
+                           d_result + start, e->d_cs);
+        RA_HIP(hipGetLastError());
+    }
+    return RA_OK;
+}
+
 extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_state, ra_result *d_result,
                         const float *cs)
 {
@@ -771,7 +830,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             if (evc) RA_HIP(hipEventRecord(evc->first, sp));
             // one workgroup per CU (its LDS plan fills the CU); each walks over its share of the chunk
             hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
-                               (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand);
+                               (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, (const int *)nullptr);
             RA_HIP(hipGetLastError());
             if (evc) RA_HIP(hipEventRecord(evc->second, sp));
             hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, 1, cn, st,
@@ -1150,6 +1209,7 @@ struct Legacy {
     bool isac = false;
     std::vector<unsigned> cid_idx;       // [ref_num + 1] first particle of every class
     unsigned *d_cid_idx = nullptr;
+    int *d_cls = nullptr;                // [sbj_num] class of every particle (class-resident single launch)
 } L;
 
 void die(const char *what)
@@ -1240,7 +1300,7 @@ extern "C" void gpu_clear(void)
     if (L.h_counts) (void)hipHostFree(L.h_counts);
     if (L.h_res) (void)hipHostFree(L.h_res);
     for (void *p : {(void *)L.d_sbj, (void *)L.d_ref, (void *)L.d_aligned, (void *)L.d_state, (void *)L.d_sums,
-                    (void *)L.d_counts, (void *)L.d_res, (void *)L.d_cid_idx})
+                    (void *)L.d_counts, (void *)L.d_res, (void *)L.d_cid_idx, (void *)L.d_cls})
         if (p) (void)hipFree(p);
     int dev = L.device;
     L = Legacy();
@@ -1450,6 +1510,13 @@ extern "C" AlignParam *ref_free_alignment_2D_init(const AlignConfig *aln_cfg, co
     hip_or_die(hipMalloc((void **)&L.d_cid_idx, (R + 1) * sizeof(unsigned)), "cid alloc");
     hip_or_die(hipMemset(L.d_res, 0, B * sizeof(ra_result)), "res clear");
     hip_or_die(hipMemcpy(L.d_cid_idx, L.cid_idx.data(), (R + 1) * sizeof(unsigned), hipMemcpyHostToDevice), "cid upload");
+    {
+        std::vector<int> cls(B);
+        for (unsigned r = 0; r < R; r++)
+            for (unsigned i = L.cid_idx[r]; i < L.cid_idx[r + 1]; i++) cls[i] = (int)r;
+        hip_or_die(hipMalloc((void **)&L.d_cls, B * sizeof(int)), "class index alloc");
+        hip_or_die(hipMemcpy(L.d_cls, cls.data(), B * sizeof(int), hipMemcpyHostToDevice), "class index upload");
+    }
     for (size_t i = 0; i < B; i++) memcpy(L.h_stage + i * npix, sbj_data_list[i], npix * sizeof(float));
     hip_or_die(hipMemcpy(L.d_sbj, L.h_stage, B * npix * sizeof(float), hipMemcpyHostToDevice), "image upload");
     for (size_t i = 0; i < R; i++) memcpy(L.h_stage + i * npix, ref_data_list[i], npix * sizeof(float));
@@ -1478,11 +1545,16 @@ extern "C" void ref_free_alignment_2D(void)
     const unsigned B = L.cfg.sbj_num, R = L.cfg.ref_num;
     for (unsigned i = 0; i < B; i++) { L.h_state[2 * i] = L.h_param[i].shift_x; L.h_state[2 * i + 1] = L.h_param[i].shift_y; }
     hip_or_die(hipMemcpy(L.d_state, L.h_state, sizeof(float) * 2 * B, hipMemcpyHostToDevice), "state upload");
-    for (unsigned r = 0; r < R; r++) {
-        const unsigned b = L.cid_idx[r], e = L.cid_idx[r + 1];
-        if (e <= b) continue;
-        if (ra_set_references(L.eng, L.d_ref + (size_t)r * npix)) die("ra_set_references");
-        if (ra_align(L.eng, L.d_sbj + (size_t)b * npix, (int)(e - b), L.d_state + 2 * (size_t)b, L.d_res + b, nullptr)) die("ra_align");
+    // all classes in one launch where the fused search kernel covers the geometry, class by class otherwise
+    if (ra_set_class_references(L.eng, L.d_ref, (int)R) == RA_OK) {
+        if (ra_align_classes(L.eng, L.d_sbj, (int)B, L.d_state, L.d_res, L.d_cls)) die("ra_align_classes");
+    } else {
+        for (unsigned r = 0; r < R; r++) {
+            const unsigned b = L.cid_idx[r], e = L.cid_idx[r + 1];
+            if (e <= b) continue;
+            if (ra_set_references(L.eng, L.d_ref + (size_t)r * npix)) die("ra_set_references");
+            if (ra_align(L.eng, L.d_sbj + (size_t)b * npix, (int)(e - b), L.d_state + 2 * (size_t)b, L.d_res + b, nullptr)) die("ra_align");
+        }
     }
     if (ra_transform_accumulate(L.eng, L.d_sbj, (int)B, 0, L.d_res, L.d_aligned, nullptr, nullptr)) die("transform");
     hipLaunchKernelGGL(class_mean_kernel, dim3(R, 8), dim3(256), 0, L.eng->stream, (int)npix, L.d_aligned, L.d_cid_idx, L.d_ref);

@@ -135,6 +135,9 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
 __global__ void pack_refs_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ refspec, int nref,
                                        float *__restrict__ Bf)
 {
+    // class-resident mode: gridDim.y classes of nref (= 1) references each, one B stream per class
+    refspec += (size_t)blockIdx.y * nref * g.lring;
+    Bf += (size_t)blockIdx.y * f.b_floats;
     const float inv = 1.0f / (float)g.maxrin;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < f.b_floats; idx += gridDim.x * blockDim.x) {
         const int code = f.bsrc[idx];
@@ -252,9 +255,11 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 template <int N, int NRPW>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
-                                                                  const float *__restrict__ Bf, int nref,
-                                                                  CandT *__restrict__ cand)
+                                                                  const float *__restrict__ Bf0, int nref,
+                                                                  CandT *__restrict__ cand, const int *__restrict__ cls)
 {
+    // cls != null (class-resident mode, one reference): particle p is aligned to reference cls[p], whose B stream is
+    // Bf0 + cls[p] * b_floats (pack_refs_fused_kernel with blockIdx.y = class)
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     extern __shared__ __align__(16) float lds[];
     // LDS plan of polar_fft_kernel, then the extras of this kernel
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
     RF_LDS_BARRIER();                           // the previous particle's last pass has left the image and `red`
     const float *src = particles + (size_t)p * g.nx * g.nx;
+    const float *Bf = cls ? Bf0 + (size_t)cls[p] * f.b_floats : Bf0;
     for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
         const int y = row - g.bd;
         const bool yin = y >= 0 && y < g.nx;

@@ -168,6 +168,14 @@ int  ra_get_prepared_references(ra_engine *e, float *h_crefim);
  * Asynchronous on the engine's stream. */
 int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
               ra_result *d_result, const float *cs);
+/* class-resident alignment (the ISAC mode behind ref_free_alignment_2D, cuda/gpu_aln_noref.cu:559-782): every particle
+ * against the average of its own class, all classes in one launch.  ra_set_class_references prepares ncls references
+ * (d_refs [ncls][nx][nx] device); ra_align_classes aligns particle i to reference d_cls[i] (device, [n]); results and
+ * state as ra_align.  Needs RA_MODE_REFFREE with nref = 1 on a geometry the fused search kernel covers
+ * (ra_search_path == 1); RA_ERR_STATE otherwise -- loop over the classes with ra_set_references / ra_align then. */
+int  ra_set_class_references(ra_engine *e, const float *d_refs, int ncls);
+int  ra_align_classes(ra_engine *e, const float *d_particles, int n, float *d_state,
+                      ra_result *d_result, const int *d_cls);
 /* apply rot_shift2D with the parameters in d_result and write the aligned images
  * (d_aligned [n][nx][nx], may be NULL) and/or add them into the class sums
  * (d_sums [nref][2][nx][nx] +=, d_counts [nref] +=, may be NULL);

@@ -959,10 +959,14 @@ def test_transform_kernel_matches_the_reference_tree_bit_for_bit(golden_dir):
         eng.close()
 
 
-def test_class_resident_alignment_isac_surface():
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["one-launch", "class-by-class"])
+def test_class_resident_alignment_isac_surface(fused, monkeypatch):
     """ref_free_alignment_2D* (cuda/gpu_aln_noref.h:94-109): every particle against the average of its own class
-    with ormq rules, rot_shift2D, class means rebuilt on the device, tangent filter of the averages"""
+    with ormq rules, rot_shift2D, class means rebuilt on the device, tangent filter of the averages; all classes in one
+    launch of the fused search kernel (ra_set_class_references / ra_align_classes) and, with the fused kernel switched
+    off, class by class through the kernel pair"""
     from oracle import refine_oracle as ro
+    monkeypatch.setenv("RALIGN_FUSED", fused)
     nx, ou, xr, ncls = 64, 25, 2, 5
     sizes = [17, 30, 1, 24, 40]
     refs = synth.make_references(ncls, nx, ou)
@@ -1011,6 +1015,37 @@ def test_class_resident_alignment_isac_surface():
         want = ro.filt_tanl(cur[c], 0.25, 0.1)
         assert np.abs(got_refs[c] - want).max() < 2e-4 * np.abs(want).max()
     lib.gpu_clear()
+
+
+def test_align_classes_equals_the_class_loop():
+    """ra_set_class_references + ra_align_classes (one launch, reference per particle) give the records of
+    ra_set_references + ra_align run class by class, bit for bit"""
+    nx, ou, xr, ncls = 64, 25, 2, 6
+    sizes = [9, 33, 1, 20, 64, 5]
+    refs = synth.make_references(ncls, nx, ou)
+    parts, cls = [], []
+    for c, m in enumerate(sizes):
+        p, _ = synth.make_particles(refs[c:c + 1], m, xr, xr, 0.5, shard=c, ou=ou)
+        parts.append(p); cls += [c] * m
+    parts = np.concatenate(parts); n = len(cls)
+    dev = torch.device("cuda:0")
+    eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE)
+    assert eng.search_path == 1
+    tp = torch.from_numpy(parts).to(dev); tr = torch.from_numpy(refs).to(dev)
+    tc = torch.tensor(cls, dtype=torch.int32, device=dev)
+    st1, res1 = eng.new_state(n), eng.new_result(n)
+    eng.set_class_references(tr)
+    eng.align_classes(tp, st1, res1, tc)
+    eng.sync()
+    st2, res2 = eng.new_state(n), eng.new_result(n)
+    start = 0
+    for c, m in enumerate(sizes):
+        eng.set_references(tr[c:c + 1])
+        eng.align(tp[start:start + m], st2[start:start + m], res2[start:start + m])
+        start += m
+    eng.sync()
+    assert torch.equal(res1, res2) and torch.equal(st1, st2)
+    eng.close()
 
 
 def test_size_check_says_no_when_it_does_not_fit_and_covers_what_init_allocates():
