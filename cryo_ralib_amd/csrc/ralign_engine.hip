@@ -137,7 +137,7 @@ static int build_device_geometry(ra_engine *e)
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
-    d.nn_weight = g.nn_weight; d.mode = e->cfg.mode; d.nomirror = 0;
+    d.nn_weight = g.nn_weight; d.mode = e->cfg.mode; d.nomirror = 0; d.quad_aligned = g.quad_aligned ? 1 : 0;
 #ifdef RALIGN_PROFILE_SWITCHES
     d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
     d.timeline = nullptr;
@@ -527,6 +527,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         return RA_ERR_ARG;
     }
     e->generic = !fits_specialised_kernels(e->geo, *cfg);
+    if (e->generic && e->geo.maxrin <= 1024 && !(getenv("RALIGN_QUAD_ALIGN") && atoi(getenv("RALIGN_QUAD_ALIGN")) == 0)) align_ring_quads(e->geo);
     if (e->geo.maxrin > 4096) {
         g_last_error = "rings longer than 4096 samples are not supported";
         delete e;
@@ -1241,7 +1242,9 @@ size_t legacy_bytes(unsigned num_particles, const AlignConfig *c)
         return (size_t)-1;
     ra_config rc = legacy_config(c, 0, RA_MODE_MREF);
     rc.chunk = (int)std::min<unsigned>(8192, std::max(2u, c->sbj_num));
-    const WorkspacePlan wp = plan_workspace(g, rc, !fits_specialised_kernels(g, rc));
+    const bool generic = !fits_specialised_kernels(g, rc);
+    if (generic && g.maxrin <= 1024) align_ring_quads(g);      // as ra_create: the panel size follows the layout
+    const WorkspacePlan wp = plan_workspace(g, rc, generic);
     const size_t npix = (size_t)c->img_dim * c->img_dim, B = c->sbj_num, R = c->ref_num;
     const size_t batch = B * npix * 4 * 2 + B * (2 * sizeof(float) + sizeof(ra_result)) + R * npix * 4 * 3 + R * 4;
     (void)num_particles;     // the AlignParam array lives in pinned host memory

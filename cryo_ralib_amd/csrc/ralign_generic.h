@@ -221,6 +221,65 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     // one sampling pass: ring FFTs and, in multi-reference mode, the Normalize_ring partial sums (added in ring order)
     float av = 0.f, sq = 0.f;
     float *blk = out + ((size_t)p * ngroup + grp) * g.a_blk;
+    if (g.quad_aligned) {
+        // Panels with ring quads aligned across bins (maxrin <= 1024): the spectra of rings 4c .. 4c+3 stay in registers
+        // (bin k = lane + 64 t, t < 9) and leave as whole float4 panel pieces, Re row and Im row of this offset slot --
+        // 16-byte stores instead of the 4-byte scattered ones of the loop below.
+        constexpr int T = 9;
+        int base[T], i0al[T];
+        float rns[T];
+        int nsk[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int k = min(lane + 64 * t, g.nbins - 1);
+            nsk[t] = (g.bin_offp[k + 1] - g.bin_offp[k]) >> 2;
+            rns[t] = 1.0f / (float)nsk[t];
+            base[t] = g.bin_offp[k] * 8 + 8 * slot;
+            i0al[t] = g.bin_first[k] & ~3;
+        }
+        for (int c4 = 0; c4 < g.nring; c4 += 4) {
+            float2 xq[4][T];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = c4 + r;
+                if (i < g.nring) {        // uniform
+                    const int4 ri = g.ringinfo[i];
+                    const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
+                    const float wt = g.ringw[i];
+                    float *xr = reinterpret_cast<float *>(bx);
+                    float a = 0.f, q = 0.f;
+                    for (int j = lane; j < nlen; j += 64) {
+                        const float sv = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+                        xr[j] = sv;
+                        a += sv * wt; q += sv * sv * wt;
+                    }
+                    av += wave_sum(a); sq += wave_sum(q);
+                    wave_lds_sync();
+                    const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        const int k = lane + 64 * t;
+                        xq[r][t] = k <= h ? split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]) : make_float2(0.f, 0.f);
+                    }
+                    wave_lds_sync();
+                } else {
+#pragma unroll
+                    for (int t = 0; t < T; t++) xq[r][t] = make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const int k = lane + 64 * t;
+                if (k < g.nbins && c4 >= i0al[t]) {
+                    const int j0 = c4 - i0al[t];
+                    const int kk = (int)(((float)j0 + 0.5f) * rns[t]), s4 = j0 - kk * nsk[t];      // j0 / ns, exact (see align_ring_quads)
+                    float *dst = blk + base[t] + (s4 >> 2) * 128 + kk * 32;
+                    *reinterpret_cast<float4 *>(dst) = make_float4(xq[0][t].x, xq[1][t].x, xq[2][t].x, xq[3][t].x);
+                    *reinterpret_cast<float4 *>(dst + 4) = make_float4(xq[0][t].y, xq[1][t].y, xq[2][t].y, xq[3][t].y);
+                }
+            }
+        }
+    } else
     for (int i = 0; i < g.nring; i++) {
         const int4 ri = g.ringinfo[i];
         const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;

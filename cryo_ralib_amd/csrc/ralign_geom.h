@@ -33,6 +33,8 @@ struct Geometry {
     std::vector<int> samp_dst;     // [lcirc] destination float index in the padded ring buffer
     std::vector<float> samp_w;     // [lcirc] Normalize_ring weight r*2pi/n of the sample's ring
     std::vector<int> bin_first;    // [nbins] first ring that has bin k (rings are a suffix)
+    std::vector<int> lead;         // [nbins] empty ring slots in front of bin k's rings (align_ring_quads; else 0)
+    bool quad_aligned = false;     // ring quads aligned across bins (align_ring_quads)
     std::vector<int> bin_off;      // [nbins+1] prefix of ring counts     (A layout)
     std::vector<int> bin_offp;     // [nbins+1] prefix of padded counts   (B layout)
     std::vector<int> ent_src;      // [LB] float offset (ring_off[i] + 2k) of entry e=(k,i)
@@ -108,6 +110,7 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
 
     // bin-major contraction layout
     g.bin_first.assign(g.nbins, 0);
+    g.lead.assign(g.nbins, 0); g.quad_aligned = false;
     g.bin_off.assign(g.nbins + 1, 0); g.bin_offp.assign(g.nbins + 1, 0);
     for (int k = 0; k < g.nbins; k++) {
         int i0 = 0;
@@ -150,6 +153,21 @@ inline int panel_pos(int ns, int rows, int kk, int row, int s)
     return off + (kk * rows + row);
 }
 
+// Size-generic kernels (large boxes): ring slot j of bin k is ring (bin_first[k] & ~3) + j and every bin holds a multiple of
+// 16 slots, so that the four rings of a panel float4 are rings 4c .. 4c+3 for EVERY bin.  polar_generic_kernel can then
+// keep four rings in registers and store whole 16-byte panel pieces (its 4-byte scattered stores cost 5x the panel size in
+// HBM writes); the price is <= 15 zero slots per bin in the contraction.  Call before build_operand_tables.
+inline void align_ring_quads(Geometry &g)
+{
+    g.quad_aligned = true;
+    for (int k = 0; k < g.nbins; k++) {
+        g.lead[k] = g.bin_first[k] & 3;
+        const int cnt = g.nring - g.bin_first[k] + g.lead[k];
+        g.bin_offp[k + 1] = g.bin_offp[k] + (cnt + 15) / 16 * 16;
+    }
+    g.LBP = g.bin_offp[g.nbins];
+}
+
 // a_src: per A-block float, the source offset inside the 4 LDS ring buffers (stride sbuf) | offset slot << 24, -1 = 0
 // b_src: per B-tile float, (entry e << 4 | col), -1 = 0
 inline void build_operand_tables(Geometry &g, int sbuf)
@@ -161,7 +179,7 @@ inline void build_operand_tables(Geometry &g, int sbuf)
         const int cnt = g.bin_off[k + 1] - g.bin_off[k], kp = g.bin_offp[k + 1] - g.bin_offp[k];
         const int ns = kp / 4;
         for (int j = 0; j < cnt; j++) {
-            const int kk = j / ns, s = j % ns, e = g.bin_off[k] + j;
+            const int jj = j + g.lead[k], kk = jj / ns, s = jj % ns, e = g.bin_off[k] + j;
             g.ent_apos[2 * e] = g.bin_offp[k] * 8 + panel_pos(ns, 8, kk, 0, s);
             g.ent_apos[2 * e + 1] = panel_pos(ns, 8, kk, 1, s) - panel_pos(ns, 8, kk, 0, s);
             for (int row = 0; row < 8; row++)

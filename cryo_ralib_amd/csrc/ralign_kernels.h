@@ -49,6 +49,7 @@ struct DevGeom {
     float nn_weight;
     int mode;                     // RA_MODE_*
     int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
+    int quad_aligned;             // generic kernels: ring quads aligned across bins (ralign_geom.h: align_ring_quads)
     int dbg;                      // phase-skip mask of profiling builds (-DRALIGN_PROFILE_SWITCHES); unused otherwise
     unsigned long long *timeline; // profiling builds: [pass][wave][stamp] clock values of workgroup 0's first particle, or null
     int sbuf;                     // LDS stride of one ring buffer (floats)
