@@ -1046,6 +1046,15 @@ def test_align_classes_equals_the_class_loop():
     eng.sync()
     assert torch.equal(res1, res2) and torch.equal(st1, st2)
     eng.close()
+    # protocol: the class-resident launch needs one reference in ormq mode, and its references before the search
+    eng = api.Engine(nx, ou, xr, xr, 1.0, 3, api.RA_MODE_MREF)
+    with pytest.raises(api.EngineError):
+        eng.set_class_references(tr)
+    eng.close()
+    eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE)
+    with pytest.raises(api.EngineError):
+        eng.align_classes(tp, st1, res1, tc)
+    eng.close()
 
 
 def test_size_check_says_no_when_it_does_not_fit_and_covers_what_init_allocates():
