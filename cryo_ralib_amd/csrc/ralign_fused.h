@@ -51,6 +51,8 @@ struct FusedGeom {
     int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's)
     int gstr;                      // ints per group in the LDS table of ring offsets (quads of 4, padded by one quad)
     const float *cdc_w;            // [nref] DC weights of the references: sum over rings of n_r * B_r(bin 0) (ref_dc_weights_kernel)
+    int wmap[16];                  // contraction role of wave w: bin group | share of the reference pairs << 8 (balance_waves)
+    int stat_wave[4];              // the wave that reduces the Normalize_ring partials of offset slot s
 };
 
 struct FusedPlanHost {
@@ -107,6 +109,32 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
         boff += f.nrp * f.grp_nq[m] * 256;
     }
     f.b_floats = boff;
+    // Contraction roles.  Waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD, and the matrix pipe of a SIMD is what the
+    // contraction phase runs on (wave timeline: ~8 matrix cycles x 8 NH instructions per ring quad and wave): deal the
+    // (bin group, share of the reference pairs) items to the waves so that the four SIMDs get equal numbers of matrix
+    // instructions, the heavier items to the older waves (the SIMDs issue oldest first).
+    {
+        struct Item { int m, s, cost; };
+        std::vector<Item> items;
+        for (int m = 0; m < f.ng; m++)
+            for (int sh = 0; sh < f.wpg; sh++) {
+                const int pairs = std::max(0, std::min(f.nrpw, f.nrp - sh * f.nrpw));
+                items.push_back({m, sh, f.grp_nq[m] * pairs});
+            }
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+        int light[4] = {0, 1, 2, 3};
+        for (const Item &it : items) {
+            int c = -1;
+            for (int q = 0; q < 4; q++)
+                if (used[q] < 4 && (c < 0 || load[q] < load[c])) c = q;
+            const int w = c + 4 * used[c];
+            f.wmap[w] = it.m | (it.s << 8);
+            load[c] += it.cost; used[c]++;
+            light[c] = w;            // items arrive heaviest first: the last one of a class is its lightest
+        }
+        for (int q = 0; q < 4; q++) f.stat_wave[q] = light[q];
+    }
     out.bsrc.assign(boff, -1);
     for (int m = 0; m < f.ng; m++)
         for (int rp = 0; rp < f.nrp; rp++)
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
     // compiler cannot see through -- red[7], rewritten per pass -- so that it is not hoisted out of the pass loop and
     // kept alive across the ring jobs, which need every register they can get.)
     constexpr int NU = 2 * NRPW;
-    const int xm = wave / f.wpg, rp0 = (wave % f.wpg) * NRPW;
+    const int xm = f.wmap[wave] & 255, rp0 = (f.wmap[wave] >> 8) * NRPW;
 
     const int ngroup = g.nshift_pad / 4;
 #pragma unroll 1
@@ -368,12 +396,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         }
         RF_LDS_BARRIER();
         RA_STAMP(g, tl, grp, wave, 2);
-        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One wave per offset (waves 1, 3, 5, 7) reduces its ring partials
+        // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One wave per offset (the lightest contraction role of each SIMD) reduces its ring partials
         // with a fixed butterfly (reproducible) on its way into the contraction; nobody waits for it: subtracting avg from
         // every sample only moves the DC coefficients, so the correction is applied to the contracted DC term
         // (a -= avg * sum_r n_r B_r(0), store_round) and 1/sigma to the peak record.
-        if ((wave & 1) && wave < 8) {            // waves 1, 3, 5, 7: the odd wave of a bin group holds the smaller share of the
-            const int os = wave >> 1;            // reference pairs, and the oldest waves finish their contraction first
+        const int os = wave == f.stat_wave[0] ? 0 : wave == f.stat_wave[1] ? 1 : wave == f.stat_wave[2] ? 2 : wave == f.stat_wave[3] ? 3 : -1;
+        if (os >= 0) {                           // the wave with the lightest contraction role of each SIMD
             float a = 0.f, q = 0.f;
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum(a); q = wave_sum(q);
