@@ -253,10 +253,13 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 #pragma unroll
     for (int h = 0; h < NH; h++) bA[h] = b0[h];      // quad 0 was requested before the barrier that ends the ring jobs
     read_a(oA, aA);
+    // Both multiplies of a trip are unconditional: with the second one under `if (rq + 1 < nq)` the compiler sank the
+    // requests of its B operands into that block, right in front of their use (one exposed memory latency per trip); an
+    // odd last quad is multiplied after the loop.
 #pragma unroll 1
-    for (int rq = 0; rq < nq; rq += 2) {
+    for (int rq = 0; rq + 1 < nq; rq += 2) {
         RA_STAMP(g, tl && rq < 12, tgrp, twave, 9 + (rq >> 1));      // profiling builds: iteration starts (stamps 9 .. 14)
-        load_b(min(rq + 1, ql), bB);
+        load_b(rq + 1, bB);
         read_a(oB, aB);
         oA = gq[min(rq + 2, ql)];
         __builtin_amdgcn_sched_barrier(0);
@@ -266,9 +269,10 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         read_a(oA, aA);
         oB = gq[min(rq + 3, ql)];
         __builtin_amdgcn_sched_barrier(0);
-        if (rq + 1 < nq) mul_rq(aB, bB);
+        mul_rq(aB, bB);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (nq & 1) mul_rq(aA, bA);
 }
 
 // workgroup barrier that orders LDS traffic only: global requests (the B stream, the record stores) stay in flight
