@@ -202,7 +202,7 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
 template <int NRPW, int NH>
 __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f, const float *bufs, const int *goff_s,
                                             const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW],
-                                            const float4 (&b0)[NRPW], bool tl = false, int tgrp = 0, int twave = 0)
+                                            const float4 (&b0)[NRPW], int4 oA, int4 oB, bool tl = false, int tgrp = 0, int twave = 0)
 {
     const int xb = ln >> 2, xj = ln & 3;
     const int nq = f.grp_nq[xm];
@@ -213,13 +213,19 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
     float4 bA[NH], bB[NH];
     float aA[8], aB[8];
+#ifdef RALIGN_PROFILE_SWITCHES
+    for (int h = 0; h < NH; h++) bB[h] = b0[h];          // defined operands for the switches that skip the requests
+    for (int c = 0; c < 8; c++) aA[c] = aB[c] = (float)(ln + c);
+#endif
     auto load_b = [&](int rq, float4 (&b)[NH]) {
+        if (RA_DBG(g, 512)) return;       // profiling: no B requests in the loop
 #pragma unroll
         for (int h = 0; h < NH; h++)      // a pair beyond the last one re-reads the last: its units are never stored
             b[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : (min(rp0 + h, f.nrp - 1) * nq + rq) * 256));
     };
     auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
         if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
+        if (RA_DBG(g, 2048)) return;      // profiling: no A reads in the loop
         a[0] = *reinterpret_cast<const float *>(abase + o.x); a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off);
         a[2] = *reinterpret_cast<const float *>(abase + o.y); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
         a[4] = *reinterpret_cast<const float *>(abase + o.z); a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off);
@@ -249,7 +255,6 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // for every wave whatever its share; three B buffers (requests two multiplies ahead), non-temporal loads and fewer
     // active CUs change nothing: 235 KB per pass reach a CU at ~21 B/clk, the miss parallelism of its vector L1.
     const int ql = nq - 1;
-    int4 oA = gq[0], oB = gq[min(1, ql)];
 #pragma unroll
     for (int h = 0; h < NH; h++) bA[h] = b0[h];      // quad 0 was requested before the barrier that ends the ring jobs
     read_a(oA, aA);
@@ -398,6 +403,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             for (int h = 0; h < NRPW; h++)
                 b0[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : min(rp0 + h, f.nrp - 1) * nq * 256));
         }
+        // ... and so do the ring offsets of its first two quads (a static table) and the cleared accumulators
+        const int4 o0 = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr)[0];
+        const int4 o1 = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr)[min(1, f.grp_nq[xm] - 1)];
+        f32x4 acc[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         RF_LDS_BARRIER();
         RA_STAMP(g, tl, grp, wave, 2);
         // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One wave per offset (the lightest contraction role of each SIMD) reduces its ring partials
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         if (os >= 0) {                           // the wave with the lightest contraction role of each SIMD
             float a = 0.f, q = 0.f;
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
-            a = wave_sum(a); q = wave_sum(q);
+            a = wave_sum_dpp(a); q = wave_sum_dpp(q);
             float avg = 0.f, rsg = 1.f;
             if (g.mode == RA_MODE_MREF) {
                 const float nn = g.nn_weight;
@@ -425,13 +436,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         }
         // ---- contraction: accumulate this wave's units over the rings that have bins of its group
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
-        f32x4 acc[NU];
-#pragma unroll
-        for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
             // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
-            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, tl, grp, wave);
-            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, tl, grp, wave);
+            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
         }
         RA_STAMP(g, tl, grp, wave, 3);
         RF_LDS_BARRIER();                       // every wave has finished reading the ring buffers

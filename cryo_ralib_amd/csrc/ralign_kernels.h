@@ -105,6 +105,18 @@ template <int LR> __device__ __forceinline__ float group_sum_dpp(float v)
     return v;
 }
 
+// sum over the 64 lanes without LDS traffic: row totals by DPP, the four rows through scalar registers, fixed order
+// ((r0 + r1) + (r2 + r3)); __shfl_xor is a ds_bpermute, i.e. six dependent LDS round trips per sum
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v = group_sum_dpp<16>(v);
+    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a0 + a1) + (a2 + a3);
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -959,32 +971,36 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
     }
 #pragma unroll
     for (int q = 0; q < NP; q++) {
+        // Maximum first, index second: the running maximum of both sequences is one v_max per value, the 16-lane maximum
+        // one DPP v_max per step, and only the sequence that wins (straight on ties: qn >= qm, Util::multiref_polar_ali_2d;
+        // nomirror: Crosrng_ns, straight only) is searched for the position of its maximum -- the LAST element equal to it
+        // (the CPU scan's ">=" keeps the last maximum; ascending n1 within the lane, the larger index across lanes).
         float bq = -1.0e20f, bt = -1.0e20f;
-        int iq = 0, it = 0;
         if (j < R1) {
 #pragma unroll
-            for (int n1 = 0; n1 < R2; n1++) {
-                const int ix = R1 * n1 + j;    // ascending in n1: ">=" keeps the last maximum
-                if (v[q][n1].x >= bq) { bq = v[q][n1].x; iq = ix; }
-                if (v[q][n1].y >= bt) { bt = v[q][n1].y; it = ix; }
-            }
+            for (int n1 = 0; n1 < R2; n1++) { bq = __builtin_fmaxf(bq, v[q][n1].x); bt = __builtin_fmaxf(bt, v[q][n1].y); }
         }
-        // 16-lane argmax, ties -> larger index; DPP row permutes (mirror 15-i, half mirror 7-i, quad [2,3,0,1], quad
-        // [1,0,3,2]) reach all 16 lanes of the row, and every lane ends up with the row's winner
-#define RA_DPP_STEP(CTRL)                                                                                              \
-        {                                                                                                              \
-            const float oq = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bq), CTRL, 0xF, 0xF, true));  \
-            const int oiq = __builtin_amdgcn_update_dpp(0, iq, CTRL, 0xF, 0xF, true);                                  \
-            const float ot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bt), CTRL, 0xF, 0xF, true));  \
-            const int oit = __builtin_amdgcn_update_dpp(0, it, CTRL, 0xF, 0xF, true);                                  \
-            if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }                                              \
-            if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }                                              \
-        }
-        RA_DPP_STEP(0x140) RA_DPP_STEP(0x141) RA_DPP_STEP(0x4E) RA_DPP_STEP(0xB1)
-#undef RA_DPP_STEP
-        // qn >= qm keeps the straight match (Util::multiref_polar_ali_2d); nomirror: Crosrng_ns, straight only
+        // DPP row permutes (mirror 15-i, half mirror 7-i, quad [2,3,0,1], quad [1,0,3,2]) reach all 16 lanes of the row
+#define RA_DPP_FMAX(X, CTRL) X = __builtin_fmaxf(X, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xF, 0xF, true)))
+        RA_DPP_FMAX(bq, 0x140); RA_DPP_FMAX(bt, 0x140); RA_DPP_FMAX(bq, 0x141); RA_DPP_FMAX(bt, 0x141);
+        RA_DPP_FMAX(bq, 0x4E); RA_DPP_FMAX(bt, 0x4E); RA_DPP_FMAX(bq, 0xB1); RA_DPP_FMAX(bt, 0xB1);
+#undef RA_DPP_FMAX
         const bool mir = !nomirror && !(bq >= bt);
-        const int jt = mir ? it : iq;
+        const float best = mir ? bt : bq;
+        float c[R2];
+        int jt = -1;
+        if (j < R1) {
+            int nb = -1;
+#pragma unroll
+            for (int n1 = 0; n1 < R2; n1++) {
+                c[n1] = mir ? v[q][n1].y : v[q][n1].x;
+                nb = c[n1] == best ? n1 : nb;
+            }
+            jt = nb >= 0 ? R1 * nb + j : -1;
+        }
+#define RA_DPP_IMAX(CTRL) jt = max(jt, __builtin_amdgcn_update_dpp(0, jt, CTRL, 0xF, 0xF, true))
+        RA_DPP_IMAX(0x140); RA_DPP_IMAX(0x141); RA_DPP_IMAX(0x4E); RA_DPP_IMAX(0xB1);
+#undef RA_DPP_IMAX
         CandT *dst = pc + pr[q];
         // neighbour jt + k (k = -3..3) lives in lane (jt + k) mod R1 at register (jt + k) / R1
         const int d = (j - jt) & (R1 - 1);
@@ -993,14 +1009,11 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
             const int n1 = ((jt + k + N) & (N - 1)) / R1;
             float val = 0.f;
 #pragma unroll
-            for (int r = 0; r < R2; r++) {
-                const float c = mir ? v[q][r].y : v[q][r].x;
-                val = (r == n1) ? c : val;
-            }
+            for (int r = 0; r < R2; r++) val = (r == n1) ? c[r] : val;
             dst->t7[k + 3] = val;
         }
         if (j == 0) {
-            dst->val = mir ? bt : bq;
+            dst->val = best;
             dst->jtot = jt + 1;
             dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + (pr[q] & REFMASK));
         }
