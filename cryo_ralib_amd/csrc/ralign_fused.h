@@ -254,30 +254,59 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // path plus the matrix instructions.  The wave timeline (scripts/fused_timeline.sh) shows ~1000 cycles per ring quad
     // for every wave whatever its share; three B buffers (requests two multiplies ahead), non-temporal loads and fewer
     // active CUs change nothing: 235 KB per pass reach a CU at ~21 B/clk, the miss parallelism of its vector L1.
-    const int ql = nq - 1;
+    // quad 0 (its B operands were requested before the barrier that ends the ring jobs) starts the accumulators: C = 0
+    // is an inline constant of the matrix instruction, so nothing is cleared
+    auto mul_first = [&](const float (&a)[8], const float4 (&b)[NRPW]) {
+        if (RA_DBG(g, 128)) {
 #pragma unroll
-    for (int h = 0; h < NH; h++) bA[h] = b0[h];      // quad 0 was requested before the barrier that ends the ring jobs
+            for (int i = 0; i < 2 * NH; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[h].x, zero, 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[h].x, zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 1; c < 4; c++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
+                acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int i = 2 * NH; i < 2 * NRPW; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};      // a dummy pair: defined, never stored
+    const int ql = nq - 1;
     read_a(oA, aA);
+    load_b(min(1, ql), bB);
+    read_a(oB, aB);
+    oA = gq[min(2, ql)];
+    __builtin_amdgcn_sched_barrier(0);
+    mul_first(aA, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    // Quads 1 .. nq - 1, two per trip; at the head of a trip (aB, bB) hold quad rq and oA the ring offsets of quad rq + 1.
     // Both multiplies of a trip are unconditional: with the second one under `if (rq + 1 < nq)` the compiler sank the
-    // requests of its B operands into that block, right in front of their use (one exposed memory latency per trip); an
-    // odd last quad is multiplied after the loop.
+    // requests of its B operands into that block, right in front of their use (one exposed memory latency per trip); a
+    // last single quad is multiplied after the loop.
 #pragma unroll 1
-    for (int rq = 0; rq + 1 < nq; rq += 2) {
+    for (int rq = 1; rq + 1 < nq; rq += 2) {
         RA_STAMP(g, tl && rq < 12, tgrp, twave, 9 + (rq >> 1));      // profiling builds: iteration starts (stamps 9 .. 14)
-        load_b(rq + 1, bB);
-        read_a(oB, aB);
-        oA = gq[min(rq + 2, ql)];
-        __builtin_amdgcn_sched_barrier(0);
-        mul_rq(aA, bA);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(min(rq + 2, ql), bA);
+        load_b(rq + 1, bA);
         read_a(oA, aA);
-        oB = gq[min(rq + 3, ql)];
+        oB = gq[min(rq + 2, ql)];
         __builtin_amdgcn_sched_barrier(0);
         mul_rq(aB, bB);
         __builtin_amdgcn_sched_barrier(0);
+        load_b(min(rq + 2, ql), bB);
+        read_a(oB, aB);
+        oA = gq[min(rq + 3, ql)];
+        __builtin_amdgcn_sched_barrier(0);
+        mul_rq(aA, bA);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (nq & 1) mul_rq(aA, bA);
+    if (!(nq & 1)) mul_rq(aB, bB);
 }
 
 // workgroup barrier that orders LDS traffic only: global requests (the B stream, the record stores) stay in flight
@@ -403,12 +432,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             for (int h = 0; h < NRPW; h++)
                 b0[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : min(rp0 + h, f.nrp - 1) * nq * 256));
         }
-        // ... and so do the ring offsets of its first two quads (a static table) and the cleared accumulators
+        // ... and so do the ring offsets of its first two quads (a static table)
         const int4 o0 = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr)[0];
         const int4 o1 = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr)[min(1, f.grp_nq[xm] - 1)];
         f32x4 acc[NU];
-#pragma unroll
-        for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         RF_LDS_BARRIER();
         RA_STAMP(g, tl, grp, wave, 2);
         // Normalize_ring: avg = av/nn, sigma = sqrt((sq - av^2/nn)/nn).  One wave per offset (the lightest contraction role of each SIMD) reduces its ring partials
@@ -422,9 +449,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             a = wave_sum_dpp(a); q = wave_sum_dpp(q);
             float avg = 0.f, rsg = 1.f;
             if (g.mode == RA_MODE_MREF) {
-                const float nn = g.nn_weight;
-                avg = a / nn;
-                rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
+                // avg = av / nn, 1 / sigma = 1 / sqrt((sq - av^2 / nn) / nn) with the host's 1 / nn and v_rsq_f32 (1 ulp):
+                // four IEEE divisions and a square root are ~100 instructions on the wave that ends the phase
+                avg = a * g.inv_nn_weight;
+                rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
             }
             if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
         } else if (wave == 4 && lane < 4 && grp + 1 < ngroup) {
@@ -440,6 +468,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
             if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
             else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         RA_STAMP(g, tl, grp, wave, 3);
         RF_LDS_BARRIER();                       // every wave has finished reading the ring buffers

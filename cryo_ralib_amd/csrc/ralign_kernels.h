@@ -47,6 +47,7 @@ struct DevGeom {
     int nshift, nshift_pad, nkx, nky;
     float step, xrng, yrng;
     float nn_weight;
+    float inv_nn_weight;           // 1 / nn_weight, rounded once on the host
     int mode;                     // RA_MODE_*
     int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
     int quad_aligned;             // generic kernels: ring quads aligned across bins (ralign_geom.h: align_ring_quads)
