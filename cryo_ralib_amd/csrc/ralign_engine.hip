@@ -137,7 +137,7 @@ static int build_device_geometry(ra_engine *e)
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
-    d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.mode = e->cfg.mode; d.nomirror = 0; d.quad_aligned = g.quad_aligned ? 1 : 0;
+    d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.quad_aligned = g.quad_aligned ? 1 : 0;
 #ifdef RALIGN_PROFILE_SWITCHES
     d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
     d.timeline = nullptr;

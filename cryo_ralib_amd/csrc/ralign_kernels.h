@@ -48,6 +48,7 @@ struct DevGeom {
     float step, xrng, yrng;
     float nn_weight;
     float inv_nn_weight;           // 1 / nn_weight, rounded once on the host
+    int lg_maxrin;                 // log2(maxrin): twiddle strides are shifts (v_mul_lo_u32 is quarter rate)
     int mode;                     // RA_MODE_*
     int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
     int quad_aligned;             // generic kernels: ring quads aligned across bins (ralign_geom.h: align_ring_quads)
@@ -166,7 +167,9 @@ __device__ __forceinline__ float bilinear_pad(const float *base, int st, float x
     // the column lerp (4 instructions; differs from Util::bilinear's operation order by rounding only, < 1 ulp of the taps)
     const v2f r0 = {p[0], p[1]}, r1 = {p[st], p[st + 1]};
     const v2f g = __builtin_elementwise_fma((v2f){ydif, ydif}, r1 - r0, r0);
-    return __builtin_fmaf(xdif, g.y - g.x, g.x);
+    float d = g.y - g.x;
+    asm("" : "+v"(d));      // keeps the column lerp scalar: packed over two samples it costs three register moves
+    return __builtin_fmaf(xdif, d, g.x);
 #endif
 }
 
@@ -413,19 +416,20 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         return;
     }
     Dft<-1, R1>::run(v);
-    const int tstep = __mul24(t, g.maxrin / H);
+    constexpr int LGH = __builtin_ctz(H), LGNR = LGH + 1;
+    const int tstep = t << (g.lg_maxrin - LGH);      // t * maxrin / H
     // element (row c, column t) is parked at LR*c + ((t + c) mod LR): conflict-free both ways
 #pragma unroll
     for (int c = 0; c < R1; c++) {
         float2 o = v[c];
-        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c) & (g.maxrin - 1)]);      // 24-bit multiplies are full rate, v_mul_lo_u32 is not
+        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c)]);      // t c < H: no wrap; 24-bit multiplies are full rate, v_mul_lo_u32 is not
         *reinterpret_cast<float2 *>(buf + 2 * (LR * c + ((t + c) & (LR - 1)))) = o;
     }
     RA_WAVE_SYNC();
     // real-FFT split step of one pair: X_k and X_{H-k} from Z_k, Z_{H-k} (k = 0 gives X_0 and the Nyquist term X_H)
     auto split_pair = [&](float2 zk, float2 zm, int k, float2 &xk, float2 &xm) {
         v2f a, b;
-        vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[__mul24(k, g.maxrin / NR)]), a, b);
+        vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[k << (g.lg_maxrin - LGNR)]), a, b);
         xk = to_f2(a); xm = to_f2(b);
     };
     if constexpr (R1 == 2 * LR) {
@@ -561,11 +565,11 @@ __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb
         v[a] = make_float2(val.x, val.y);
     }
     Dft<-1, 4>::run(v);
-    const int tstep = __mul24(t, g.maxrin >> (lg - 1));          // maxrin / H
+    const int tstep = t << (g.lg_maxrin - (lg - 1));          // t * maxrin / H
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float2 o = v[c];
-        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c) & (g.maxrin - 1)]);
+        if (c > 0) o = cmul(o, tw_s[__mul24(tstep, c)]);      // t c < H: no wrap
         *reinterpret_cast<float2 *>(buf + 2 * ((c << lgLR) + ((t + c) & (LR - 1)))) = o;
     }
     RA_WAVE_SYNC();
@@ -602,7 +606,7 @@ __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb
             } else {
                 const float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
                 v2f xk, xm;
-                vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[__mul24(k, g.maxrin >> lg)]), xk, xm);
+                vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[k << (g.lg_maxrin - lg)]), xk, xm);
                 *reinterpret_cast<float2 *>(buf + 2 * k) = to_f2(xk);
                 if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = to_f2(xm);
             }
