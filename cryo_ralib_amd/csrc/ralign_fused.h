@@ -488,6 +488,17 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
             const int ref_b = 2 * rp0 + (xj >> 1);
             float *zk = bufs + (odd * f.rz + ref_b - ref_lo) * ZL::kPairStride + 2 * (k + (k >> 4));
             const int dkm = 2 * (km + (km >> 4)) - 2 * (k + (k >> 4));
+            // Normalize_ring mean x DC weight of every unit (bin group 0 only), read up front: under the unit's own condition
+            // each of the reads is a dependent LDS round trip of its own
+            float dcv[NU];
+            if (xm == 0) {
+                const float av0 = red[8 + odd], av1 = red[10 + odd];
+#pragma unroll
+                for (int h = 0; h < NRPW; h++) {
+                    const float w = cdc_s[min(ref_b + 2 * h, nref - 1)];
+                    dcv[2 * h] = av0 * w; dcv[2 * h + 1] = av1 * w;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NU; i++) {
                 const int h = i >> 1, op = i & 1, ref = ref_b + 2 * h, o = 2 * op + odd, rr = ref - ref_lo;
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const bool live = ref < nref && rr >= 0 && rr < nrz && o < nlive;      // ref < nref implies a real reference pair
                 float2 vk, vm;
                 if (xm == 0) {                                            // wave-uniform: the group that holds bin 0
-                    if (xb == 0 && live) ca -= red[8 + o] * cdc_s[ref];  // Normalize_ring mean: the DC term only
+                    if (xb == 0 && live) ca -= dcv[i];                    // Normalize_ring mean: the DC term only
                     const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                     vk = xb == 0 ? make_float2(ca, ca) : make_float2(apd + bpc, cmb + amd);
                     vm = xb == 0 ? make_float2(cd, cd) : make_float2(apd - bpc, amd - cmb);
