@@ -318,6 +318,13 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
     } while (0)
 
+// ring_job's `sync`: the workgroup barrier that ends the previous pass's inverse FFTs, taken between the sampling and
+// the first write to the ring buffers (on = wave-uniform)
+struct PassSync {
+    bool on;
+    __device__ __forceinline__ void operator()() const { if (on) RF_LDS_BARRIER(); }
+};
+
 template <int N, int NRPW>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
@@ -394,11 +401,32 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         red[7] = 0.f;
     }
     RF_LDS_BARRIER();
+    const bool defer = f.nzr == 1;      // one store / inverse-FFT round per pass: its closing barrier moves into the next pass
+    // best reference per offset of pass gr (ascending reference, ">=": later wins), scaled by 1/sigma; by wave 2: an old
+    // wave -- it gets through its ring job first -- that is not the one with the extra short job
+    auto reduce_records = [&](int gr, int nl) {
+        constexpr int W = sizeof(CandT) / 4;
+        if (wave == 2 && lane < nl * W) {
+            const int o = lane / W, wd = lane - o * W;
+            float bv = pc[o * nref].val; int br = 0;
+            for (int q3 = 1; q3 < nref; q3++) {
+                const float v = pc[o * nref + q3].val;
+                if (v >= bv) { bv = v; br = q3; }
+            }
+            int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
+            if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
+            reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
+        }
+    };
     for (int grp = 0; grp < ngroup; grp++) {
         const bool tl = p == (int)blockIdx.x && blockIdx.x == 0;      // timeline: first particle of workgroup 0
         RA_STAMP(g, tl, grp, wave, 0);
-        // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel)
+        // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel).
+        // The spectra of the previous pass occupy the ring buffers until its inverse FFTs are done; the barrier that says so
+        // is taken INSIDE this pass's first ring job, after the sampling (which touches only the image and the tables): a
+        // wave that is through with its inverse FFTs -- or had none -- samples while the others still transform.
         const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
+        const bool pend = defer && grp > 0;
         if (!RA_DBG(g, 16)) {
 #pragma unroll 1
             for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
@@ -407,19 +435,24 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const int job = jr * RF_WAVES + wave;
                 if (job >= g.n_job) continue;
                 const int4 jd = jobs_s[job];
+                const PassSync ps = {pend && jr == 0};
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
-                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive); break;
+                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 }
             }
+            if (pend && wave >= g.n_job) RF_LDS_BARRIER();      // a wave without a job in round 0
+        } else if (pend) {
+            RF_LDS_BARRIER();
         }
+        if (pend) reduce_records(grp - 1, 4);                  // only the last pass can carry padding offsets
         RA_STAMP(g, tl, grp, wave, 1);
         // lane roles of the contraction (see above), and its first B quad: requested here, it travels while the last ring
         // jobs finish and the barrier is crossed (the barrier does not drain global requests)
@@ -542,7 +575,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 RA_STAMP(g, tl, grp, wave, 6);
                 ifft_round(0, nref);
                 RA_STAMP(g, tl, grp, wave, 7);
-                RF_LDS_BARRIER();
+                if (grp + 1 == ngroup) RF_LDS_BARRIER();      // otherwise taken inside the next pass's ring jobs (`pend`)
                 RA_STAMP(g, tl, grp, wave, 8);
             } else {
                 for (int zr = 0; zr < f.nzr; zr++) {
@@ -553,25 +586,13 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                     RF_LDS_BARRIER();
                 }
             }
+        } else if (defer && grp + 1 == ngroup) {
+            RF_LDS_BARRIER();
         }
-        // best reference per offset of the pass (ascending reference, ">=": later wins), scaled by 1/sigma
-        // (by wave 2: an old wave -- it gets through its ring job of the next pass first -- that is not the one with the
-        // extra short job)
-        if (wave == 2 && lane < nlive * (int)(sizeof(CandT) / 4)) {
-            constexpr int W = sizeof(CandT) / 4;
-            const int o = lane / W, wd = lane - o * W;
-            float bv = pc[o * nref].val; int br = 0;
-            for (int q3 = 1; q3 < nref; q3++) {
-                const float v = pc[o * nref + q3].val;
-                if (v >= bv) { bv = v; br = q3; }
-            }
-            int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
-            if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
-            reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + grp * 4 + o)[wd] = word;
-        }
-        // no barrier here: the next pass's ring jobs touch the ring buffers (free since the barrier after the inverse
-        // FFTs), the ring partials (read before the contraction barrier) and the centres (written after the first
-        // barrier of this pass); `pc` and red[12..15] are next written two and one barriers into the next pass
+        if (!defer || grp + 1 == ngroup) reduce_records(grp, nlive);
+        // no barrier here: the next pass's ring jobs sample first (image and tables only) and take the barrier before they
+        // touch the ring buffers; the ring partials were read before the contraction barrier, the centres written after
+        // the first barrier of this pass; `pc` and red[12..15] are next written two and one barriers into the next pass
     }
     }
 }

@@ -329,10 +329,16 @@ __device__ __forceinline__ void ring_fft_all(const DevGeom &g, float *bufs, int 
 // `part` receives the Normalize_ring partial sums {sum w x, sum w x^2} of every (offset slot, ring).  NYQ1 (fused
 // search kernel): the Nyquist coefficient of a full-length ring (n == maxrin) is stored in the imaginary slot of
 // bin 0, EMAN2's own packing, so that the contraction sees bins 0 .. maxrin/2 - 1 only.
-template <int R1, int LR, bool NYQ1 = false>
+// `sync` runs once, in uniform control flow, between the sampling (which reads the image and the tables only) and the first
+// write to the ring buffers: the fused kernel passes the workgroup barrier that ends the previous pass's inverse FFTs there
+// (their spectra occupy the ring buffers), so a wave samples while the others still transform.
+struct NoSync { __device__ __forceinline__ void operator()() const {} };
+
+template <int R1, int LR, bool NYQ1 = false, class Sync = NoSync>
 __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                          const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
-                                         const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4)
+                                         const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4,
+                                         Sync sync = Sync())
 {
     // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
     // inside the job instead of hoisted out of the pass loop for all six variants (VGPR spills)
@@ -340,12 +346,13 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
 
     constexpr int H = R1 * LR, NR = 2 * H, LT = NR / 4;
     const int sub = lane / LR, t = lane % LR;
-    if (sub >= count) return;
-    const int4 in = inst_s[inst0 + sub];
+    const int subc = min(sub, count - 1);       // lanes past the last instance stay in the control flow (see `sync`), inactive
+    const int4 in = inst_s[inst0 + subc];
     const int slot = in.x & 255, ring = in.x >> 8;
-    if (slot >= nlive) return;          // padding offsets of the last pass (the instances of a slot are contiguous: whole jobs drop out)
+    // inactive: no instance, or a padding offset of the last pass (the instances of a slot are contiguous: whole jobs drop out)
+    const bool active = sub < count && slot < nlive;
     float *buf = bufs + (__mul24(slot, sbuf) + in.y);
-    const float rad = (float)in.w, wt = instw_s[inst0 + sub];
+    const float rad = (float)in.w, wt = instw_s[inst0 + subc];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
     const float2 *qt = qt_s + in.z;
     // Normalize_ring partial sums: plain sums of the lane's samples and their squares, two at a time (packed f32),
@@ -365,6 +372,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
         if constexpr (QCT) { qd = 0; return 2 * LR * step + 2 * t + u; }
         else { const int j = 2 * (LR * step + t) + u; qd = j / LT; return j % LT; }
     };
+    if (active) {
     int qdn[2];
     float2 scn[2];
 #pragma unroll
@@ -409,6 +417,9 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
             if ((NYQ1 && (QCT ? 4 * b + q : b) >= R1 / 2) || ((QCT ? q : b) & 1)) __builtin_amdgcn_sched_barrier(0);   // at most 4 samples' taps in flight (fused kernel: 2 once half of the samples are held in registers)
         }
     }
+    }
+    sync();
+    if (!active) return;
     float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
     if (RA_DBG(g, 256)) {   // diagnostic: leave the raw samples in natural order, no FFT
 #pragma unroll
@@ -524,23 +535,25 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
 // short rings of a pass fit the 64 lanes of one wave and every wave of the workgroup gets exactly one job -- as three jobs
 // (one per length) the two shortest cost a second round of ~3 k cycles each on the wave timeline.  The instance table holds
 // one entry per LANE: in.x = slot | ring << 8 | log2 n << 16 | lane-in-ring << 20.  Same arithmetic as ring_job<4, LR>.
-template <bool NYQ1>
+template <bool NYQ1, class Sync = NoSync>
 __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                              const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
-                                             const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4)
+                                             const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4,
+                                             Sync sync = Sync())
 {
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
-    if (lane >= count) return;
-    const int4 in = inst_s[inst0 + lane];
+    const int lanec = min(lane, count - 1);     // lanes without an instance stay in the control flow (see ring_job's `sync`)
+    const int4 in = inst_s[inst0 + lanec];
     const int slot = in.x & 255, ring = (in.x >> 8) & 255, lg = (in.x >> 16) & 15, t = in.x >> 20;
-    if (slot >= nlive) return;
+    const bool active = lane < count && slot < nlive;
     const int lgLR = lg - 3, LR = 1 << lgLR, H = 4 << lgLR, lgLT = lg - 2, LTm = (1 << lgLT) - 1;
     float *buf = bufs + (__mul24(slot, sbuf) + in.y);
-    const float rad = (float)in.w, wt = instw_s[inst0 + lane];
+    const float rad = (float)in.w, wt = instw_s[inst0 + lanec];
     const v2f ctr2 = {ctr[2 * slot], ctr[2 * slot + 1]};
     const float2 *qt = qt_s + in.z;
     v2f av2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
     float2 v[4];
+    if (active) {
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         v2f val;
@@ -564,6 +577,9 @@ __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb
         sq2 += val * val;
         v[a] = make_float2(val.x, val.y);
     }
+    }
+    sync();
+    if (!active) return;
     Dft<-1, 4>::run(v);
     const int tstep = t << (g.lg_maxrin - (lg - 1));          // t * maxrin / H
 #pragma unroll
