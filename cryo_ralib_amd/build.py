@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libralign_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "ralign_engine.hip")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("ralign_geom.h", "ralign_kernels.h", "ralign_fft.h", "ralign_generic.h", "ralign_refine.h")] + \
+HEADERS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
           [os.path.join(ROOT, "include", "ralign.h")]
 
 

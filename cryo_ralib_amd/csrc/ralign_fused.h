@@ -292,7 +292,7 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // last single quad is multiplied after the loop.
 #pragma unroll 1
     for (int rq = 1; rq + 1 < nq; rq += 2) {
-        RA_STAMP(g, tl && rq < 12, tgrp, twave, 9 + (rq >> 1));      // profiling builds: iteration starts (stamps 9 .. 14)
+        RA_STAMP(g, tl && rq < 8, tgrp, twave, 9 + (rq >> 1));       // profiling builds: iteration starts (stamps 9 .. 12)
         load_b(rq + 1, bA);
         read_a(oA, aA);
         oB = gq[min(rq + 2, ql)];
@@ -318,11 +318,30 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");    \
     } while (0)
 
-// ring_job's `sync`: the workgroup barrier that ends the previous pass's inverse FFTs, taken between the sampling and
-// the first write to the ring buffers (on = wave-uniform)
+// ring_job's `sync`: the point where the previous pass's inverse FFTs must be over (their spectra occupy the ring buffers),
+// between the sampling and the first write to the ring buffers.  Not an s_barrier: a wave that finishes its transforms adds
+// one to an LDS counter and walks on into its sampling; here a wave only waits until the counter says that all 16 are done
+// (a barrier at this point would also wait for the SAMPLING of the waves that transform last).  on / target: wave-uniform.
 struct PassSync {
     bool on;
-    __device__ __forceinline__ void operator()() const { if (on) RF_LDS_BARRIER(); }
+    const int *done;        // LDS: number of (wave, pass) inverse-FFT phases finished by this workgroup
+    int target;
+#ifdef RALIGN_PROFILE_SWITCHES
+    unsigned long long *tl; // wave timeline (profiling builds): stamps 13 / 14 of this wave's row before / after the wait
+#endif
+    __device__ __forceinline__ void operator()() const
+    {
+        if (!on) return;
+#ifdef RALIGN_PROFILE_SWITCHES
+        if (tl && threadIdx.x % 64 == 0) tl[13] = clock64();
+#endif
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#ifdef RALIGN_PROFILE_SWITCHES
+        if (tl && threadIdx.x % 64 == 0) tl[14] = clock64();
+#endif
+    }
 };
 
 template <int N, int NRPW>
@@ -367,6 +386,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
     }
     const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    int *ifft_done = reinterpret_cast<int *>(red + 6);      // arrival counter of the inverse-FFT phases (PassSync)
+    if (tid == 0) *ifft_done = 0;
+    int done_target = 0;
 
     // contraction roles: group m = 16 bins (block b = lane >> 2 is bin 16 m + b); a wave takes NRPW reference pairs
     // rp0 .. rp0 + NRPW - 1 of its group and both offset pairs: unit (h, op) accumulates in acc[2 h + op].
@@ -435,7 +457,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const int job = jr * RF_WAVES + wave;
                 if (job >= g.n_job) continue;
                 const int4 jd = jobs_s[job];
-                const PassSync ps = {pend && jr == 0};
+#ifdef RALIGN_PROFILE_SWITCHES
+                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
+#else
+                const PassSync ps = {pend && jr == 0, ifft_done, done_target};
+#endif
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
                 case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
@@ -448,9 +474,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 }
             }
-            if (pend && wave >= g.n_job) RF_LDS_BARRIER();      // a wave without a job in round 0
+            if (pend && wave >= g.n_job) { const PassSync ps = {true, ifft_done, done_target}; ps(); }      // a wave without a job in round 0
         } else if (pend) {
-            RF_LDS_BARRIER();
+            const PassSync ps = {true, ifft_done, done_target};
+            ps();
         }
         if (pend) reduce_records(grp - 1, 4);                  // only the last pass can carry padding offsets
         RA_STAMP(g, tl, grp, wave, 1);
@@ -575,8 +602,6 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 RA_STAMP(g, tl, grp, wave, 6);
                 ifft_round(0, nref);
                 RA_STAMP(g, tl, grp, wave, 7);
-                if (grp + 1 == ngroup) RF_LDS_BARRIER();      // otherwise taken inside the next pass's ring jobs (`pend`)
-                RA_STAMP(g, tl, grp, wave, 8);
             } else {
                 for (int zr = 0; zr < f.nzr; zr++) {
                     const int ref_lo = zr * f.rz, nrz = min(f.rz, nref - ref_lo);
@@ -586,9 +611,20 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                     RF_LDS_BARRIER();
                 }
             }
-        } else if (defer && grp + 1 == ngroup) {
-            RF_LDS_BARRIER();
         }
+        if (defer) {
+            if (grp + 1 < ngroup) {
+                // this wave's transforms (if it had any) are over: count it; the next pass's ring jobs wait for all 16 before
+                // they write to the ring buffers (PassSync).  The LDS array serves requests in order, so the reads above
+                // precede the increment and the increment precedes whatever a wave that has seen it writes.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                done_target += RF_WAVES;
+            } else {
+                RF_LDS_BARRIER();
+            }
+        }
+        RA_STAMP(g, tl, grp, wave, 8);
         if (!defer || grp + 1 == ngroup) reduce_records(grp, nlive);
         // no barrier here: the next pass's ring jobs sample first (image and tables only) and take the barrier before they
         // touch the ring buffers; the ring partials were read before the contraction barrier, the centres written after
