@@ -458,7 +458,7 @@ static int setup_fused(ra_engine *e)
     if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
-    if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats, true))) return rc;
+    if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
     hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
@@ -762,7 +762,7 @@ extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int nc
         if (e->d_cls_Bf) (void)hipFree(e->d_cls_Bf);
         e->d_cls_refspec = nullptr; e->d_cls_Bf = nullptr; e->cls_cap = 0;
         if (hipMalloc((void **)&e->d_cls_refspec, (size_t)ncls * e->geo.lring * sizeof(float)) != hipSuccess ||
-            hipMalloc((void **)&e->d_cls_Bf, (size_t)ncls * f.b_floats * sizeof(float)) != hipSuccess) {
+            hipMalloc((void **)&e->d_cls_Bf, ((size_t)ncls * f.b_floats + 256) * sizeof(float)) != hipSuccess) {
             g_last_error = "out of device memory (class references)";
             return RA_ERR_NOMEM;
         }

@@ -206,7 +206,13 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 {
     const int xb = ln >> 2, xj = ln & 3;
     const int nq = f.grp_nq[xm];
-    const float *bp = Bf + f.grp_boff[xm] + ln * 4;
+    // B operands: one wave-uniform row base per reference pair (scalar registers) + the lane's 16 bytes; the quad index moves
+    // the scalar part only (global_load ... v_lane, s[base]: no vector instruction on the request path).  The schedule
+    // requests up to one quad past the end of a row (never multiplied): the stream is allocated with one quad of slack.
+    const char *bu[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) bu[h] = reinterpret_cast<const char *>(Bf + f.grp_boff[xm] + (size_t)((rp0 + h) * nq) * 256);
+    const unsigned loff = (unsigned)ln * 16u;
     // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
     const char *abase = reinterpret_cast<const char *>(bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
     const int a1off = 8 * g.sbuf;
@@ -220,8 +226,8 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     auto load_b = [&](int rq, float4 (&b)[NH]) {
         if (RA_DBG(g, 512)) return;       // profiling: no B requests in the loop
 #pragma unroll
-        for (int h = 0; h < NH; h++)      // a pair beyond the last one re-reads the last: its units are never stored
-            b[h] = *reinterpret_cast<const float4 *>(bp + (RA_DBG(g, 32) ? 0 : (min(rp0 + h, f.nrp - 1) * nq + rq) * 256));
+        for (int h = 0; h < NH; h++)
+            b[h] = *reinterpret_cast<const float4 *>(bu[h] + (RA_DBG(g, 32) ? 0 : (size_t)rq * 1024) + loff);
     };
     auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
         if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
@@ -280,7 +286,7 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     for (int i = 2 * NH; i < 2 * NRPW; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};      // a dummy pair: defined, never stored
     const int ql = nq - 1;
     read_a(oA, aA);
-    load_b(min(1, ql), bB);
+    load_b(1, bB);
     read_a(oB, aB);
     oA = gq[min(2, ql)];
     __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +305,7 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         __builtin_amdgcn_sched_barrier(0);
         mul_rq(aB, bB);
         __builtin_amdgcn_sched_barrier(0);
-        load_b(min(rq + 2, ql), bB);
+        load_b(rq + 2, bB);
         read_a(oB, aB);
         oA = gq[min(rq + 3, ql)];
         __builtin_amdgcn_sched_barrier(0);
