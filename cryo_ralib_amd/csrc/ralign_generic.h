@@ -253,7 +253,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
                         xr[j] = sv;
                         a += sv * wt; q += sv * sv * wt;
                     }
-                    av += wave_sum(a); sq += wave_sum(q);
+                    av += a; sq += q;          // per-lane partial sums over the rings, reduced once below
                     wave_lds_sync();
                     const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
             xr[j] = sv;
             a += sv * wt; q += sv * sv * wt;
         }
-        av += wave_sum(a); sq += wave_sum(q);
+        av += a; sq += q;          // per-lane partial sums over the rings, reduced once below
         wave_lds_sync();
         const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
         for (int k = lane; k <= h; k += 64) {
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
         }
         wave_lds_sync();
     }
+    av = wave_sum_dpp(av); sq = wave_sum_dpp(sq);      // fixed order: reproducible
     if (lane == 0) {
         float avg = 0.f, rsg = 1.f;
         if (g.mode == RA_MODE_MREF) {
