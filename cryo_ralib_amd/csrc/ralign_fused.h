@@ -199,7 +199,8 @@ __device__ __forceinline__ void rf_store_z(float *Z, int zslot, int k, float ca,
 
 // contraction of one pass for one wave: NH live reference pairs rp0 .. rp0 + NH - 1 of bin group xm, both offset pairs;
 // unit (h, op) accumulates in acc[2 h + op]
-template <int NRPW, int NH>
+// OP1 = false (last pass with at most two live offsets): the second offset pair is padding, its A reads and multiplies are skipped
+template <int NRPW, int NH, bool OP1>
 __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f, const float *bufs, const int *goff_s,
                                             const float *__restrict__ Bf, int xm, int rp0, int ln, f32x4 (&acc)[2 * NRPW],
                                             const float4 (&b0)[NRPW], int4 oA, int4 oB, bool tl = false, int tgrp = 0, int twave = 0)
@@ -232,10 +233,12 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
         if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
         if (RA_DBG(g, 2048)) return;      // profiling: no A reads in the loop
-        a[0] = *reinterpret_cast<const float *>(abase + o.x); a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off);
-        a[2] = *reinterpret_cast<const float *>(abase + o.y); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
-        a[4] = *reinterpret_cast<const float *>(abase + o.z); a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off);
-        a[6] = *reinterpret_cast<const float *>(abase + o.w); a[7] = *reinterpret_cast<const float *>(abase + o.w + a1off);
+        a[0] = *reinterpret_cast<const float *>(abase + o.x); a[2] = *reinterpret_cast<const float *>(abase + o.y);
+        a[4] = *reinterpret_cast<const float *>(abase + o.z); a[6] = *reinterpret_cast<const float *>(abase + o.w);
+        if constexpr (OP1) {
+            a[1] = *reinterpret_cast<const float *>(abase + o.x + a1off); a[3] = *reinterpret_cast<const float *>(abase + o.y + a1off);
+            a[5] = *reinterpret_cast<const float *>(abase + o.z + a1off); a[7] = *reinterpret_cast<const float *>(abase + o.w + a1off);
+        }
     };
     auto mul_rq = [&](const float (&a)[8], const float4 (&b)[NH]) {
         if (RA_DBG(g, 128)) {        // profiling: operands stay live, no matrix instructions
@@ -250,16 +253,15 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 #pragma unroll
             for (int h = 0; h < NH; h++) {
                 acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
-                acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+                if constexpr (OP1) acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
             }
     };
     // modulo schedule over the ring quads: while quad rq is multiplied, the A operands of quad rq + 1 are on
     // their way from LDS, its B operands from L2, and the ring offsets of quad rq + 2 from the LDS table
-    // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  In-situ
-    // measurements (scripts/fused_phases.sh): the phase is paced by the B stream through the vector memory
-    // path plus the matrix instructions.  The wave timeline (scripts/fused_timeline.sh) shows ~1000 cycles per ring quad
-    // for every wave whatever its share; three B buffers (requests two multiplies ahead), non-temporal loads and fewer
-    // active CUs change nothing: 235 KB per pass reach a CU at ~21 B/clk, the miss parallelism of its vector L1.
+    // (sched_barrier: hipcc otherwise sinks the requests to just in front of their first use).  The wave timeline
+    // (scripts/fused_timeline.sh) shows 800 - 1000 cycles per ring quad against 200 cycles of matrix time; neither the B
+    // stream (three buffers: slower; every request to one L1-resident line: unchanged) nor the A reads are what it waits
+    // for -- the per-quad chain of scalar index arithmetic, LDS round trips and the matrix burst is.
     // quad 0 (its B operands were requested before the barrier that ends the ring jobs) starts the accumulators: C = 0
     // is an inline constant of the matrix instruction, so nothing is cleared
     auto mul_first = [&](const float (&a)[8], const float4 (&b)[NRPW]) {
@@ -272,14 +274,15 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 #pragma unroll
         for (int h = 0; h < NH; h++) {
             acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[h].x, zero, 0, 0, 0);
-            acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[h].x, zero, 0, 0, 0);
+            if constexpr (OP1) acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[h].x, zero, 0, 0, 0);
+            else acc[2 * h + 1] = zero;
         }
 #pragma unroll
         for (int c = 1; c < 4; c++)
 #pragma unroll
             for (int h = 0; h < NH; h++) {
                 acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c], rf_f4(b[h], c), acc[2 * h], 0, 0, 0);
-                acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
+                if constexpr (OP1) acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2 * c + 1], rf_f4(b[h], c), acc[2 * h + 1], 0, 0, 0);
             }
     };
 #pragma unroll
@@ -532,8 +535,15 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
         if (!RA_DBG(g, 2) && rp0 < f.nrp) {
             // the last wave of a group may hold one reference pair less: no requests or matrix instructions for a dummy pair
-            if (NRPW > 1 && f.nrp - rp0 == NRPW - 1) rf_contract<NRPW, (NRPW > 1 ? NRPW - 1 : 1)>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
-            else rf_contract<NRPW, NRPW>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+            constexpr int NHL = NRPW > 1 ? NRPW - 1 : 1;
+            const bool lastshare = NRPW > 1 && f.nrp - rp0 == NRPW - 1;
+            if (nlive > 2) {
+                if (lastshare) rf_contract<NRPW, NHL, true>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+                else rf_contract<NRPW, NRPW, true>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+            } else {
+                if (lastshare) rf_contract<NRPW, NHL, false>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+                else rf_contract<NRPW, NRPW, false>(g, f, bufs, goff_s, Bf, xm, rp0, ln, acc, b0, o0, o1, tl, grp, wave);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NU; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -320,8 +320,12 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 // zscr: [gridDim.x][N][64 TM TR] complex scratch for the CCF spectra of the block (they do not fit LDS at maxrin >= 512);
 // P = pairs transformed per LDS batch (power of two, P * (N + 1) complex fit the dynamic LDS), in place.
 // stats [n_mtile * 8] {avg, 1/sigma} of every particle-offset (polar_generic_kernel), cdc [nref] = sum_r n_r C_r(0).
+#ifndef RA_GCCF_TM
 #define RA_GCCF_TM 2        // tiles of 8 particle-offsets per block
+#endif
+#ifndef RA_GCCF_TR
 #define RA_GCCF_TR 2        // tiles of 8 references per block (4: contraction 25 instead of 28 ms at 100 references, twice the scratch)
+#endif
 #define RA_GCCF_ZPAIRS (64 * RA_GCCF_TM * RA_GCCF_TR)
 __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
