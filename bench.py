@@ -225,7 +225,9 @@ def committed_traffic(kernel_substr, workload):
     (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; scripts/profile.sh); PMC counters cannot be
     read from inside this process."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+    import re
+    natural = lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))]      # r02_v10 after r02_v9
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=natural, reverse=True):
         try:
             with open(path) as f:
                 pm = json.load(f)
