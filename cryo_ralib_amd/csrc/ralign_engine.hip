@@ -246,7 +246,9 @@ static int build_device_geometry(ra_engine *e)
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
             const int lanes_of[8] = {16, 8, 8, 4, 4, 4, 8, 4};
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
-            const bool mixed = nslot == 4 && !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0);
+            // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
+            // the job variants of codes 1, 6, 7 and 9 only)
+            const bool mixed = nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0));
             for (int lg = 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
                 const int code = (n == 256 && nslot == 4) ? 6 : ((n == 64 && nslot == 4) ? 7 : code_of(n));

@@ -472,15 +472,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target};
 #endif
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 2: ring_job<4, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 3: ring_job<4, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 4: ring_job<2, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
                 case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                default: ring_job<1, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+                default: break;      // the fused job table holds codes 1, 6, 7 and 9 only (make_jobs with 4 offset slots)
                 }
             }
             if (pend && wave >= g.n_job) { const PassSync ps = {true, ifft_done, done_target}; ps(); }      // a wave without a job in round 0
