@@ -417,19 +417,23 @@ static ccf_fn select_ccf(int maxrin)
 }
 
 typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
-static fused_fn select_fused(int maxrin, int nref)
+static fused_fn select_fused(int maxrin, int nref, int nzr)
 {
     if (nref > RF_MAXREF) return nullptr;
     const int nrp = (nref + 1) / 2;
+    const bool one = nzr == 1;      // one store / inverse-FFT round per pass
     if (maxrin == 256) {
         switch ((nrp + 1) / 2) {       // 2 waves per 16-bin group
-        case 1: return search_fused_kernel<256, 1>;
-        case 2: return search_fused_kernel<256, 2>;
-        case 3: return search_fused_kernel<256, 3>;
-        default: return search_fused_kernel<256, 4>;
+        case 1: return one ? search_fused_kernel<256, 1, true> : search_fused_kernel<256, 1, false>;
+        case 2: return one ? search_fused_kernel<256, 2, true> : search_fused_kernel<256, 2, false>;
+        case 3: return one ? search_fused_kernel<256, 3, true> : search_fused_kernel<256, 3, false>;
+        default: return one ? search_fused_kernel<256, 4, true> : search_fused_kernel<256, 4, false>;
         }
     }
-    if (maxrin == 128) return (nrp + 3) / 4 == 1 ? search_fused_kernel<128, 1> : search_fused_kernel<128, 2>;      // 4 waves per group
+    if (maxrin == 128) {               // 4 waves per group
+        if ((nrp + 3) / 4 == 1) return one ? search_fused_kernel<128, 1, true> : search_fused_kernel<128, 1, false>;
+        return one ? search_fused_kernel<128, 2, true> : search_fused_kernel<128, 2, false>;
+    }
     return nullptr;
 }
 
@@ -456,14 +460,14 @@ static int setup_fused(ra_engine *e)
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (!select_fused(g.maxrin, e->cfg.nref)) return RA_OK;
+    if (!select_fused(g.maxrin, e->cfg.nref, 1)) return RA_OK;
     if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
     if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
-    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref, fp.f.nzr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     e->fused = true;
     return RA_OK;
@@ -790,7 +794,7 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
     const FusedGeom f = e->fplan.f;
-    fused_fn fk = select_fused(g.maxrin, 1);
+    fused_fn fk = select_fused(g.maxrin, 1, f.nzr);
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *st = d_state + (size_t)start * 2;
@@ -825,7 +829,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
-        fused_fn fk = select_fused(g.maxrin, e->cfg.nref);
+        fused_fn fk = select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr);
         for (int start = 0; start < n; start += e->chunk) {
             const int cn = std::min(e->chunk, n - start);
             float *st = d_state + (size_t)start * 2;

@@ -353,7 +353,9 @@ struct PassSync {
     }
 };
 
-template <int N, int NRPW>
+// ONE: all references of a pass fit one store / inverse-FFT round (f.nzr == 1); the two-round code stays out of that kernel
+// (the instruction cache holds 64 KB for two CUs: code that is never run still spreads the code that is)
+template <int N, int NRPW, bool ONE>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
                                                                   const float *__restrict__ Bf0, int nref,
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         red[7] = 0.f;
     }
     RF_LDS_BARRIER();
-    const bool defer = f.nzr == 1;      // one store / inverse-FFT round per pass: its closing barrier moves into the next pass
+    constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its closing barrier moves into the next pass
     // best reference per offset of pass gr (ascending reference, ">=": later wins), scaled by 1/sigma; by wave 2: an old
     // wave -- it gets through its ring job first -- that is not the one with the extra short job
     auto reduce_records = [&](int gr, int nl) {
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
                 ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
         };
         if (!RA_DBG(g, 4)) {
-            if (f.nzr == 1) {                  // the accumulators die before the inverse FFT: no register pressure from them
+            if constexpr (ONE) {               // the accumulators die before the inverse FFT: no register pressure from them
                 store_round(0, nref);
                 RA_STAMP(g, tl, grp, wave, 5);
                 RF_LDS_BARRIER();
