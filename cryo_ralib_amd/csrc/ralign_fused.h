@@ -17,8 +17,11 @@
 //                 one N-point complex inverse FFT per (offset, reference) pair yields q and t together, wavefront
 //                 argmax with EMAN2's tie rules (ifft_argmax of ralign_kernels.h); the best reference per offset
 //                 leaves the CU as one 40-byte record.
-// Normalize_ring is applied as in polar_fft_kernel (DC bin corrected in the ring buffer before the contraction) except
-// for the scale 1/sigma, which multiplies the peak record instead of every spectrum element.
+// Normalize_ring: subtracting the mean only moves the DC coefficients, so it is applied to the contracted DC term
+// (a -= avg * sum_r n_r B_r(0)); the scale 1/sigma multiplies the peak record instead of every spectrum element.
+// Synchronisation per pass: workgroup barriers (LDS traffic only) after the ring jobs, the contraction and the spectra
+// store; the end of the inverse FFTs is an arrival counter that the NEXT pass's ring jobs wait for between their sampling
+// and their first write to the ring buffers (PassSync), so waves that are through with their transforms sample meanwhile.
 //
 // Reference call sites restated: Util.multiref_polar_ali_2d / ormq as called from test_mref_gpu_align.py:1043-1044 and
 // sp_alignment.ali2d_single_iter (test_reffree_gpu_align.py:844-847); SURVEY.md Appendix A.3-A.9.
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         red[7] = 0.f;
     }
     RF_LDS_BARRIER();
-    constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its closing barrier moves into the next pass
+    constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its end is the arrival counter, not a barrier
     // best reference per offset of pass gr (ascending reference, ">=": later wins), scaled by 1/sigma; by wave 2: an old
     // wave -- it gets through its ring job first -- that is not the one with the extra short job
     auto reduce_records = [&](int gr, int nl) {
@@ -455,9 +458,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         const bool tl = p == (int)blockIdx.x && blockIdx.x == 0;      // timeline: first particle of workgroup 0
         RA_STAMP(g, tl, grp, wave, 0);
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel).
-        // The spectra of the previous pass occupy the ring buffers until its inverse FFTs are done; the barrier that says so
-        // is taken INSIDE this pass's first ring job, after the sampling (which touches only the image and the tables): a
-        // wave that is through with its inverse FFTs -- or had none -- samples while the others still transform.
+        // The spectra of the previous pass occupy the ring buffers until its inverse FFTs are done; the wait for that
+        // (PassSync: an arrival counter) sits INSIDE this pass's first ring job, after the sampling (which touches only the
+        // image and the tables): a wave that is through with its inverse FFTs -- or had none -- samples while the others
+        // still transform.
         const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
         const bool pend = defer && grp > 0;
         if (!RA_DBG(g, 16)) {
@@ -640,8 +644,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, Fus
         }
         RA_STAMP(g, tl, grp, wave, 8);
         if (!defer || grp + 1 == ngroup) reduce_records(grp, nlive);
-        // no barrier here: the next pass's ring jobs sample first (image and tables only) and take the barrier before they
-        // touch the ring buffers; the ring partials were read before the contraction barrier, the centres written after
+        // no barrier here: the next pass's ring jobs sample first (image and tables only) and wait for the counter before
+        // they touch the ring buffers; the ring partials were read before the contraction barrier, the centres written after
         // the first barrier of this pass; `pc` and red[12..15] are next written two and one barriers into the next pass
     }
     }
