@@ -390,7 +390,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.refspec_floats = (size_t)cfg.nref * g.lring;
     w.b_floats = (size_t)nrtile * g.LBP * 16;
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
-    w.zscr_recs = generic ? (size_t)512 * RA_GCCF_ZPAIRS * g.maxrin : 0;
+    w.zscr_recs = generic ? (size_t)512 * RA_GCCF_ZPAIRS_MAX * g.maxrin : 0;
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
@@ -572,7 +572,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     } else {
         he = hipFuncSetAttribute((const void *)polar_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)polar_generic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
-        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
     }
     if (he == hipSuccess && !e->xf_generic) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -871,8 +872,12 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
-        if (e->generic)
-            hipLaunchKernelGGL(ccf_generic_kernel, dim3(std::min((n_mtile + RA_GCCF_TM - 1) / RA_GCCF_TM, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
+        if (e->generic && gccf_wide_blocks(e->nrtile))
+            hipLaunchKernelGGL((ccf_generic_kernel<1, 7>), dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
+                               Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
+                               (const float *)e->d_gcdc);
+        else if (e->generic)
+            hipLaunchKernelGGL((ccf_generic_kernel<2, 2>), dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);
         else

@@ -320,13 +320,12 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 // zscr: [gridDim.x][N][64 TM TR] complex scratch for the CCF spectra of the block (they do not fit LDS at maxrin >= 512);
 // P = pairs transformed per LDS batch (power of two, P * (N + 1) complex fit the dynamic LDS), in place.
 // stats [n_mtile * 8] {avg, 1/sigma} of every particle-offset (polar_generic_kernel), cdc [nref] = sum_r n_r C_r(0).
-#ifndef RA_GCCF_TM
-#define RA_GCCF_TM 2        // tiles of 8 particle-offsets per block
-#endif
-#ifndef RA_GCCF_TR
-#define RA_GCCF_TR 2        // tiles of 8 references per block (4: contraction 25 instead of 28 ms at 100 references, twice the scratch)
-#endif
-#define RA_GCCF_ZPAIRS (64 * RA_GCCF_TM * RA_GCCF_TR)
+// Block shapes (TM tiles of 8 particle-offsets x TR tiles of 8 references): 2 x 2 by default; 1 x 7 when the reference
+// tiles come in (nearly) whole sevens -- 13 tiles at 100 references: the A operands are read twice instead of seven times
+// (45.2 -> 44.2 ms per chunk).  The scratch holds the largest shape.
+#define RA_GCCF_ZPAIRS_MAX (64 * 7)
+inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 7 * 7 - nrtile <= 1; }
+template <int TM, int TR>
 __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
@@ -338,14 +337,14 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
     const int N = g.maxrin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_GCCF_THREADS / 64;
-    float2 *zs = zscr + (size_t)blockIdx.x * RA_GCCF_ZPAIRS * N;
+    constexpr int ZPAIRS = 64 * TM * TR;
+    float2 *zs = zscr + (size_t)blockIdx.x * ZPAIRS * N;
     float2 *xb = reinterpret_cast<float2 *>(lds);
     const int pstride = N + 1;              // complex slots per pair: one N-point buffer (in-place transform) + 1 (bank skew)
     float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
     for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
     __syncthreads();
 
-    constexpr int TM = RA_GCCF_TM, TR = RA_GCCF_TR;
     const int n_mt2 = (n_mtile + TM - 1) / TM, n_rt2 = (nrtile + TR - 1) / TR;
     for (int mt2 = blockIdx.x; mt2 < n_mt2; mt2 += gridDim.x) {
         for (int rt2 = 0; rt2 < n_rt2; rt2++) {
@@ -447,8 +446,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                             const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
                             const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                             const int zp = (TR * ai + bi) * 64 + pair;
-                            zs[(size_t)k * RA_GCCF_ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
-                            zs[(size_t)((N - k) & (N - 1)) * RA_GCCF_ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
+                            zs[(size_t)k * ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
+                            zs[(size_t)((N - k) & (N - 1)) * ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
                         }
                 }
             }
@@ -473,7 +472,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const int idx = idx0 + u * RA_GCCF_THREADS;
-                            if (idx < P * N) t[u] = src[(size_t)(idx >> lgp) * RA_GCCF_ZPAIRS + (idx & (P - 1))];
+                            if (idx < P * N) t[u] = src[(size_t)(idx >> lgp) * ZPAIRS + (idx & (P - 1))];
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
