@@ -469,6 +469,7 @@ static int setup_fused(ra_engine *e)
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
     hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref, fp.f.nzr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: fused plan: %zu bytes of LDS (polar part %zu), sbuf %d, pst %d, nzr %d, rz %d\n", fp.lds_bytes, e->lds_polar, e->dg.sbuf, e->dg.pst, fp.f.nzr, fp.f.rz);
     e->fused = true;
     return RA_OK;
 }
