@@ -112,6 +112,20 @@ def test_product_never_touches_the_oracle():
                 assert "oracle" not in txt.replace("# oracle-free", ""), f
 
 
+def test_build_tracks_every_engine_header():
+    """a header that is not in build.HEADERS can change without a rebuild: the library then runs stale code"""
+    import re
+    from cryo_ralib_amd import build
+    csrc = os.path.join(os.path.dirname(build.__file__), "csrc")
+    tracked = {os.path.basename(h) for h in build.HEADERS}
+    included = set()
+    for name in os.listdir(csrc):
+        with open(os.path.join(csrc, name)) as f:
+            included.update(re.findall(r'#include "([^"/]+\.h)"', f.read()))
+    assert included and included <= tracked, sorted(included - tracked)
+    assert all(os.path.exists(h) for h in build.HEADERS)
+
+
 def test_stack_io_round_trip(tmp_path):
     from cryo_ralib_amd import stackio
     rng = np.random.default_rng(0)
