@@ -1,0 +1,49 @@
+"""random geometries through the engine against the CPU checker (run on the GPU box: python scripts/dev/random_sweep.py [n] [seed]);
+prints one line per case and the search path the engine took; exits non-zero on the first mismatch."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cryo_ralib_amd import api, synth          # noqa: E402
+from oracle import oracle as orc               # noqa: E402
+from test_gpu_parity import compare_search     # noqa: E402
+
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+for case in range(ncase):
+    xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
+    nx = int(rng.integers(36, 101))
+    oumax = (nx - 1) // 2 - max(xr, yr) - 1
+    ou = int(rng.integers(8, min(40, oumax) + 1))
+    ir = int(rng.integers(1, 4)); rs = int(rng.integers(1, 3))
+    ts = float(rng.choice([1.0, 1.0, 0.5]))
+    mode = api.RA_MODE_MREF if rng.random() < 0.7 else api.RA_MODE_REFFREE
+    nref = int(rng.integers(1, 17)) if mode == api.RA_MODE_MREF else 1
+    n = int(rng.integers(3, 20))
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, yr, 0.25, ou=ou)
+    rg = orc.rings(ir, ou, rs)
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask, rg)
+    d = np.zeros((n, 2), np.float32)
+    if mode == api.RA_MODE_MREF:
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8)
+    else:
+        params = np.zeros((n, 6), np.float32)
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8)
+    eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs)
+    eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    tp = torch.from_numpy(parts).to(eng.dev)
+    st, res = eng.new_state(n), eng.new_result(n)
+    eng.align(tp, st, res)
+    eng.sync()
+    path = eng.search_path
+    compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    eng.close()
+    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path), flush=True)
+print("all %d cases agree with the checker" % ncase)
