@@ -152,8 +152,8 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     out.cdc_w.assign(g.nring, 0.f);
     if (g.nring > 64) return false;
     for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
-    f.gstr = 4 * ((g.nring + 3) / 4) + 4;
-    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + 8 * (g.nring + 8) + RF_MAXREF + 64;
+    f.gstr = 4 * ((g.nring + 3) / 4) + 8;      // two quads of slack: the contraction reads the offsets of up to two quads past a group's last
+    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * RF_MAXREF + 4) * (sizeof(CandT) / 4) + 8 * (g.nring + 12) + RF_MAXREF + 64;
     out.lds_bytes = fl * sizeof(float);
     f.on = out.lds_bytes <= 160 * 1024 && 4 * f.rz * zstride <= 4 * sbuf;
     return f.on != 0;
@@ -220,7 +220,13 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     // A element of (offset pair op, ring r): bufs[(2 op + (xj >> 1)) * sbuf + roff[r] + 2 (16 m + b) + (xj & 1)]
     const char *abase = reinterpret_cast<const char *>(bufs + (xj >> 1) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
     const int a1off = 8 * g.sbuf;
-    const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
+    // ring offsets of the quads: LDS table row of the group, walked with a pointer kept in a vector register (one v_add per
+    // trip, immediate offsets in between); rows are padded with copies of the last ring's offset: no clamps
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) i32x4 *lds_quad_p;
+    lds_quad_p gq = (lds_quad_p)(goff_s + xm * f.gstr);
+    asm volatile("" : "+v"(gq));
+    auto quad_offsets = [&](int i) { const i32x4 q = gq[i]; return make_int4(q.x, q.y, q.z, q.w); };
     float4 bA[NH], bB[NH];
     float aA[8], aB[8];
 #ifdef RALIGN_PROFILE_SWITCHES
@@ -294,7 +300,8 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     read_a(oA, aA);
     load_b(1, bB);
     read_a(oB, aB);
-    oA = gq[min(2, ql)];
+    oA = quad_offsets(2);
+    gq += 1;                     // gq[i] is now quad rq + i of the trip that starts at rq = 1
     __builtin_amdgcn_sched_barrier(0);
     mul_first(aA, b0);
     __builtin_amdgcn_sched_barrier(0);
@@ -307,13 +314,14 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
         RA_STAMP(g, tl && rq < 8, tgrp, twave, 9 + (rq >> 1));       // profiling builds: iteration starts (stamps 9 .. 12)
         load_b(rq + 1, bA);
         read_a(oA, aA);
-        oB = gq[min(rq + 2, ql)];
+        oB = quad_offsets(2);
         __builtin_amdgcn_sched_barrier(0);
         mul_rq(aB, bB);
         __builtin_amdgcn_sched_barrier(0);
         load_b(rq + 2, bB);
         read_a(oB, aB);
-        oA = gq[min(rq + 3, ql)];
+        oA = quad_offsets(3);
+        gq += 2;
         __builtin_amdgcn_sched_barrier(0);
         mul_rq(aA, bA);
         __builtin_amdgcn_sched_barrier(0);
