@@ -154,6 +154,13 @@ static int build_device_geometry(ra_engine *e)
     // Fused kernel: == 16 (mod 32), the two offsets a 4x4x1 MFMA A operand reads (16 bins x Re/Im each) sit in disjoint
     // halves of the 32 banks (RALIGN_SBUF_PAD overrides: experiments)
     int sbuf = (g.lring + 31) / 32 * 32 + (getenv("RALIGN_SBUF_PAD") ? atoi(getenv("RALIGN_SBUF_PAD")) : (fused_wanted(e) ? 16 : 8));
+    // fused kernel at maxrin 256: pad the stride to the compile-time value of its fixed-stride instantiations when the image
+    // and four such buffers (+ 16 KB of tables and records) still fit the LDS (RALIGN_SBUF_FIXED=0: keep the run-time stride)
+    if (fused_wanted(e) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !getenv("RALIGN_SBUF_PAD") &&
+        !(getenv("RALIGN_SBUF_FIXED") && atoi(getenv("RALIGN_SBUF_FIXED")) == 0)) {
+        const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = g.nx + 2 * bd0 + 3;
+        if ((size_t)(pst0 * pst0 + 4 * RF_SBUF_FIXED + 3400) * sizeof(float) <= 160 * 1024) sbuf = RF_SBUF_FIXED;
+    }
     d.sbuf = sbuf;
     d.a_blk = g.LBP * 8 + 64;
     // classes of bins with equal ring-slot count
@@ -417,22 +424,29 @@ static ccf_fn select_ccf(int maxrin)
 }
 
 typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
-static fused_fn select_fused(int maxrin, int nref, int nzr)
+static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf)
 {
     if (nref > RF_MAXREF) return nullptr;
     const int nrp = (nref + 1) / 2;
     const bool one = nzr == 1;      // one store / inverse-FFT round per pass
     if (maxrin == 256) {
+        if (one && sbuf == RF_SBUF_FIXED)      // compile-time ring-buffer stride
+            switch ((nrp + 1) / 2) {
+            case 1: return search_fused_kernel<256, 1, true, RF_SBUF_FIXED>;
+            case 2: return search_fused_kernel<256, 2, true, RF_SBUF_FIXED>;
+            case 3: return search_fused_kernel<256, 3, true, RF_SBUF_FIXED>;
+            default: return search_fused_kernel<256, 4, true, RF_SBUF_FIXED>;
+            }
         switch ((nrp + 1) / 2) {       // 2 waves per 16-bin group
-        case 1: return one ? search_fused_kernel<256, 1, true> : search_fused_kernel<256, 1, false>;
-        case 2: return one ? search_fused_kernel<256, 2, true> : search_fused_kernel<256, 2, false>;
-        case 3: return one ? search_fused_kernel<256, 3, true> : search_fused_kernel<256, 3, false>;
-        default: return one ? search_fused_kernel<256, 4, true> : search_fused_kernel<256, 4, false>;
+        case 1: return one ? search_fused_kernel<256, 1, true, 0> : search_fused_kernel<256, 1, false, 0>;
+        case 2: return one ? search_fused_kernel<256, 2, true, 0> : search_fused_kernel<256, 2, false, 0>;
+        case 3: return one ? search_fused_kernel<256, 3, true, 0> : search_fused_kernel<256, 3, false, 0>;
+        default: return one ? search_fused_kernel<256, 4, true, 0> : search_fused_kernel<256, 4, false, 0>;
         }
     }
     if (maxrin == 128) {               // 4 waves per group
-        if ((nrp + 3) / 4 == 1) return one ? search_fused_kernel<128, 1, true> : search_fused_kernel<128, 1, false>;
-        return one ? search_fused_kernel<128, 2, true> : search_fused_kernel<128, 2, false>;
+        if ((nrp + 3) / 4 == 1) return one ? search_fused_kernel<128, 1, true, 0> : search_fused_kernel<128, 1, false, 0>;
+        return one ? search_fused_kernel<128, 2, true, 0> : search_fused_kernel<128, 2, false, 0>;
     }
     return nullptr;
 }
@@ -460,14 +474,14 @@ static int setup_fused(ra_engine *e)
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (!select_fused(g.maxrin, e->cfg.nref, 1)) return RA_OK;
+    if (!select_fused(g.maxrin, e->cfg.nref, 1, 0)) return RA_OK;
     if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
     if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
-    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref, fp.f.nzr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: fused plan: %zu bytes of LDS (polar part %zu), sbuf %d, pst %d, nzr %d, rz %d\n", fp.lds_bytes, e->lds_polar, e->dg.sbuf, e->dg.pst, fp.f.nzr, fp.f.rz);
     e->fused = true;
@@ -796,7 +810,7 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
     const FusedGeom f = e->fplan.f;
-    fused_fn fk = select_fused(g.maxrin, 1, f.nzr);
+    fused_fn fk = select_fused(g.maxrin, 1, f.nzr, e->dg.sbuf);
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *st = d_state + (size_t)start * 2;
@@ -831,7 +845,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
-        fused_fn fk = select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr);
+        fused_fn fk = select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf);
         for (int start = 0; start < n; start += e->chunk) {
             const int cn = std::min(e->chunk, n - start);
             float *st = d_state + (size_t)start * 2;

@@ -366,14 +366,20 @@ struct PassSync {
 
 // ONE: all references of a pass fit one store / inverse-FFT round (f.nzr == 1); the two-round code stays out of that kernel
 // (the instruction cache holds 64 KB for two CUs: code that is never run still spreads the code that is)
-template <int N, int NRPW, bool ONE>
-__global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g, FusedGeom f, const float *__restrict__ particles,
+// SB: ring-buffer stride known at compile time (RF_SBUF_FIXED floats; the engine pads the stride up to it when the LDS
+// allows) or 0 = g.sbuf.  With a constant stride the second offset pair of every A operand is an immediate offset of its
+// read (ds_read2st64_b32: both offset pairs in one instruction): 4 instead of 8 address and LDS instructions per ring quad.
+#define RF_SBUF_FIXED 6432       // >= the stride at ou = 36 (6416); 8 x 6432 bytes is a multiple of 256
+template <int N, int NRPW, bool ONE, int SB>
+__global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
                                                                   const float *__restrict__ Bf0, int nref,
                                                                   CandT *__restrict__ cand, const int *__restrict__ cls)
 {
     // cls != null (class-resident mode, one reference): particle p is aligned to reference cls[p], whose B stream is
     // Bf0 + cls[p] * b_floats (pack_refs_fused_kernel with blockIdx.y = class)
+    DevGeom g = g_in;
+    if constexpr (SB != 0) g.sbuf = SB;
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     extern __shared__ __align__(16) float lds[];
     // LDS plan of polar_fft_kernel, then the extras of this kernel
