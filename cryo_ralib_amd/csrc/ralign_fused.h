@@ -233,11 +233,14 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
     for (int h = 0; h < NH; h++) bB[h] = b0[h];          // defined operands for the switches that skip the requests
     for (int c = 0; c < 8; c++) aA[c] = aB[c] = (float)(ln + c);
 #endif
-    auto load_b = [&](int rq, float4 (&b)[NH]) {
+    // one running 32-bit offset in a vector register (lane part + quad part, advanced once per trip) on top of the scalar row
+    // bases: global_load ... v_off, s[base] offset:imm -- no 64-bit pointer arithmetic per request
+    unsigned voff = loff;                  // + 1024 per quad consumed
+    auto load_b = [&](int ahead, float4 (&b)[NH]) {      // B of the quad `ahead` quads past the running offset
         if (RA_DBG(g, 512)) return;       // profiling: no B requests in the loop
 #pragma unroll
         for (int h = 0; h < NH; h++)
-            b[h] = *reinterpret_cast<const float4 *>(bu[h] + (RA_DBG(g, 32) ? 0 : (size_t)rq * 1024) + loff);
+            b[h] = *reinterpret_cast<const float4 *>(bu[h] + (size_t)(RA_DBG(g, 32) ? loff : voff) + (size_t)ahead * 1024);
     };
     auto read_a = [&](int4 o, float (&a)[8]) {     // 4 rings x 2 offset pairs (padded ring slots have zero B)
         if (RA_DBG(g, 64)) o = make_int4(0, 0, 0, 0);
@@ -312,13 +315,14 @@ __device__ __forceinline__ void rf_contract(const DevGeom &g, const FusedGeom &f
 #pragma unroll 1
     for (int rq = 1; rq + 1 < nq; rq += 2) {
         RA_STAMP(g, tl && rq < 8, tgrp, twave, 9 + (rq >> 1));       // profiling builds: iteration starts (stamps 9 .. 12)
-        load_b(rq + 1, bA);
+        load_b(2, bA);
         read_a(oA, aA);
         oB = quad_offsets(2);
         __builtin_amdgcn_sched_barrier(0);
         mul_rq(aB, bB);
         __builtin_amdgcn_sched_barrier(0);
-        load_b(rq + 2, bB);
+        load_b(3, bB);
+        voff += 2048;
         read_a(oB, aB);
         oA = quad_offsets(3);
         gq += 2;
