@@ -383,6 +383,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
     // cls != null (class-resident mode, one reference): particle p is aligned to reference cls[p], whose B stream is
     // Bf0 + cls[p] * b_floats (pack_refs_fused_kernel with blockIdx.y = class)
     DevGeom g = g_in;
+    g.maxrin = N; g.lg_maxrin = __builtin_ctz(N);      // the kernel is instantiated per maxrin: constants, not kernel arguments
     if constexpr (SB != 0) g.sbuf = SB;
     constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     extern __shared__ __align__(16) float lds[];
