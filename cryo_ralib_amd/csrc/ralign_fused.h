@@ -456,6 +456,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         red[7] = 0.f;
     }
     RF_LDS_BARRIER();
+    // this wave's job of round 0 is the same in every pass: fetched once per particle, not once per pass
+    const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its end is the arrival counter, not a barrier
     // best reference per offset of pass gr (ascending reference, ">=": later wins), scaled by 1/sigma; by wave 2: an old
     // wave -- it gets through its ring job first -- that is not the one with the extra short job
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
                 // their long jobs earliest (wave timeline, scripts/fused_timeline.sh) and take the short jobs of round 1
                 const int job = jr * RF_WAVES + wave;
                 if (job >= g.n_job) continue;
-                const int4 jd = jobs_s[job];
+                const int4 jd = jr == 0 ? jd0 : jobs_s[job];
 #ifdef RALIGN_PROFILE_SWITCHES
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
 #else
