@@ -10,6 +10,7 @@ scaling) and the only collective is the RCCL all-reduce of the class sums.
     python bench.py --gpus 1 --steps 6 --warmup 1                       # BASELINE configs[1] (the metric's config)
     python bench.py --workload reffree                                  # BASELINE configs[2]
     python bench.py --workload largebox                                 # BASELINE configs[4] geometry, one GPU's share
+    python bench.py --workload mref50                                   # BASELINE configs[3], one GPU's share (125k particles, nref=50)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,6 +36,7 @@ WORKLOADS = {
     "mref": ("configs[1]", 90, 36, 3.0, 10, 50000, 6, 1),
     "reffree": ("configs[2]", 90, 36, 3.0, 1, 50000, 10, 1),
     "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 4096, 2, 1),
+    "mref50": ("configs[3], one GPU's share", 90, 36, 3.0, 50, 125000, 3, 1),
 }
 
 

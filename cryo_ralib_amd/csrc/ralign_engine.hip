@@ -16,6 +16,7 @@
 #include "ralign_kernels.h"
 #include "ralign_generic.h"
 #include "ralign_fused.h"
+#include "ralign_tiled.h"
 #include "ralign_refine.h"
 
 using namespace ralign;
@@ -81,6 +82,7 @@ struct ra_engine {
     std::vector<int> qoff;              // quadrant-table offset per log2(ring length)
     std::vector<float> ringw_h;
     bool fused = false;                 // plan valid and not disabled (RALIGN_FUSED=0)
+    bool tiled = false;                 // the plan is search_tiled_kernel's (ralign_tiled.h: reference tiles, more than RF_MAXREF references)
     float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
     size_t f_cap_b = 0;
@@ -121,10 +123,20 @@ static bool fft_plan(int h, int &R1, int &R2)
 }
 
 // the particle-resident kernel is planned for this engine (decided before the LDS layout, which differs slightly)
+static bool tiled_wanted(const ra_engine *e)
+{
+    // search_tiled_kernel: more references than one pass of search_fused_kernel accumulates (RALIGN_TILED=1 forces it for fewer)
+    const bool force = getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) != 0;
+    if (getenv("RALIGN_TILED") && !force) return false;
+    return (e->cfg.nref > RF_MAXREF || force) && e->geo.maxrin == 256 && e->geo.nring <= 4 * RT_NQ && e->cfg.nref <= 127;
+}
+
 static bool fused_wanted(const ra_engine *e)
 {
-    if (e->generic || e->cfg.nref > RF_MAXREF) return false;
+    if (e->generic) return false;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
+    if (tiled_wanted(e)) return true;
+    if (e->cfg.nref > RF_MAXREF) return false;
     return e->geo.maxrin == 256 || e->geo.maxrin == 128;
 }
 
@@ -451,6 +463,21 @@ static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf)
     return nullptr;
 }
 
+static fused_fn select_tiled(int nh, int sbuf)
+{
+    if (sbuf == RF_SBUF_FIXED)
+        switch (nh) {
+        case 4: return search_tiled_kernel<256, 4, RF_SBUF_FIXED>;
+        case 5: return search_tiled_kernel<256, 5, RF_SBUF_FIXED>;
+        default: return nullptr;
+        }
+    switch (nh) {
+    case 4: return search_tiled_kernel<256, 4, 0>;
+    case 5: return search_tiled_kernel<256, 5, 0>;
+    default: return nullptr;
+    }
+}
+
 template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap, const std::vector<T> &h)
 {
     if (h.size() > *cap || !*dptr) {
@@ -468,22 +495,27 @@ template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap
 // geometry the LDS-resident kernels cover, up to RF_MAXREF references; everything else keeps the two-kernel path.
 static int setup_fused(ra_engine *e)
 {
-    e->fused = false;
+    e->fused = false; e->tiled = false;
     e->fplan.f.on = 0;
     if (e->generic) return RA_OK;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (!select_fused(g.maxrin, e->cfg.nref, 1, 0)) return RA_OK;
-    if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
+    if (tiled_wanted(e) && build_tiled_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp) && select_tiled(fp.f.nh, e->dg.sbuf)) {
+        e->tiled = true;
+    } else {
+        if (!select_fused(g.maxrin, e->cfg.nref, 1, 0)) return RA_OK;
+        if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
+    }
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
     if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
-    hipError_t he = hipFuncSetAttribute((const void *)select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    const fused_fn fk = e->tiled ? select_tiled(fp.f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf);
+    hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
-    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: fused plan: %zu bytes of LDS (polar part %zu), sbuf %d, pst %d, nzr %d, rz %d\n", fp.lds_bytes, e->lds_polar, e->dg.sbuf, e->dg.pst, fp.f.nzr, fp.f.rz);
+    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: %s plan: %zu bytes of LDS (polar part %zu), sbuf %d, pst %d, nzr %d, rz %d\n", e->tiled ? "tiled" : "fused", fp.lds_bytes, e->lds_polar, e->dg.sbuf, e->dg.pst, fp.f.nzr, fp.f.rz);
     e->fused = true;
     return RA_OK;
 }
@@ -776,7 +808,7 @@ __global__ void apply_cs_kernel(int n, const float *__restrict__ cs, const ra_re
 extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int ncls)
 {
     if (!e || !d_refs || ncls <= 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    if (!e->fused || e->cfg.nref != 1 || e->cfg.mode != RA_MODE_REFFREE) { g_last_error = "class-resident launch needs the fused kernel with one reference"; return RA_ERR_STATE; }
+    if (!e->fused || e->tiled || e->cfg.nref != 1 || e->cfg.mode != RA_MODE_REFFREE) { g_last_error = "class-resident launch needs the fused kernel with one reference"; return RA_ERR_STATE; }
     const FusedGeom f = e->fplan.f;
     int rc;
     if (ncls > e->cls_cap) {
@@ -806,7 +838,7 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
     if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (n == 0) return RA_OK;
     if (!d_particles || !d_state || !d_result || !d_cls) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    if (!e->fused || e->cfg.nref != 1 || e->cls_ready <= 0) { g_last_error = "ra_set_class_references has not been called"; return RA_ERR_STATE; }
+    if (!e->fused || e->tiled || e->cfg.nref != 1 || e->cls_ready <= 0) { g_last_error = "ra_set_class_references has not been called"; return RA_ERR_STATE; }
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
     const FusedGeom f = e->fplan.f;
@@ -845,7 +877,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
-        fused_fn fk = select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf);
+        fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf);
         for (int start = 0; start < n; start += e->chunk) {
             const int cn = std::min(e->chunk, n - start);
             float *st = d_state + (size_t)start * 2;

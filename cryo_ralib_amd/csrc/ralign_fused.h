@@ -56,6 +56,7 @@ struct FusedGeom {
     const float *cdc_w;            // [nref] DC weights of the references: sum over rings of n_r * B_r(bin 0) (ref_dc_weights_kernel)
     int wmap[16];                  // contraction role of wave w: bin group | share of the reference pairs << 8 (balance_waves)
     int stat_wave[4];              // the wave that reduces the Normalize_ring partials of offset slot s
+    int ntile, nh;                 // search_tiled_kernel (ralign_tiled.h): reference tiles per pass, reference pairs per tile
 };
 
 struct FusedPlanHost {
@@ -78,7 +79,37 @@ inline int rf_bsrc_code(const Geometry &g, int k, int r, int ref, int part)
     } else if (k > n / 2 || (k == n / 2 && n == g.maxrin)) return -1;
     else if (k == n / 2 && part == 1) return -1;        // Nyquist of a shorter ring is real
     const int e = g.bin_off[ks] + (r - g.bin_first[ks]);
-    return (e << 5) | (ref << 1) | part;
+    return (e << 8) | (ref << 1) | part;
+}
+
+// B-stream layout shared by search_fused_kernel and search_tiled_kernel: [bin group][reference pair][ring quad][lane][4 rings]
+inline void rf_layout_b(const Geometry &g, int nref, FusedGeom &f, std::vector<int> &bsrc)
+{
+    int boff = 0;
+    for (int m = 0; m < f.ng; m++) {
+        int r0 = 0;
+        while (r0 < g.nring) {      // first ring with a bin >= 16 m (bins 0 .. n/2, the full-length Nyquist merged into bin 0)
+            const int n = g.numr[3 * r0 + 2], nbin = (n == g.maxrin) ? n / 2 : n / 2 + 1;
+            if (16 * m < nbin) break;
+            r0++;
+        }
+        f.grp_ring0[m] = r0;
+        f.grp_nq[m] = (g.nring - r0 + 3) / 4;
+        f.grp_boff[m] = boff;
+        boff += f.nrp * f.grp_nq[m] * 256;
+    }
+    f.b_floats = boff;
+    bsrc.assign(boff, -1);
+    for (int m = 0; m < f.ng; m++)
+        for (int rp = 0; rp < f.nrp; rp++)
+            for (int rq = 0; rq < f.grp_nq[m]; rq++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int c = 0; c < 4; c++) {
+                        const int r = f.grp_ring0[m] + 4 * rq + c, k = 16 * m + (lane >> 2), j = lane & 3;
+                        const int ref = 2 * rp + (j >> 1);
+                        if (ref >= nref) continue;
+                        bsrc[f.grp_boff[m] + ((rp * f.grp_nq[m] + rq) * 64 + lane) * 4 + c] = rf_bsrc_code(g, k, r, ref, j & 1);
+                    }
 }
 
 // lds_polar_floats: LDS floats polar_fft_kernel needs for this geometry (image, 4 ring buffers, tables, reductions)
@@ -98,20 +129,7 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     f.nzr = (nref + rzmax - 1) / rzmax;
     f.rz = (nref + f.nzr - 1) / f.nzr;
     f.rz_inv = (65536 + f.rz - 1) / f.rz;
-    int boff = 0;
-    for (int m = 0; m < f.ng; m++) {
-        int r0 = 0;
-        while (r0 < g.nring) {      // first ring with a bin >= 16 m (bins 0 .. n/2, the full-length Nyquist merged into bin 0)
-            const int n = g.numr[3 * r0 + 2], nbin = (n == g.maxrin) ? n / 2 : n / 2 + 1;
-            if (16 * m < nbin) break;
-            r0++;
-        }
-        f.grp_ring0[m] = r0;
-        f.grp_nq[m] = (g.nring - r0 + 3) / 4;
-        f.grp_boff[m] = boff;
-        boff += f.nrp * f.grp_nq[m] * 256;
-    }
-    f.b_floats = boff;
+    rf_layout_b(g, nref, f, out.bsrc);
     // Contraction roles.  Waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD, and the matrix pipe of a SIMD is what the
     // contraction phase runs on (wave timeline: ~8 matrix cycles x 8 NH instructions per ring quad and wave): deal the
     // (bin group, share of the reference pairs) items to the waves so that the four SIMDs get equal numbers of matrix
@@ -138,17 +156,6 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
         }
         for (int q = 0; q < 4; q++) f.stat_wave[q] = light[q];
     }
-    out.bsrc.assign(boff, -1);
-    for (int m = 0; m < f.ng; m++)
-        for (int rp = 0; rp < f.nrp; rp++)
-            for (int rq = 0; rq < f.grp_nq[m]; rq++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int c = 0; c < 4; c++) {
-                        const int r = f.grp_ring0[m] + 4 * rq + c, k = 16 * m + (lane >> 2), j = lane & 3;
-                        const int ref = 2 * rp + (j >> 1);
-                        if (ref >= nref) continue;
-                        out.bsrc[f.grp_boff[m] + ((rp * f.grp_nq[m] + rq) * 64 + lane) * 4 + c] = rf_bsrc_code(g, k, r, ref, j & 1);
-                    }
     out.cdc_w.assign(g.nring, 0.f);
     if (g.nring > 64) return false;
     for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
@@ -174,7 +181,7 @@ __global__ void pack_refs_fused_kernel(DevGeom g, FusedGeom f, const float *__re
         const int code = f.bsrc[idx];
         float v = 0.f;
         if (code >= 0) {
-            const int e = code >> 5, ref = (code >> 1) & 15;
+            const int e = code >> 8, ref = (code >> 1) & 127;
             if (ref < nref) v = refspec[(size_t)ref * g.lring + g.ent_src[e] + (code & 1)] * g.ent_wgt[e] * inv;
         }
         Bf[idx] = v;

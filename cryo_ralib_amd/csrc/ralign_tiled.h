@@ -1,0 +1,354 @@
+// Particle-resident search kernel for MORE references than one pass of search_fused_kernel can accumulate
+// (BASELINE configs[3]: 90 x 90, nref = 50; any nref at maxrin 256 and <= 36 rings).
+//
+// Same pass structure as search_fused_kernel (ralign_fused.h): 4 search offsets per pass, ring jobs into the 4 LDS ring
+// buffers, contraction on v_mfma_f32_4x4x1_16b_f32, CCF spectra in LDS, inverse FFT + argmax there.  What changes is
+// where the A operand (the particle spectra) lives while the references are walked in TILES of 2 NH <= 10:
+//   * after the ring jobs every wave loads ITS slice of the spectra -- the 16 Fourier bins of its bin group x the
+//     (Re, Im) of one offset pair x every ring that has those bins: one float per ring and lane, <= 36 VGPRs -- into
+//     registers.  From then on the ring buffers are dead, so the CCF spectra of every tile can use their space (47 slots
+//     of N complex points = 4 offsets x 10 references + slack) while the A operand stays available for the next tile.
+//   * wave role = (bin group, offset pair): 8 groups x 2 offset pairs = 16 waves; a tile accumulates NH reference
+//     pairs in NH x 4 VGPRs.  The contraction of a tile touches no LDS at all (A in registers, B from L2): the waves
+//     that are through with the inverse FFTs of tile t run the contraction of tile t + 1 on the matrix pipe while the
+//     others still transform on the vector pipe.
+//   * two workgroup barriers per tile (before the spectra store: every inverse FFT of the previous tile is over;
+//     after it: the spectra are complete); the best record per offset is carried across tiles in LDS with the same
+//     ascending-reference ">=" rule reduce_records applies within a tile.
+// HBM sees the image once and one record per search offset; the B stream (1.3 MB at 50 references) comes from L2.
+//
+// Reference call site restated: Util.multiref_polar_ali_2d (test_mref_gpu_align.py:1043-1044); replaces what
+// cu_ccf_mult_m + CcfResultTable do at cuda/gpu_aln_noref.cu:1009-1143, 2095-2206.
+#pragma once
+
+#include "ralign_fused.h"
+
+namespace ralign {
+
+constexpr int RT_MAXNH = 5;        // reference pairs per tile (4 offsets x 10 references = 40 of the 47 spectrum slots)
+constexpr int RT_NQ = 9;           // ring quads of a wave's A slice (<= 36 rings)
+
+inline bool build_tiled_plan(const Geometry &g, int nref, int sbuf, size_t lds_polar_floats, FusedPlanHost &out)
+{
+    FusedGeom &f = out.f;
+    f = FusedGeom{};
+    out.bsrc.clear(); out.cdc_w.clear();
+    if (g.maxrin != 256 || g.numr[2] < 8 || g.nring > 4 * RT_NQ || nref > 127) return false;
+    f.ng = 8; f.wpg = 2;
+    f.nrp = (nref + 1) / 2;
+    f.ntile = (f.nrp + RT_MAXNH - 1) / RT_MAXNH;
+    f.nh = (f.nrp + f.ntile - 1) / f.ntile;
+    f.nrpw = f.nh;
+    const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
+    f.rz = 2 * f.nh; f.nzr = f.ntile;
+    f.rz_inv = (65536 + f.rz - 1) / f.rz;
+    if (4 * f.rz * zstride > 4 * sbuf) return false;
+    rf_layout_b(g, nref, f, out.bsrc);
+    // wave roles (bin group m | offset pair << 8).  Waves w, w + 4, w + 8, w + 12 share a SIMD.  The inverse-FFT round of a
+    // tile gives waves 0 - 7 a full call, waves 8 - 11 a half-filled one and waves 12 - 15 none (ifft_round): the waves
+    // without a transform take the heaviest contraction items of their SIMD, and the SIMDs get equal ring-quad totals.
+    {
+        struct Item { int m, op, cost; };
+        std::vector<Item> items;
+        for (int m = 0; m < f.ng; m++)
+            for (int op = 0; op < 2; op++) items.push_back({m, op, f.grp_nq[m]});
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, light[4] = {0, 1, 2, 3};
+        for (const Item &it : items) {
+            int c = -1;
+            for (int q = 0; q < 4; q++)
+                if (used[q] < 4 && (c < 0 || load[q] < load[c])) c = q;
+            const int w = c + 4 * (3 - used[c]);          // heaviest first -> waves 12 .. 15, lightest -> waves 0 .. 3
+            f.wmap[w] = it.m | (it.op << 8);
+            load[c] += it.cost; used[c]++;
+            light[c] = w;
+        }
+        for (int q = 0; q < 4; q++) f.stat_wave[q] = light[q];
+    }
+    out.cdc_w.assign(g.nring, 0.f);
+    for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
+    f.gstr = 4 * RT_NQ + 4;
+    const size_t fl = lds_polar_floats + 2 * g.maxrin + (4 * 2 * RT_MAXNH + 8) * (sizeof(CandT) / 4) + f.ng * f.gstr + ((nref + 3) & ~3) + 64;
+    out.lds_bytes = fl * sizeof(float);
+    f.on = out.lds_bytes <= 160 * 1024;
+    return f.on != 0;
+}
+
+// contraction of one tile for one wave: NH reference pairs rp0 .. rp0 + NH - 1 of the wave's bin group against the A slice
+// in registers (one offset pair); acc[h] = the 4 x 4 block (2 offsets x (Re, Im)) x (2 references x (Re, Im)) per bin
+template <int NH>
+__device__ __forceinline__ void rt_contract(const float (&a)[4 * RT_NQ], const float *__restrict__ Bg, int rp0, int nrp, int nq,
+                                            int ln, f32x4 (&acc)[NH])
+{
+    // B operands: one wave-uniform row base per reference pair + the lane's 16 bytes + 1 KB per ring quad; a pair past the
+    // last one (final tile) re-reads the last pair's rows and is never stored
+    const char *bu[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) bu[h] = reinterpret_cast<const char *>(Bg + (size_t)(min(rp0 + h, nrp - 1) * nq) * 256);
+    const unsigned loff = (unsigned)ln * 16u;
+    float4 bc[NH], bn[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) bc[h] = *reinterpret_cast<const float4 *>(bu[h] + loff);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < RT_NQ; q++) {
+        if (q < nq) {                                   // wave-uniform
+            if (q + 1 < nq) {
+#pragma unroll
+                for (int h = 0; h < NH; h++) bn[h] = *reinterpret_cast<const float4 *>(bu[h] + loff + (size_t)(q + 1) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                    acc[h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[4 * q + c], rf_f4(bc[h], c), (q == 0 && c == 0) ? zero : acc[h], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < NH; h++) bc[h] = bn[h];
+        }
+    }
+}
+
+template <int N, int NH, int SB>
+__global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, FusedGeom f, const float *__restrict__ particles,
+                                                                  const float *__restrict__ state, int n,
+                                                                  const float *__restrict__ Bf, int nref,
+                                                                  CandT *__restrict__ cand, const int *__restrict__ /*cls*/)
+{
+    DevGeom g = g_in;
+    g.maxrin = N; g.lg_maxrin = __builtin_ctz(N);
+    if constexpr (SB != 0) g.sbuf = SB;
+    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
+    constexpr int RZ = 2 * NH;                                         // references per tile
+    extern __shared__ __align__(16) float lds[];
+    // LDS plan of polar_fft_kernel / search_fused_kernel, then the extras of this kernel
+    const int npad = g.pst * g.pst;
+    float *img = lds;
+    float *bufs = lds + ((npad + 3) & ~3);                             // [4][sbuf] ring buffers | CCF spectra of a tile
+    float2 *tw_s = reinterpret_cast<float2 *>(bufs + 4 * g.sbuf);
+    float2 *qt_s = tw_s + g.maxrin;
+    int4 *inst_s = reinterpret_cast<int4 *>(qt_s + g.n_qtab + (g.n_qtab & 1));
+    int4 *jobs_s = inst_s + g.n_inst;
+    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);
+    float *red = instw_s + g.n_inst;
+    float2 *tws = reinterpret_cast<float2 *>(red + 24 + 8 * g.nring + ((g.n_inst + 8 * g.nring) & 1));
+    CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);              // [4][RZ] records of the tile
+    CandT *pbest = pc + 4 * 2 * RT_MAXNH;                              // [4] best record per offset over the tiles so far
+    int *goff_s = reinterpret_cast<int *>(pbest + 8);                  // [ng][gstr] ring offsets (bytes) of every group's ring quads
+    float *cdc_s = reinterpret_cast<float *>(goff_s + f.ng * f.gstr);  // [nref] DC weights of the references
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < g.maxrin; i += RF_THREADS) tw_s[i] = g.tw[i];
+    for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
+    for (int i = tid; i < g.n_inst; i += RF_THREADS) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
+    for (int i = tid; i < g.n_job; i += RF_THREADS) jobs_s[i] = g.jobs[i];
+    for (int i = tid; i < R1 * R2; i += RF_THREADS) {
+        const float2 t = g.tw[((i / R2) * (i % R2) * (g.maxrin / N)) & (g.maxrin - 1)];
+        tws[i] = make_float2(t.x, -t.y);
+    }
+    for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;
+    for (int i = tid; i < nref; i += RF_THREADS) cdc_s[i] = f.cdc_w[i];
+    for (int i = tid; i < f.ng * f.gstr; i += RF_THREADS) {
+        const int m = i / f.gstr, j = i - m * f.gstr;
+        goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
+    }
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    int *ifft_done = reinterpret_cast<int *>(red + 6);
+    if (tid == 0) *ifft_done = 0;
+    int done_target = 0;
+
+    const int xm = f.wmap[wave] & 255, op = f.wmap[wave] >> 8;       // this wave's bin group and offset pair
+    const int nq = f.grp_nq[xm];
+    const float *Bg = Bf + f.grp_boff[xm];
+    const int ngroup = g.nshift_pad / 4, ntile = f.ntile;
+#pragma unroll 1
+    for (int p = blockIdx.x; p < n; p += gridDim.x) {
+    RF_LDS_BARRIER();
+    const float *src = particles + (size_t)p * g.nx * g.nx;
+    for (int row = wave; row < g.pst; row += RF_WAVES) {
+        const int y = row - g.bd;
+        const bool yin = y >= 0 && y < g.nx;
+        for (int c = lane; c < g.pst; c += 64) {
+            const int x = c - g.bd;
+            img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
+        }
+    }
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
+    if (tid < 4) {
+        const int si = min((int)tid, g.nshift - 1);
+        red[16 + 2 * tid] = cxf + g.shift_x[si];
+        red[17 + 2 * tid] = cyf + g.shift_y[si];
+        red[7] = 0.f;
+    }
+    RF_LDS_BARRIER();
+    const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
+    // records of tile t (ascending reference, ">=": later wins) against the best of the earlier tiles (a later tile wins
+    // ties, as a later reference does); the last tile of a pass scales by 1/sigma and writes the pass's records out
+    auto merge_records = [&](int t, bool last, int gr, int nl) {
+        constexpr int W = sizeof(CandT) / 4;
+        if (wave == 2 && lane < nl * W) {
+            const int o = lane / W, wd = lane - o * W;
+            const int nrz = min(RZ, nref - t * RZ);
+            float bv = pc[o * RZ].val; int br = 0;
+            for (int q3 = 1; q3 < nrz; q3++) {
+                const float v = pc[o * RZ + q3].val;
+                if (v >= bv) { bv = v; br = q3; }
+            }
+            const CandT *srcr = pc + o * RZ + br;
+            if (t > 0 && !(bv >= pbest[o].val)) srcr = pbest + o;
+            int word = reinterpret_cast<const int *>(srcr)[wd];
+            if (last) {
+                if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
+                reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
+            } else {
+                reinterpret_cast<int *>(pbest + o)[wd] = word;
+            }
+        }
+    };
+    for (int grp = 0; grp < ngroup; grp++) {
+        const int nlive = min(4, g.nshift - 4 * grp);
+        const bool pend = grp > 0;
+        // ---- ring jobs (as search_fused_kernel): the previous pass's last inverse FFTs are awaited inside the first job,
+        // between its sampling and its first write to the ring buffers
+#pragma unroll 1
+        for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
+            const int job = jr * RF_WAVES + wave;
+            if (job >= g.n_job) continue;
+            const int4 jd = jr == 0 ? jd0 : jobs_s[job];
+#ifdef RALIGN_PROFILE_SWITCHES
+            const PassSync ps = {pend && jr == 0, ifft_done, done_target, nullptr};
+#else
+            const PassSync ps = {pend && jr == 0, ifft_done, done_target};
+#endif
+            switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+            case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+            case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+            case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+            case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
+            default: break;
+            }
+        }
+        if (pend && wave >= g.n_job) {
+#ifdef RALIGN_PROFILE_SWITCHES
+            const PassSync ps = {true, ifft_done, done_target, nullptr};
+#else
+            const PassSync ps = {true, ifft_done, done_target};
+#endif
+            ps();
+        }
+        if (pend) merge_records(ntile - 1, true, grp - 1, 4);
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
+        RF_LDS_BARRIER();
+        // Normalize_ring statistics of the 4 offsets and the next pass's sampling centres (as search_fused_kernel)
+        const int os = wave == f.stat_wave[0] ? 0 : wave == f.stat_wave[1] ? 1 : wave == f.stat_wave[2] ? 2 : wave == f.stat_wave[3] ? 3 : -1;
+        if (os >= 0) {
+            float a = 0.f, q = 0.f;
+            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
+            a = wave_sum_dpp(a); q = wave_sum_dpp(q);
+            float avg = 0.f, rsg = 1.f;
+            if (g.mode == RA_MODE_MREF) {
+                avg = a * g.inv_nn_weight;
+                rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
+            }
+            if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
+        }
+        if (wave == 5 && lane < 4 && grp + 1 < ngroup) {
+            const int si = min((grp + 1) * 4 + (int)lane, g.nshift - 1);
+            red[16 + 2 * lane] = cxf + g.shift_x[si];
+            red[17 + 2 * lane] = cyf + g.shift_y[si];
+            red[7] = 0.f;
+        }
+        // ---- this wave's slice of the spectra: bins 16 xm .. 16 xm + 15 of its offset pair, every ring that has them
+        const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
+        const bool live_op = 2 * op < nlive;           // the last pass may leave an offset pair without a live offset
+        float a[4 * RT_NQ];
+        {
+            const char *abase = reinterpret_cast<const char *>(bufs + (2 * op + (xj >> 1)) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
+            const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
+#pragma unroll
+            for (int q = 0; q < RT_NQ; q++) {
+                if (q < nq && live_op) {
+                    const int4 o = gq[q];
+                    a[4 * q] = *reinterpret_cast<const float *>(abase + o.x); a[4 * q + 1] = *reinterpret_cast<const float *>(abase + o.y);
+                    a[4 * q + 2] = *reinterpret_cast<const float *>(abase + o.z); a[4 * q + 3] = *reinterpret_cast<const float *>(abase + o.w);
+                } else {
+                    a[4 * q] = a[4 * q + 1] = a[4 * q + 2] = a[4 * q + 3] = 0.f;
+                }
+            }
+        }
+        // ---- tiles of RZ references
+#pragma unroll 1
+        for (int t = 0; t < ntile; t++) {
+            const int ref_lo = t * RZ, nrz = min(RZ, nref - ref_lo);
+            f32x4 acc[NH];
+            if (live_op) rt_contract<NH>(a, Bg, t * NH, f.nrp, nq, ln, acc);
+            else {
+#pragma unroll
+                for (int h = 0; h < NH; h++) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
+            if (t > 0) merge_records(t - 1, false, grp, nlive);
+            {
+                // Z_k = Q_k + i T_k and Z_{N-k} (rf_store_z) for this lane's bin of every reference pair of the tile
+                typedef ZLayout<N> ZL;
+                const int k = 16 * xm + xb, km = k ? N - k : N / 2;
+                const int ref_b = ref_lo + (xj >> 1), o = 2 * op + odd;
+                float *zk = bufs + (o * RZ + (xj >> 1)) * ZL::kPairStride + 2 * (k + (k >> 4));
+                const int dkm = 2 * (km + (km >> 4)) - 2 * (k + (k >> 4));
+                float dcv[NH];
+                if (xm == 0) {
+                    const float av = red[8 + o];
+#pragma unroll
+                    for (int h = 0; h < NH; h++) dcv[h] = av * cdc_s[min(ref_b + 2 * h, nref - 1)];
+                }
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const int ref = ref_b + 2 * h;
+                    const f32x4 c4 = acc[h];
+                    const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
+                    const float r0x = swap_lane_pair(s0), r1x = swap_lane_pair(s1);
+                    float ca = odd ? r0x : c4[0];
+                    const float cb = odd ? r1x : c4[1], cc = odd ? c4[2] : r0x, cd = odd ? c4[3] : r1x;
+                    const bool live = ref < nref && o < nlive;
+                    float2 vk, vm;
+                    if (xm == 0) {
+                        if (xb == 0 && live) ca -= dcv[h];
+                        const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                        vk = xb == 0 ? make_float2(ca, ca) : make_float2(apd + bpc, cmb + amd);
+                        vm = xb == 0 ? make_float2(cd, cd) : make_float2(apd - bpc, amd - cmb);
+                    } else {
+                        const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
+                        vk = make_float2(apd + bpc, cmb + amd);
+                        vm = make_float2(apd - bpc, amd - cmb);
+                    }
+                    if (live) {
+                        float *z = zk + 2 * h * ZL::kPairStride;
+                        *reinterpret_cast<float2 *>(z) = vk;
+                        *reinterpret_cast<float2 *>(z + dkm) = vm;
+                    }
+                }
+            }
+            RF_LDS_BARRIER();         // the spectra of the tile are complete
+            {
+                const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
+                const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
+                const int o = __mul24(zs, f.rz_inv) >> 16, rr = zs - __mul24(o, RZ);
+                if (zs < 4 * RZ && rr < nrz && o < nlive)
+                    ifft_argmax<N, 1, 0>(bufs, pc + (o * RZ + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
+            }
+        }
+        if (grp + 1 < ngroup) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            done_target += RF_WAVES;
+        } else {
+            RF_LDS_BARRIER();
+            merge_records(ntile - 1, true, grp, nlive);
+        }
+    }
+    }
+}
+
+}  // namespace ralign

@@ -1234,3 +1234,48 @@ def test_fused_kernel_with_two_spectra_rounds(nref, nx, ou):
     if nx >= 48:         # 12 references in a 32 x 32 box are too alike for the planted class to win every time (the oracle agrees)
         assert (r["ref_id"] == truth["cls"]).all()
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# more than 16 references: search_tiled_kernel (ralign_tiled.h), BASELINE configs[3]
+
+@pytest.mark.parametrize("nref,sigma", [(50, 0.25), (50, 1.0), (100, 1.0), (17, 1.0), (24, 1.0), (37, 0.5)])
+def test_tiled_kernel_covers_more_than_sixteen_references(nref, sigma):
+    """nref > 16 at the headline geometry stays particle-resident (search_path 1: reference tiles walked inside the
+    workgroup, A operand in registers); assignments and peaks against the oracle, ragged last tiles included"""
+    nx, ou, xr, n = 90, 36, 3, 300
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    d[::7] = (2, -1); d[3::11] = (-7, 6)             # edge-limited windows too
+    d0 = d.copy()
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=d0)
+    assert eng.search_path == 1
+    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    _log_flips("tiled nref=%d sigma=%g" % (nref, sigma), n, flips)
+    eng.close()
+
+
+def test_tiled_kernel_equals_fused_kernel_at_ten_references(monkeypatch):
+    """RALIGN_TILED=1 forces the tiled kernel at nref = 10 (one tile): same records as search_fused_kernel"""
+    nx, ou, nref, xr, n = 90, 36, 10, 3, 300
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    a = api.Engine.result_to_numpy(res).copy(); sa = st.cpu().numpy().copy()
+    eng.close()
+    monkeypatch.setenv("RALIGN_TILED", "1")
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == 1
+    b = api.Engine.result_to_numpy(res).copy(); sb = st.cpu().numpy().copy()
+    eng.close()
+    rel = np.abs(a["peak"] - b["peak"]) / np.abs(a["peak"])
+    assert rel.max() < 2e-5
+    same = np.ones(n, bool)
+    for fld in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+        same &= a[fld] == b[fld]
+    assert (~same).sum() <= 2 and (rel[~same] < TIE_RTOL).all()
+    np.testing.assert_array_equal(sa[same], sb[same])
