@@ -44,26 +44,30 @@ inline bool build_tiled_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     f.rz_inv = (65536 + f.rz - 1) / f.rz;
     if (4 * f.rz * zstride > 4 * sbuf) return false;
     rf_layout_b(g, nref, f, out.bsrc);
-    // wave roles (bin group m | offset pair << 8).  Waves w, w + 4, w + 8, w + 12 share a SIMD.  The inverse-FFT round of a
-    // tile gives waves 0 - 7 a full call, waves 8 - 11 a half-filled one and waves 12 - 15 none (ifft_round): the waves
-    // without a transform take the heaviest contraction items of their SIMD, and the SIMDs get equal ring-quad totals.
+    // wave roles (bin group m | offset pair << 8).  Waves w, w + 4, w + 8, w + 12 share a SIMD, whose issue port the vector
+    // and the matrix instructions of its waves share (wave timeline, scripts/tiled_timeline.sh: a tile costs a SIMD the sum
+    // of both).  The inverse-FFT round of a tile is one call (4 transforms) for each of the waves 0 .. 7 and, at rz = 10, a
+    // second one for waves 0 and 1, so two SIMDs carry three calls and two carry two: the contraction items (cost = ring quads of the group) are dealt
+    // heaviest-first to the SIMD with the least work so far, a call counted as RT_CALL_QUADS ring quads, and inside a SIMD
+    // the heaviest item goes to the youngest wave (no call, or the call that starts last).
     {
         struct Item { int m, op, cost; };
         std::vector<Item> items;
         for (int m = 0; m < f.ng; m++)
             for (int op = 0; op < 2; op++) items.push_back({m, op, f.grp_nq[m]});
         std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
-        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, light[4] = {0, 1, 2, 3};
+        constexpr int RT_CALL_QUADS = 10;      // ~390 vector instructions x 4 cycles against 20 matrix instructions x 8 cycles per ring quad
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 8; w++) load[w & 3] += RT_CALL_QUADS;              // ifft calls: waves 0 - 7, and a second one of
+        if (4 * f.rz > 32) { load[0] += RT_CALL_QUADS; load[1] += RT_CALL_QUADS; }      // waves 0 and 1 (search_tiled_kernel)
         for (const Item &it : items) {
             int c = -1;
             for (int q = 0; q < 4; q++)
                 if (used[q] < 4 && (c < 0 || load[q] < load[c])) c = q;
-            const int w = c + 4 * (3 - used[c]);          // heaviest first -> waves 12 .. 15, lightest -> waves 0 .. 3
-            f.wmap[w] = it.m | (it.op << 8);
+            f.wmap[c + 4 * (3 - used[c])] = it.m | (it.op << 8);
             load[c] += it.cost; used[c]++;
-            light[c] = w;
         }
-        for (int q = 0; q < 4; q++) f.stat_wave[q] = light[q];
+        for (int q = 0; q < 4; q++) f.stat_wave[q] = q;           // the oldest waves: lightest contraction roles
     }
     out.cdc_w.assign(g.nring, 0.f);
     for (int r = 0; r < 68; r++) f.roff[r] = g.ring_off[std::min(r, g.nring - 1)];
@@ -74,38 +78,48 @@ inline bool build_tiled_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
     return f.on != 0;
 }
 
-// contraction of one tile for one wave: NH reference pairs rp0 .. rp0 + NH - 1 of the wave's bin group against the A slice
-// in registers (one offset pair); acc[h] = the 4 x 4 block (2 offsets x (Re, Im)) x (2 references x (Re, Im)) per bin
-template <int NH>
-__device__ __forceinline__ void rt_contract(const float (&a)[4 * RT_NQ], const float *__restrict__ Bg, int rp0, int nrp, int nq,
-                                            int ln, f32x4 (&acc)[NH])
+// contraction of one tile for one wave: NH reference pairs of the wave's bin group against the A slice in registers (one
+// offset pair); acc[h] = the 4 x 4 block (2 offsets x (Re, Im)) x (2 references x (Re, Im)) per bin.
+// NS ring-quad slots in one straight line -- no branch between the B requests and their multiplies, so the compiler
+// counts the outstanding requests exactly (s_waitcnt vmcnt(n)) instead of draining them at block boundaries.  The slice
+// is RIGHT-aligned in a[]: a wave whose group has fewer than NS ring quads multiplies zeros in its first slots (the B
+// rows it reads there belong to the preceding rows of the stream: finite values).  Two instantiations per kernel:
+// NS = RT_NQ for the groups of the low bins, NS = 4 for the groups only the full-length rings reach.
+// One B buffer per reference pair, refilled for the next slot as soon as its four multiplies have been issued (the
+// matrix instruction reads its operands at issue); the pairs are multiplied two at a time, interleaved, so that
+// consecutive matrix instructions are independent.  B requests are buffer loads: descriptor and row offsets in scalar
+// registers, one lane offset in a vector register.
+typedef int rt_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rt_load_b(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff)
 {
-    // B operands: one wave-uniform row base per reference pair + the lane's 16 bytes + 1 KB per ring quad; a pair past the
-    // last one (final tile) re-reads the last pair's rows and is never stored
-    const char *bu[NH];
+    const rt_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
+template <int NH, int NS>
+__device__ __forceinline__ void rt_contract(const float (&a)[4 * RT_NQ], __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                            const unsigned (&row)[NH], f32x4 (&acc)[NH])
+{
+    constexpr int A0 = 4 * (RT_NQ - NS);
+    float4 bc[NH];
 #pragma unroll
-    for (int h = 0; h < NH; h++) bu[h] = reinterpret_cast<const char *>(Bg + (size_t)(min(rp0 + h, nrp - 1) * nq) * 256);
-    const unsigned loff = (unsigned)ln * 16u;
-    float4 bc[NH], bn[NH];
-#pragma unroll
-    for (int h = 0; h < NH; h++) bc[h] = *reinterpret_cast<const float4 *>(bu[h] + loff);
+    for (int h = 0; h < NH; h++) bc[h] = rt_load_b(rsrc, voff, row[h]);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < RT_NQ; q++) {
-        if (q < nq) {                                   // wave-uniform
-            if (q + 1 < nq) {
+    for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) bn[h] = *reinterpret_cast<const float4 *>(bu[h] + loff + (size_t)(q + 1) * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int h0 = 0; h0 < NH; h0 += 2) {
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int h = 0; h < NH; h++)
-                    acc[h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[4 * q + c], rf_f4(bc[h], c), (q == 0 && c == 0) ? zero : acc[h], 0, 0, 0);
+                for (int h = h0; h < h0 + 2 && h < NH; h++)
+                    acc[h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[A0 + 4 * sl + c], rf_f4(bc[h], c), (sl == 0 && c == 0) ? zero : acc[h], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (sl + 1 < NS) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) bc[h] = bn[h];
+                for (int h = h0; h < h0 + 2 && h < NH; h++) bc[h] = rt_load_b(rsrc, voff, row[h] + (sl + 1) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -160,7 +174,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
 
     const int xm = f.wmap[wave] & 255, op = f.wmap[wave] >> 8;       // this wave's bin group and offset pair
     const int nq = f.grp_nq[xm];
-    const float *Bg = Bf + f.grp_boff[xm];
+    // the B stream as a buffer resource (scalar descriptor; requests carry a scalar row offset and the lane's 16 bytes)
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bf), 0, (f.b_floats + 256) * 4, 0x00020000);
     const int ngroup = g.nshift_pad / 4, ntile = f.ntile;
 #pragma unroll 1
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
@@ -210,6 +225,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
     for (int grp = 0; grp < ngroup; grp++) {
         const int nlive = min(4, g.nshift - 4 * grp);
         const bool pend = grp > 0;
+        // profiling builds: wave timeline of workgroup 0's first particle (stamps: 0 pass start, 1 ring jobs done, 2 behind their
+        // barrier, 3 slice in registers; tile t < 2: 4 + 5 t contraction done, + 1 behind barrier A, + 2 spectra stored, + 3 behind
+        // barrier B, + 4 transforms done; 15 end of the pass)
+        const bool tl = p == (int)blockIdx.x && blockIdx.x == 0 && grp < 64;
+        RA_STAMP(g, tl, grp, wave, 0);
         // ---- ring jobs (as search_fused_kernel): the previous pass's last inverse FFTs are awaited inside the first job,
         // between its sampling and its first write to the ring buffers
 #pragma unroll 1
@@ -239,8 +259,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             ps();
         }
         if (pend) merge_records(ntile - 1, true, grp - 1, 4);
+        RA_STAMP(g, tl, grp, wave, 1);
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
         RF_LDS_BARRIER();
+        RA_STAMP(g, tl, grp, wave, 2);
         // Normalize_ring statistics of the 4 offsets and the next pass's sampling centres (as search_fused_kernel)
         const int os = wave == f.stat_wave[0] ? 0 : wave == f.stat_wave[1] ? 1 : wave == f.stat_wave[2] ? 2 : wave == f.stat_wave[3] ? 3 : -1;
         if (os >= 0) {
@@ -268,27 +290,38 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             const char *abase = reinterpret_cast<const char *>(bufs + (2 * op + (xj >> 1)) * g.sbuf + 2 * (16 * xm + xb) + (xj & 1));
             const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * f.gstr);
 #pragma unroll
-            for (int q = 0; q < RT_NQ; q++) {
-                if (q < nq && live_op) {
-                    const int4 o = gq[q];
-                    a[4 * q] = *reinterpret_cast<const float *>(abase + o.x); a[4 * q + 1] = *reinterpret_cast<const float *>(abase + o.y);
-                    a[4 * q + 2] = *reinterpret_cast<const float *>(abase + o.z); a[4 * q + 3] = *reinterpret_cast<const float *>(abase + o.w);
+            for (int sl = 0; sl < RT_NQ; sl++) {       // right-aligned: slot sl holds ring quad sl - (RT_NQ - nq)
+                if (sl >= RT_NQ - nq && live_op) {
+                    const int4 o = gq[sl - (RT_NQ - nq)];
+                    a[4 * sl] = *reinterpret_cast<const float *>(abase + o.x); a[4 * sl + 1] = *reinterpret_cast<const float *>(abase + o.y);
+                    a[4 * sl + 2] = *reinterpret_cast<const float *>(abase + o.z); a[4 * sl + 3] = *reinterpret_cast<const float *>(abase + o.w);
                 } else {
-                    a[4 * q] = a[4 * q + 1] = a[4 * q + 2] = a[4 * q + 3] = 0.f;
+                    a[4 * sl] = a[4 * sl + 1] = a[4 * sl + 2] = a[4 * sl + 3] = 0.f;
                 }
             }
         }
+        RA_STAMP(g, tl, grp, wave, 3);
         // ---- tiles of RZ references
 #pragma unroll 1
         for (int t = 0; t < ntile; t++) {
             const int ref_lo = t * RZ, nrz = min(RZ, nref - ref_lo);
             f32x4 acc[NH];
-            if (live_op) rt_contract<NH>(a, Bg, t * NH, f.nrp, nq, ln, acc);
-            else {
+            if (live_op) {
+                // row offsets (bytes) of the tile's reference pairs in the wave's group block, moved back by the slots the
+                // wave pads; a pair past the last one (final tile) re-reads the last pair's rows and is never stored
+                unsigned row[NH];
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                    row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)(((nq > 4 ? RT_NQ : 4) - nq) * 1024);
+                if (nq > 4) rt_contract<NH, RT_NQ>(a, brsrc, (unsigned)ln * 16u, row, acc);
+                else rt_contract<NH, 4>(a, brsrc, (unsigned)ln * 16u, row, acc);
+            } else {
 #pragma unroll
                 for (int h = 0; h < NH; h++) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            RA_STAMP(g, tl && t < 2, grp, wave, 4 + 5 * t);
             RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
+            RA_STAMP(g, tl && t < 2, grp, wave, 5 + 5 * t);
             if (t > 0) merge_records(t - 1, false, grp, nlive);
             {
                 // Z_k = Q_k + i T_k and Z_{N-k} (rf_store_z) for this lane's bin of every reference pair of the tile
@@ -330,15 +363,26 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
                     }
                 }
             }
+            RA_STAMP(g, tl && t < 2, grp, wave, 6 + 5 * t);
             RF_LDS_BARRIER();         // the spectra of the tile are complete
-            {
+            RA_STAMP(g, tl && t < 2, grp, wave, 7 + 5 * t);
+            // 4 RZ transforms, 16 lanes each, four per call: waves 0 - 7 take slots 0 .. 31 (lane groups (sub, sub ^ 1) of a
+            // half-wave take slots zs and zs + 16, whose LDS images are 32 banks apart); slots 32 .. 4 RZ - 1 are a second call
+            // of the OLDEST waves 0 and 1, whose first call is over first (the SIMDs issue oldest-first; full calls with 2-way
+            // bank conflicts on their 35 LDS instructions rather than four half-filled calls of 390 vector instructions each:
+            // the phase is bound by vector issue, not by the LDS)
+#pragma unroll 1
+            for (int call = 0; call < 2; call++) {
+                if (wave >= (call ? 2 : 8) || (call == 1 && 4 * RZ <= 32)) break;
                 const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
-                const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
+                const int zs = call == 0 ? (uu & 15) + 16 * (sub & 1) : 32 + 4 * wave + sub;
                 const int o = __mul24(zs, f.rz_inv) >> 16, rr = zs - __mul24(o, RZ);
                 if (zs < 4 * RZ && rr < nrz && o < nlive)
                     ifft_argmax<N, 1, 0>(bufs, pc + (o * RZ + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
             }
+            RA_STAMP(g, tl && t < 2, grp, wave, 8 + 5 * t);
         }
+        RA_STAMP(g, tl, grp, wave, 15);
         if (grp + 1 < ngroup) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
