@@ -801,6 +801,72 @@ __global__ void apply_cs_kernel(int n, const float *__restrict__ cs, const ra_re
     state[2 * p + 1] = (float)((double)state[2 * p + 1] + s * u + c * v);
 }
 
+// The reference's state round trip (test_mref_gpu_align.py:1024-1026; ali2d_single_iter behind test_reffree_gpu_align.py:844-847):
+// the shift a search starts from is rebuilt from the float32 header values (alpha, sx, sy[, mirror]) of the previous
+// iteration -- inverse_transform2(alpha, sx, sy) for mref_ali2d, combine_params2(alpha, sx, sy, mirror, 0, -cs0, -cs1, 0)
+// then inverse_transform2 for ali2d -- in double, EMAN2 Transform algebra v' = M (R(alpha) v + t), and rounded to float32
+// once.  Algebraically d_old + (ix, iy) (what ra_align leaves in d_state); numerically e.g. -6.9999995, which decides
+// edge-limited windows (particle_window) the way the reference's loop does.
+__device__ __forceinline__ void tf_build_d(double a_deg, double tx, double ty, int m, double T[3][3])
+{
+    const double a = a_deg * M_PI / 180.0, c = cos(a), s = sin(a), sgn = m ? -1.0 : 1.0;
+    T[0][0] = sgn * c; T[0][1] = sgn * s; T[0][2] = sgn * tx;
+    T[1][0] = -s; T[1][1] = c; T[1][2] = ty;
+    T[2][0] = 0; T[2][1] = 0; T[2][2] = 1;
+}
+__device__ __forceinline__ void tf_params_d(const double T[3][3], double out[4])
+{
+    const double det = T[0][0] * T[1][1] - T[0][1] * T[1][0];
+    const int m = det < 0;
+    const double sgn = m ? -1.0 : 1.0, c = sgn * T[0][0], s = sgn * T[0][1];
+    double alpha = atan2(s, c) * 180.0 / M_PI;
+    alpha = fmod(alpha, 360.0);
+    if (alpha < 0) alpha += 360.0;
+    if (alpha >= 360.0) alpha -= 360.0;
+    out[0] = alpha; out[1] = sgn * T[0][2]; out[2] = T[1][2]; out[3] = m;
+}
+__global__ void state_from_params_kernel(int n, int mode, const float *__restrict__ cs, const ra_result *__restrict__ res,
+                                         float *__restrict__ state)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double A[3][3], B[3][3], C[3][3], I[3][3], prm[4];
+    double alpha = (double)res[p].alpha, tx = (double)res[p].sx, ty = (double)res[p].sy;
+    if (mode == RA_MODE_REFFREE) {
+        tf_build_d(alpha, tx, ty, res[p].mirror, A);
+        tf_build_d(0.0, -(double)cs[0], -(double)cs[1], 0, B);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                C[i][j] = 0;
+                for (int k = 0; k < 3; k++) C[i][j] += B[i][k] * A[k][j];
+            }
+        tf_params_d(C, prm);
+        alpha = prm[0]; tx = prm[1]; ty = prm[2];
+    }
+    tf_build_d(alpha, tx, ty, 0, A);
+    const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    I[0][0] = A[1][1] / det; I[0][1] = -A[0][1] / det;
+    I[1][0] = -A[1][0] / det; I[1][1] = A[0][0] / det;
+    I[0][2] = -(I[0][0] * A[0][2] + I[0][1] * A[1][2]);
+    I[1][2] = -(I[1][0] * A[0][2] + I[1][1] * A[1][2]);
+    I[2][0] = 0; I[2][1] = 0; I[2][2] = 1;
+    tf_params_d(I, prm);
+    state[2 * p] = (float)prm[1];
+    state[2 * p + 1] = (float)prm[2];
+}
+
+extern "C" int ra_state_from_params(ra_engine *e, const ra_result *d_result, int n, const float *cs, float *d_state)
+{
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    if (!d_result || !d_state) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    const float zero[2] = {0.f, 0.f};
+    RA_HIP(hipMemcpyAsync(e->d_cs, cs ? cs : zero, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(state_from_params_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->cfg.mode, (const float *)e->d_cs, d_result, d_state);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
 // Class-resident alignment (gpu_aln_noref.cu:559-782, the ISAC mode): every particle against the average of its own class, all
 // classes in ONE launch of the fused search kernel.  ra_set_class_references prepares ncls references (Polar2Dm, Frngs,
 // Applyws) and one B stream per class; ra_align_classes aligns particle i to reference d_cls[i].  Needs the fused kernel

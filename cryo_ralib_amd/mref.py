@@ -22,9 +22,14 @@ from . import api, dist, geometry
 
 class MrefAligner:
     def __init__(self, particles, refs, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None):
+                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None, state_roundtrip=True):
         """particles: [n][nx][nx] float32 numpy array or CUDA tensor holding THIS rank's shard;
-        refs: [R][nx][nx]; index0 = global index of particles[0] (even/odd split)."""
+        refs: [R][nx][nx]; index0 = global index of particles[0] (even/odd split).
+        state_roundtrip: rebuild the shift every search starts from out of the float32 (alpha, sx, sy) of the previous
+        iteration with inverse_transform2, as the reference's loop does (test_mref_gpu_align.py:1024-1026); False carries
+        the exact accumulated shift instead (algebraically the same; differs by rounding at edge-limited windows)."""
+        self.state_roundtrip = bool(state_roundtrip)
+        self._have_params = False
         self.dev = torch.device("cuda", device)
         self.particles = self._to_dev(particles)
         self.refs = self._to_dev(refs).clone()
@@ -79,7 +84,10 @@ class MrefAligner:
     def search(self):
         """pre_align_fetch("ref_batch") + mref_align_run + kernel_sum_oe of one iteration (:410-453)."""
         self.engine.set_references(self.refs)
+        if self.state_roundtrip and self._have_params:
+            self.engine.state_from_params(self.result, self.state)         # alphai, sxi, syi = inverse_transform2(alpha, sx, sy)
         self.engine.align(self.particles, self.state, self.result)
+        self._have_params = True
         self.buf.zero_()
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
                                          self.buf.counts_i)
@@ -279,7 +287,10 @@ class RefFreeAligner:
             self.engine.filter_references(self.tavg, 0.0, 0.0, center=-1, cs_in=[cs], normalize=False)
         self.cs = cs
         self.engine.set_references(self.tavg)
-        self.engine.align(self.particles, self.state, self.result, cs if (cs[0] or cs[1]) else None)
+        if self.iteration > 0:
+            # ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0), inverse_transform2 -> sxi, syi
+            self.engine.state_from_params(self.result, self.state, cs)
+        self.engine.align(self.particles, self.state, self.result, None)
         self.buf.zero_()
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
                                          self.buf.counts_i)

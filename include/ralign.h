@@ -168,6 +168,13 @@ int  ra_get_prepared_references(ra_engine *e, float *h_crefim);
  * Asynchronous on the engine's stream. */
 int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
               ra_result *d_result, const float *cs);
+/* the reference's state round trip: rebuild the shift the next search starts from (d_state [n][2]) from the float32
+ * parameters of the previous iteration in d_result -- inverse_transform2(alpha, sx, sy) in RA_MODE_MREF
+ * (test_mref_gpu_align.py:1024-1026), combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0) then
+ * inverse_transform2 in RA_MODE_REFFREE (ali2d_single_iter; cs = host float[2] or NULL).  Call it before ra_align
+ * (then without cs) to follow the reference's loop to the rounding of the header values; without it ra_align
+ * continues from the exact d_state it left. */
+int  ra_state_from_params(ra_engine *e, const ra_result *d_result, int n, const float *cs, float *d_state);
 /* class-resident alignment (the ISAC mode behind ref_free_alignment_2D, cuda/gpu_aln_noref.cu:559-782): every particle
  * against the average of its own class, all classes in one launch.  ra_set_class_references prepares ncls references
  * (d_refs [ncls][nx][nx] device); ra_align_classes aligns particle i to reference d_cls[i] (device, [n]); results and

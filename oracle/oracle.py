@@ -77,6 +77,7 @@ def lib():
                                       ctypes.c_float, ctypes.c_int]
         L.orc_combine_params2.argtypes = [ctypes.c_double] * 3 + [ctypes.c_int] + [ctypes.c_double] * 3 + [ctypes.c_int, dp]
         L.orc_inverse_transform2.argtypes = [ctypes.c_double] * 3 + [ctypes.c_int, dp]
+        L.orc_state_from_params.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, fp]
         L.orc_search_range.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, fp]
         L.orc_prepare_refs.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, rp, ctypes.c_int, fp]
         L.orc_mref_iteration.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, rp,
@@ -217,6 +218,19 @@ def inverse_transform2(alpha, tx=0.0, ty=0.0, mirror=0):
     out = np.zeros(4, np.float64)
     lib().orc_inverse_transform2(alpha, tx, ty, int(mirror), _d(out))
     return out[0], out[1], out[2], int(out[3])
+
+
+def state_from_params(params, mode=0, cs=(0.0, 0.0)):
+    """d [n][2] float32 the next search starts from, rebuilt from the float32 header values (alpha, sx, sy[, mirror]) as
+    the reference's loops do (mode 0: mref_ali2d, inverse_transform2; mode 1: ali2d_single_iter, combine_params2 with the
+    centre correction then inverse_transform2)"""
+    params = np.ascontiguousarray(params, np.float32)
+    n = params.shape[0]
+    assert params.shape == (n, 6)
+    d = np.zeros((n, 2), np.float32)
+    csa = np.array(cs, np.float32)
+    lib().orc_state_from_params(_f(params), n, int(mode), _f(csa), _f(d))
+    return d
 
 
 def search_range(n, radius, shift, rng):

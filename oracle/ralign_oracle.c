@@ -596,6 +596,30 @@ void orc_inverse_transform2(double alpha, double tx, double ty, int mirror, doub
     tf_params(I, out);
 }
 
+/* The state round trip of the reference's iteration loops: the shift d = (sxi, syi) a search starts from is rebuilt
+ * every iteration from the header values (alpha, sx, sy[, mirror]) -- float32 here, as xform.align2d stores them --
+ * mref_ali2d: inverse_transform2(alpha, sx, sy) (test_mref_gpu_align.py:1024-1026, mirror not passed);
+ * ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0) then inverse_transform2
+ * (test_reffree_gpu_align.py:844-847).  Algebraically d_new = d_old + (ix, iy); numerically it comes back as e.g.
+ * -6.9999995, which can narrow an edge-limited search window by one offset (search_range -> int(range / step)) or
+ * trip the |sxi| > mashi reset.  The reference keeps sxi as a Python float; here it is rounded to float32 once
+ * (round-trip errors below half a float32 ulp of d are thereby snapped back). mode: 0 = mref, 1 = reference-free. */
+void orc_state_from_params(const float *params, int n, int mode, const float cs[2], float *d)
+{
+    for (int im = 0; im < n; im++) {
+        const float *p = params + 6 * (size_t)im;
+        double cp[4], inv[4];
+        if (mode == 0) {
+            orc_inverse_transform2((double)p[0], (double)p[1], (double)p[2], 0, inv);
+        } else {
+            orc_combine_params2((double)p[0], (double)p[1], (double)p[2], (int)p[3], 0.0, -(double)cs[0], -(double)cs[1], 0, cp);
+            orc_inverse_transform2(cp[0], cp[1], cp[2], 0, inv);
+        }
+        d[2 * im] = (float)inv[1];
+        d[2 * im + 1] = (float)inv[2];
+    }
+}
+
 /* sp_alignment.search_range, returned already swapped as every caller does
  * (test_mref_gpu_align.py:1035-1038): out = {left, right} = {min(ql,range), min(qe,range)} */
 void orc_search_range(int n, float radius, float shift, float range, float out[2])

@@ -98,6 +98,7 @@ void orc_combine_params2(double a1, double sx1, double sy1, int m1,
                          double a2, double sx2, double sy2, int m2,
                          double out[4]);
 void orc_inverse_transform2(double alpha, double tx, double ty, int mirror, double out[4]);
+void orc_state_from_params(const float *params, int n, int mode, const float cs[2], float *d);
 /* sp_alignment.search_range; returns the pair already swapped as the caller does
  * (test_mref_gpu_align.py:1035-1038): out = {left, right} */
 void orc_search_range(int n, float radius, float shift, float range, float out[2]);
