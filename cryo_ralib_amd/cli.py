@@ -12,7 +12,8 @@ RCCL all-reduce.  Outputs: per iteration `aqm%03d.<ext>` class averages (referen
 `params.txt` rows `idx angle_psi shift_x shift_y mirror class` / `initial2Dparams.txt` rows
 `alpha sx sy mirror`.  --function=ref_ali2d (the default) runs the FSC-fitted tangent filter and the
 centring on the device; any other name is rejected.  An optional mask file replaces model_circle(ou); with an
-.hdf input stack the parameters are also written back into its headers (EMAN.xform.align2d / assign / ID).
+.hdf input stack the parameters also go into headers (EMAN.xform.align2d / assign / ID): of a copy of the stack under
+outdir by default, of the input stack itself with --header_writeback (the reference's behaviour).
 Flags the engine does not implement (--CTF, the --MPI CPU path) are accepted and reported, not silently ignored.
 """
 import argparse
@@ -37,7 +38,11 @@ def _common(p):
     p.add_argument("--MPI", action="store_true")
     p.add_argument("--EQ", action="store_true")
     p.add_argument("--ext", default="hdf", help="format of the written stacks: hdf (EMAN2 MDF, as the reference) | mrcs | npy")
-    p.add_argument("--no_header_writeback", action="store_true", help="do not write xform.align2d / assign / ID into an HDF input stack")
+    p.add_argument("--header_writeback", action="store_true",
+                   help="write xform.align2d / assign / ID into the headers of the HDF INPUT stack itself, as the reference does "
+                        "(the stack is rebuilt and replaced; refused when it holds attributes this writer cannot carry over). "
+                        "Default: the stack with the new headers is written to <outdir>/<stack name> instead")
+    p.add_argument("--no_header_writeback", action="store_true", help="write no stack with xform.align2d / assign / ID headers at all")
 
 
 def _first(v):
@@ -50,6 +55,16 @@ def _user_func(name):
     if name in ("ref_ali2d", "none", "None", ""):
         return "ref_ali2d" if name == "ref_ali2d" else None
     raise SystemExit("--function=%s is not implemented by the MI355X engine (ref_ali2d | none)" % name)
+
+
+def _write_headers(mdfio, args, params, assign=None, ids=None):
+    """xform.align2d / assign / ID headers: into a copy of the stack under outdir (default) or, with --header_writeback,
+    into the input stack itself (refused, with the reason, when that would lose header items)"""
+    dst = args.stack if args.header_writeback else os.path.join(args.outdir, os.path.basename(args.stack))
+    lost = mdfio.write_alignment_headers(args.stack, dst, params, assign=assign, ids=ids)
+    if lost:
+        print("warning: %s does not carry the header items %s of %s (types this writer cannot encode)" % (dst, ", ".join(lost), args.stack),
+              file=sys.stderr)
 
 
 def _setup(args):
@@ -120,8 +135,7 @@ def main_mref(argv=None):
             # test_mref_cheng_yu_bdb_cuda.py:114-203)
             from . import mdfio
             rows.sort(key=lambda x: x[0])
-            mdfio.write_alignment_headers(args.stack, args.stack, [x[1:5] for x in rows], assign=[x[5] for x in rows],
-                                          ids=[x[0] for x in rows])
+            _write_headers(mdfio, args, [x[1:5] for x in rows], assign=[x[5] for x in rows], ids=[x[0] for x in rows])
     al.close()
     return 0
 
@@ -175,6 +189,6 @@ def main_reffree(argv=None):
         stackio.write_stack(os.path.join(args.outdir, "aqfinal.%s" % args.ext), al.tavg.cpu().numpy())
         if os.path.splitext(args.stack)[1].lower() in (".hdf", ".h5") and not args.no_header_writeback:
             from . import mdfio        # set_params2D(img, [angle, shift_x, shift_y, mirror, 1.0], "xform.align2d") (test_reffree.py:453)
-            mdfio.write_alignment_headers(args.stack, args.stack, rows)
+            _write_headers(mdfio, args, rows)
     al.close()
     return 0

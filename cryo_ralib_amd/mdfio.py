@@ -195,8 +195,9 @@ class _File:
             return np.zeros(dims, dtype)
         return np.frombuffer(b, dtype, count, data[0]).reshape(dims)
 
-    def attributes(self, ent):
-        """{name: value} of the version-1 attribute messages of an object (scalars and fixed strings)"""
+    def attributes(self, ent, skipped=None):
+        """{name: value} of the attribute messages of an object (numbers, numeric arrays and fixed-length strings); names of
+        attributes with a datatype this reader does not decode (variable-length strings, compounds) go to `skipped`"""
         out = {}
         b = self.b
         for mtype, _, body, msize in self.messages(ent["ohdr"]):
@@ -211,6 +212,8 @@ class _File:
             try:
                 dtype = self._datatype(p)
             except HDF5FormatError:
+                if skipped is not None:
+                    skipped.append(name)
                 continue
             q = p + pad(tsz)
             dims = self._dataspace(q)
@@ -229,7 +232,7 @@ def mdf_image_count(path):
     return sum(1 for k in imgs if k.isdigit())
 
 
-def read_mdf_stack(path, with_attrs=False, first=0, last=None):
+def read_mdf_stack(path, with_attrs=False, first=0, last=None, report=None):
     """float32 [n][ny][nx] (images in numerical order of their group names); optionally the per-image
     attribute dictionaries (EMAN.* header items).  first / last select images [first, last) -- the file is
     memory-mapped and only the selected datasets are read (each rank reads its own slice,
@@ -250,9 +253,15 @@ def read_mdf_stack(path, with_attrs=False, first=0, last=None):
         g = f.children(imgs[str(i)])
         if "image" not in g:
             raise HDF5FormatError("%s: /MDF/images/%d has no 'image' dataset" % (path, i))
-        out.append(np.asarray(f.read_dataset(g["image"]), np.float32))
+        px = f.read_dataset(g["image"])
+        if report is not None and np.asarray(px).dtype != np.float32:
+            report.setdefault("pixel_types", set()).add(str(np.asarray(px).dtype))
+        out.append(np.asarray(px, np.float32))
         if with_attrs:
-            attrs.append(f.attributes(imgs[str(i)]))
+            sk = [] if report is not None else None
+            attrs.append(f.attributes(imgs[str(i)], sk))
+            if sk:
+                report.setdefault("undecoded_attributes", set()).update(sk)
     arr = np.stack(out) if out else np.zeros((0, 0, 0), np.float32)
     if arr.ndim == 4 and arr.shape[1] == 1:
         arr = arr[:, 0]
@@ -297,17 +306,37 @@ class _Writer:
     def datatype(dt):
         dt = np.dtype(dt)
         if dt.kind == "f":
-            assert dt.itemsize == 4
-            # IEEE f32 LE: class 1 v1; bits: byte order 0, padding 0, mantissa normalisation 2 (implied), sign location 31
+            assert dt.itemsize in (4, 8)
+            # IEEE LE: class 1 v1; bits: byte order 0, padding 0, mantissa normalisation 2 (implied), sign location 31 / 63
+            if dt.itemsize == 8:
+                return struct.pack("<BBBBI", 0x11, 0x20, 63, 0, 8) + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
             return struct.pack("<BBBBI", 0x11, 0x20, 31, 0, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
-        if dt.kind == "i":
-            return struct.pack("<BBBBI", 0x10, 0x08, 0, 0, dt.itemsize) + struct.pack("<HH", 0, 8 * dt.itemsize)
+        if dt.kind in "iu":
+            return struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0, dt.itemsize) + struct.pack("<HH", 0, 8 * dt.itemsize)
+        if dt.kind == "S":       # fixed-length string, null-terminated, ASCII
+            return struct.pack("<BBBBI", 0x13, 0x00, 0, 0, dt.itemsize)
         raise ValueError(dt)
 
     def attribute(self, name, value):
-        """scalar or 1-D array attribute (EMAN2 stores a Transform, e.g. xform.align2d, as 12 floats)"""
+        """scalar or 1-D array attribute (EMAN2 stores a Transform, e.g. xform.align2d, as 12 floats); numbers keep their
+        width and signedness, str / bytes become fixed-length strings (EMAN.source_path, ...)"""
+        if isinstance(value, str):
+            value = value.encode()
         value = np.asarray(value)
-        dt = np.dtype("<f4") if value.dtype.kind == "f" else np.dtype("<i4")
+        if value.dtype.kind == "U":
+            value = np.char.encode(value)
+        if value.dtype.kind == "S":
+            dt = np.dtype("S%d" % (value.dtype.itemsize + 1))      # room for the terminating NUL (numpy strips trailing NULs)
+        elif value.dtype.kind == "f":
+            dt = np.dtype("<f8") if value.dtype.itemsize == 8 else np.dtype("<f4")
+        elif value.dtype.kind in "iu":
+            dt = np.dtype("<" + value.dtype.kind + str(value.dtype.itemsize))
+        elif value.dtype.kind == "b":
+            dt = np.dtype("<i4")
+        else:
+            raise ValueError("attribute %s: values of type %s cannot be written" % (name, value.dtype))
+        if value.ndim > 1:
+            raise ValueError("attribute %s: %d-dimensional attributes cannot be written" % (name, value.ndim))
         nm = name.encode() + b"\0"
         ty, sp = self.datatype(dt), self.dataspace(list(value.shape))
         pad = lambda x: x + bytes((-len(x)) % 8)
@@ -402,11 +431,30 @@ def params_from_matrix(m12):
 def write_alignment_headers(src, dst, params, assign=None, ids=None):
     """header write-back of the reference's drivers (test_mref_cheng_yu_bdb_cuda.py:114-203: output_attr /
     write_attr with list_params ["xform.align2d", "assign", "ID"]; set_params2D at test_mref_gpu_align.py:588):
-    copy stack `src` to `dst` (may be the same path) with, per image, EMAN.xform.align2d (12 floats), EMAN.assign
-    and EMAN.ID next to the attributes the stack already has.  params: rows (alpha, sx, sy, mirror)."""
-    arr, attrs = read_mdf_stack(src, with_attrs=True)
+    copy stack `src` to `dst` with, per image, EMAN.xform.align2d (12 floats), EMAN.assign and EMAN.ID next to the
+    attributes the stack already has.  params: rows (alpha, sx, sy, mirror).
+
+    The reference updates header items in place (EMData.write_header); this writer rebuilds the whole file, so it must be
+    able to carry everything over.  It REFUSES (HDF5FormatError, nothing written) when the source holds what it cannot
+    re-encode: attributes of a type it does not decode (variable-length strings such as EMAN.ctf, compounds), attributes
+    with more than one dimension, or pixel data that are not float32 -- with dst == src (in-place replacement of the
+    user's stack) always, with a new dst unless the attribute can simply be left out there (reported in the return value).
+    Returns the sorted names of the attributes that were NOT carried into a new dst ([] when everything was)."""
+    import os
+    report = {}
+    arr, attrs = read_mdf_stack(src, with_attrs=True, report=report)
     n = arr.shape[0]
     assert len(params) == n
+    lost = set(report.get("undecoded_attributes", ()))
+    for i in range(n):
+        lost.update(k for k, v in attrs[i].items() if k.startswith("EMAN.") and np.ndim(v) > 1)
+    inplace = os.path.abspath(src) == os.path.abspath(dst)
+    if report.get("pixel_types") and inplace:
+        raise HDF5FormatError("%s: pixel data of type %s would be re-encoded as float32; write the headers to a new file instead"
+                              % (src, ", ".join(sorted(report["pixel_types"]))))
+    if lost and inplace:
+        raise HDF5FormatError("%s: attributes %s cannot be carried over by this writer; refusing to replace the stack -- "
+                              "write the headers to a new file instead" % (src, ", ".join(sorted(lost))))
     out = []
     for i in range(n):
         a = {k[5:]: v for k, v in attrs[i].items() if k.startswith("EMAN.") and k[5:] not in ("nx", "ny", "nz") and np.ndim(v) <= 1}
@@ -416,9 +464,14 @@ def write_alignment_headers(src, dst, params, assign=None, ids=None):
         a["ID"] = np.int32(ids[i] if ids is not None else i)
         out.append(a)
     tmp = dst + ".tmp"
-    write_mdf_stack(tmp, np.array(arr), out)
-    import os
+    try:
+        write_mdf_stack(tmp, np.array(arr), out)
+    except Exception:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise
     os.replace(tmp, dst)
+    return sorted(lost)
 
 
 def write_mdf_stack(path, arr, extra_attrs=None):

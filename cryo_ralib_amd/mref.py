@@ -287,9 +287,9 @@ class RefFreeAligner:
             self.engine.filter_references(self.tavg, 0.0, 0.0, center=-1, cs_in=[cs], normalize=False)
         self.cs = cs
         self.engine.set_references(self.tavg)
-        if self.iteration > 0:
-            # ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0), inverse_transform2 -> sxi, syi
-            self.engine.state_from_params(self.result, self.state, cs)
+        # ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0), inverse_transform2 -> sxi, syi
+        # (iteration 0: the header parameters are zero, the centre of the first average is not)
+        self.engine.state_from_params(self.result, self.state, cs)
         self.engine.align(self.particles, self.state, self.result, None)
         self.buf.zero_()
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,

@@ -364,3 +364,38 @@ def test_header_write_back_and_slice_reads(tmp_path):
     for pth in (mrc, npy):
         assert stackio.stack_size(pth) == 23
         np.testing.assert_array_equal(stackio.read_stack(pth, 3, 9), imgs[3:9])
+
+
+def test_header_write_back_never_loses_header_items(tmp_path, golden_dir):
+    """a stack written by libhdf5 (tests/golden/make_hdf_strings_fixture.c) with a fixed-length string, a double and a
+    variable-length string (EMAN.ctf) in every image header: the write-back carries strings and doubles over, names
+    what it cannot encode, and refuses to replace the user's stack in place rather than dropping header items"""
+    import shutil
+    from cryo_ralib_amd import mdfio
+    src = str(tmp_path / "in.hdf")
+    shutil.copy(os.path.join(golden_dir, "eman2_mdf_strings.hdf"), src)
+    before = open(src, "rb").read()
+    rep = {}
+    arr, attrs = mdfio.read_mdf_stack(src, with_attrs=True, report=rep)
+    assert arr.shape == (5, 6, 8) and arr[3, 2, 5] == 3 * 100 + 2 * 8 + 5 + 0.5
+    assert rep == {"undecoded_attributes": {"EMAN.ctf"}}
+    assert bytes(attrs[2]["EMAN.source_path"]) == b"mics/micrograph_02.hdf" and attrs[2]["EMAN.apix_y"].dtype == np.float64
+    params = [(10.0 * i, 1.0, -2.0, i % 2) for i in range(5)]
+    with pytest.raises(mdfio.HDF5FormatError, match="EMAN.ctf"):
+        mdfio.write_alignment_headers(src, src, params)                  # in place: refused, nothing touched
+    assert open(src, "rb").read() == before and not os.path.exists(src + ".tmp")
+    dst = str(tmp_path / "out.hdf")
+    assert mdfio.write_alignment_headers(src, dst, params, assign=[1, 2, 3, 4, 0]) == ["EMAN.ctf"]
+    arr2, at2 = mdfio.read_mdf_stack(dst, with_attrs=True)
+    np.testing.assert_array_equal(arr2, arr)
+    for i in range(5):
+        assert bytes(at2[i]["EMAN.source_path"]) == b"mics/micrograph_%02d.hdf" % i
+        assert at2[i]["EMAN.apix_y"] == np.float64(1.2500000001) and at2[i]["EMAN.apix_x"] == np.float32(1.25)
+        assert int(at2[i]["EMAN.source_n"]) == 3 * i and int(at2[i]["EMAN.assign"]) == [1, 2, 3, 4, 0][i]
+        assert mdfio.params_from_matrix(at2[i]["EMAN.xform.align2d"])[3] == i % 2
+    # a stack without such items is still replaced in place (the reference's behaviour, --header_writeback)
+    plain = str(tmp_path / "plain.hdf")
+    mdfio.write_mdf_stack(plain, arr, [{"source_path": "a/b.hdf", "ptcl_source_coord": np.array([3, 4], np.int32)} for _ in range(5)])
+    assert mdfio.write_alignment_headers(plain, plain, params) == []
+    _, at3 = mdfio.read_mdf_stack(plain, with_attrs=True)
+    assert bytes(at3[4]["EMAN.source_path"]) == b"a/b.hdf" and list(at3[4]["EMAN.ptcl_source_coord"]) == [3, 4]

@@ -279,3 +279,43 @@ def test_reffree_iteration_ormq_consistency(golden_dir):
     assert out[0] == pytest.approx(params[0, 0], abs=1e-3) and int(out[3]) == int(params[0, 3])
     sx_sum = sum((p[1] if p[3] == 0 else -p[1]) for p in params)
     assert ss[0] == pytest.approx(sx_sum, rel=1e-5, abs=1e-5)
+
+
+def test_config0_plumbing_six_iterations_class_sizes_converge():
+    """BASELINE configs[0]: the CPU path alone -- 1000 synthetic 90 x 90 particles, nref = 5, xr = yr = 3, ou = 36,
+    maxit = 6 -- as the loop of mref_ali2d (test_mref_gpu_align.py:1005-1060, 517-575 without a user function): references
+    -> Polar2Dm / Frngs / Applyws, state round trip through the float32 header values, search, rot_shift2D + even/odd
+    sums, (even + odd) / n, normalize.mask.  Started from references blurred by averaging a random fifth of the stack
+    per class, the class sizes settle on the planted ones and stop changing."""
+    from cryo_ralib_amd import synth
+    nx, ou, nref, xr, n, maxit = 90, 36, 5, 3, 1000, 6
+    refs = synth.make_references(nref, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    # initial references: the planted ones + noise of the same level as the particles (a poor start)
+    rng = np.random.default_rng(3)
+    cur = np.stack([orc.normalize_mask(r + rng.standard_normal((nx, nx)).astype(np.float32), mask, 1) for r in refs])
+    d = np.zeros((n, 2), np.float32)
+    params = None
+    sizes, moved = [], []
+    prev_assign = None
+    for it in range(maxit):
+        _, cref = orc.prepare_refs(cur, None, rg)
+        if params is not None:
+            d = orc.state_from_params(params, 0)
+        params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+        assert counts.sum() == n and (counts >= 4).all()
+        assign = params[:, 4].astype(int)
+        if prev_assign is not None:
+            moved.append(int((assign != prev_assign).sum()))
+        prev_assign = assign
+        sizes.append(counts.copy())
+        cur = np.stack([orc.normalize_mask((sums[j, 0] + sums[j, 1]) * np.float32(1.0 / float(counts[j])), mask, 1)
+                        for j in range(nref)])
+    planted = np.bincount(truth["cls"], minlength=nref)
+    # convergence of the class sizes: the last two iterations agree, and with the planted sizes, to a few particles
+    assert np.abs(sizes[-1] - sizes[-2]).max() <= 5, sizes
+    assert np.abs(sizes[-1] - planted).max() <= 0.03 * n, (sizes[-1], planted)
+    assert moved[-1] <= moved[0] and moved[-1] <= 0.02 * n, moved
+    assert (prev_assign == truth["cls"]).mean() > 0.97
