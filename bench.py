@@ -175,7 +175,7 @@ def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=12.0):
                               "sample": "%d particles x 1 iteration, 1 thread, %.1f s" % (n2, dt1)}}
 
 
-def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=512):
+def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=4096):
     """SURVEY.md section 8(d) "parity checks reported with every perf number": the engine against the oracle on a
     sigma = 0.25 and a sigma = 1.0 subsample of the same synthetic workload."""
     import numpy as np
@@ -184,6 +184,8 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=512):
     from oracle import oracle as orc
     if nx > 128:
         n = 8
+    elif nref > 16:
+        n = 1024          # the oracle's share of the run grows with the reference count
     rg = orc.rings(1, ou, 1)
     mask = orc.model_circle(ou, nx, nx)
     out = {"particles_per_set": n, "peak_tolerance": 1e-4}
@@ -214,20 +216,25 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=512):
         same = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & (r["angle_bin"] == jt) & \
                (np.abs(st.cpu().numpy() - d).max(1) < 1e-6)
         rel = np.abs(r["peak"] - params[:, 5]) / np.abs(params[:, 5])
+        # sub-bin angle (prb1d on the 7-point neighbourhood of the peak) of the particles whose integer assignment agrees
+        da = np.abs(((r["alpha"][same] - params[same, 0]) + 180.0) % 360.0 - 180.0)
         key = "sigma_%g" % sigma
         out[key] = {"max_rel_peak": float(rel.max()), "exact_match_rate": float(same.mean()),
                     "tie_flips": int((~same).sum()),
-                    "max_rel_peak_gap_of_flips": float(rel[~same].max()) if (~same).any() else 0.0}
+                    "max_rel_peak_gap_of_flips": float(rel[~same].max()) if (~same).any() else 0.0,
+                    "alpha_outliers_gt_2e-3_deg": int((da > 2e-3).sum()), "max_alpha_diff_deg": float(da.max()) if da.size else 0.0}
         out["search_path"] = {0: "kernel pair", 1: "fused", 2: "generic"}[path]
     return out
 
 
-def committed_traffic(kernel_substr, workload):
+def committed_traffic(kernel_substr, workload, geometry=None):
     """HBM bytes per particle of the dominant kernel from the committed rocprofv3 --pmc passes of this workload
     (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; scripts/profile.sh); PMC counters cannot be
     read from inside this process."""
     import glob
     import re
+    if geometry is not None and tuple(geometry) != tuple(WORKLOADS[workload][1:5]):
+        return None, None          # the summaries were profiled at the workload's default (nx, ou, xr, nref) only
     natural = lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))]      # r02_v10 after r02_v9
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=natural, reverse=True):
         try:
@@ -311,9 +318,9 @@ def main():
         per_launch = n * args.steps / max(n_a, 1)
         kernels = {}
         if path == 1:
-            kernels["search_fused_kernel<%d>" % M] = {
+            kernels[("search_tiled_kernel<%d>" if nref > 16 else "search_fused_kernel<%d>") % M] = {
                 "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + inverse FFT + argmax, "
-                        "particle-resident", "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
+                        "particle-resident" + (", reference tiles of 10 with the A operand in registers" if nref > 16 else ""), "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
         else:
             nm = ("ccf_generic_kernel", "polar_generic_kernel") if path == 2 else ("ccf_kernel<%d>" % M, "polar_fft_kernel")
             kernels[nm[0]] = {"what": "Crosrng_ms contraction (16x16x4 MFMA) + inverse FFT + argmax", "avg_launch_ms": ms_a / max(n_a, 1),
@@ -325,7 +332,7 @@ def main():
             k["frac"] = k["achieved_tflops"] / PEAK_F32_TFLOPS
         dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         kern_ms = sum(k["avg_launch_ms"] * k["launches"] for k in kernels.values())
-        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0], args.workload)
+        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0], args.workload, (nx, ou, xr, nref))
         whole = (polar_f + ccf_f) * total / world / dt / 1e12
         # measured HBM rate of the dominant kernel (committed PMC bytes per particle / live launch time) beside its flop rate:
         # whichever fraction of its peak is larger names the bound (the large-box contraction streams operand panels)

@@ -14,7 +14,8 @@ RCCL all-reduce.  Outputs: per iteration `aqm%03d.<ext>` class averages (referen
 centring on the device; any other name is rejected.  An optional mask file replaces model_circle(ou); with an
 .hdf input stack the parameters also go into headers (EMAN.xform.align2d / assign / ID): of a copy of the stack under
 outdir by default, of the input stack itself with --header_writeback (the reference's behaviour).
-Flags the engine does not implement (--CTF, the --MPI CPU path) are accepted and reported, not silently ignored.
+Options that would change the result and are not implemented (--CTF, --center 2..5, --random_method, --Fourvar,
+--dst != 0, --mode other than F) end the run with an error; --MPI / --EQ select paths with the same results and are only noted.
 """
 import argparse
 import os
@@ -57,6 +58,30 @@ def _user_func(name):
     raise SystemExit("--function=%s is not implemented by the MI355X engine (ref_ali2d | none)" % name)
 
 
+def _reject_unimplemented(args, reffree):
+    """options of the reference's command lines that change the RESULT and that the engine does not implement are an error
+    (exit code 2), not a silent no-op: --center 2..5 (only -1 | 0 | 1: average-centre rule / none / phase_cog),
+    --random_method SHC | SCF, --Fourvar, --mode other than F (full rings), --CTF, --dst != 0 (the angular restriction
+    `delta` of the CPU twin's ali2d_single_iter -> Util.Crosrng_ms_delta, whose source is not in the reference tree; the
+    reference's GPU driver itself keeps delta = 0.0, test_reffree_gpu_align.py:307)."""
+    bad = []
+    if int(args.center) not in (-1, 0, 1):
+        bad.append("--center %g (implemented: -1, 0, 1)" % args.center)
+    if args.CTF:
+        bad.append("--CTF")
+    if reffree:
+        if args.random_method not in ("", "none", "None"):
+            bad.append("--random_method %s" % args.random_method)
+        if args.Fourvar:
+            bad.append("--Fourvar")
+        if str(args.mode).upper() != "F":
+            bad.append("--mode %s (implemented: F, full rings)" % args.mode)
+        if args.dst != 0:
+            bad.append("--dst %g (angular restriction, Crosrng_ms_delta)" % args.dst)
+    if bad:
+        raise SystemExit("not implemented by the MI355X engine: " + "; ".join(bad))
+
+
 def _write_headers(mdfio, args, params, assign=None, ids=None):
     """xform.align2d / assign / ID headers: into a copy of the stack under outdir (default) or, with --header_writeback,
     into the input stack itself (refused, with the reason, when that would lose header items)"""
@@ -81,9 +106,11 @@ def _setup(args):
         from . import api
         api.load_library().print_gpu_info(local)
         raise SystemExit(0)
-    for flag, name in ((args.CTF, "--CTF"), (args.MPI, "--MPI (CPU path)"), (args.EQ, "--EQ")):
+    # flags that select another code path of the reference with the same results: reported, not an error
+    for flag, name in ((args.MPI, "--MPI (the reference's CPU path; this build always runs the GPU engine)"),
+                       (args.EQ, "--EQ (equal-size classes: the reference's GPU path ignores it as well)")):
         if flag and rank == 0:
-            print("warning: %s is not implemented by the MI355X engine and is ignored" % name, file=sys.stderr)
+            print("note: %s" % name, file=sys.stderr)
     return rank, local, world
 
 
@@ -94,6 +121,7 @@ def main_mref(argv=None):
     p.add_argument("--center", type=float, default=1)
     _common(p)
     args = p.parse_args(argv)
+    _reject_unimplemented(args, reffree=False)
     rank, local, world = _setup(args)
     from . import stackio, dist as rdist
     from .mref import MrefAligner
@@ -148,8 +176,13 @@ def main_reffree(argv=None):
     p.add_argument("--nomirror", action="store_true"); p.add_argument("--dst", type=float, default=0.0)
     p.add_argument("--Fourvar", action="store_true"); p.add_argument("--mode", default="F")
     p.add_argument("--random_method", default="")
+    p.add_argument("--all_stages", action="store_true", help="run every stage of --xr/--ts lists (SPHIRE ali2d_base); the reference's "
+                   "GPU driver runs stage 0 only, which is the default here")
+    p.add_argument("--auto_stop", action="store_true", help="with --maxit 0: stop a stage when the criterion decreases (the rule the "
+                   "reference's comments state; its driver computes the flag and never tests it, which is the default here)")
     _common(p)
     args = p.parse_args(argv)
+    _reject_unimplemented(args, reffree=True)
     rank, local, world = _setup(args)
     from . import stackio, dist as rdist
     from .mref import RefFreeAligner
@@ -162,9 +195,10 @@ def main_reffree(argv=None):
     # "--xr '4 2 1 1' --ts '2 1 0.5 0.25'": one stage per entry, --maxit iterations each; --maxit 0 = 10 with auto-stop
     al = RefFreeAligner(data, ou, args.xr, args.yr, args.ts, int(args.ir), int(args.rs), device=local, index0=lo,
                         total_nima=total, nomirror=args.nomirror, mask=mask)
-    max_iter, auto_stop = (10, True) if int(args.maxit) == 0 else (int(args.maxit), False)
+    max_iter = 10 if int(args.maxit) == 0 else int(args.maxit)
+    auto_stop = args.auto_stop and int(args.maxit) == 0
     a0, it = -1.0e22, 0
-    for n_step in range(len(al.stages)):
+    for n_step in range(len(al.stages) if args.all_stages else 1):
         al.set_stage(n_step)
         for _ in range(max_iter):
             it += 1

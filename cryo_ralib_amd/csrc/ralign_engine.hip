@@ -391,6 +391,34 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
     return RA_OK;
 }
 
+// Will ra_create select a particle-resident kernel (search_fused_kernel / search_tiled_kernel) for this geometry?  The same
+// conditions as fused_wanted / tiled_wanted and the LDS estimate of build_device_geometry, evaluated without an engine, so
+// that the size checks charge what that path allocates (candidate records, the B stream) instead of the spectra panels of
+// the two-kernel path, which are then never allocated (ensure_unfused_ws is lazy).
+static bool resident_expected(const Geometry &g, const ra_config &cfg, bool generic, size_t *b_floats)
+{
+    if (generic || (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0)) return false;
+    const bool tiled = cfg.nref > RF_MAXREF && g.maxrin == 256 && g.nring <= 4 * RT_NQ && cfg.nref <= 127 &&
+                       !(getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) == 0);
+    if (!tiled && (cfg.nref > RF_MAXREF || !(g.maxrin == 256 || g.maxrin == 128))) return false;
+    if (g.numr[2] < 8 || g.nring > 64) return false;
+    const int bd0 = (int)std::ceil(std::max(cfg.xrng, cfg.yrng)) + 2, pst0 = g.nx + 2 * bd0 + 3;
+    const int sbuf0 = (g.lring + 31) / 32 * 32 + 16;
+    if ((size_t)(pst0 * pst0 + 4 * sbuf0 + 3400 + (tiled ? 1200 : 0)) * sizeof(float) > 160 * 1024) return false;
+    size_t quads = 0;
+    for (int m = 0; m < g.maxrin / 32; m++) {
+        int r0 = 0;
+        while (r0 < g.nring) {
+            const int n = g.numr[3 * r0 + 2], nbin = (n == g.maxrin) ? n / 2 : n / 2 + 1;
+            if (16 * m < nbin) break;
+            r0++;
+        }
+        quads += (g.nring - r0 + 3) / 4;
+    }
+    if (b_floats) *b_floats = (size_t)((cfg.nref + 1) / 2) * quads * 256 + 256;
+    return true;
+}
+
 static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, bool generic)
 {
     WorkspacePlan w{};
@@ -413,7 +441,14 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
-    w.bytes = (w.a_floats + w.refspec_floats + w.b_floats + w.alscratch_floats + 2) * sizeof(float) + w.cand_recs * sizeof(CandT) +
+    // the particle-resident kernels need one candidate record per particle-offset and their B stream; the spectra panels and
+    // per-tile candidates of the two-kernel path are allocated on first use only (never, when the resident kernel runs)
+    size_t bf = 0;
+    const bool resident = resident_expected(g, cfg, generic, &bf);
+    const size_t fcand = (size_t)chunk * g.nshift_pad + 8;
+    const size_t search_ws = resident ? bf * (sizeof(float) + sizeof(int)) + fcand * sizeof(CandT)      // B stream + its gather table
+                                      : w.a_floats * sizeof(float) + (w.cand_recs + fcand) * sizeof(CandT);
+    w.bytes = (w.refspec_floats + w.b_floats + w.alscratch_floats + 2) * sizeof(float) + search_ws +
               w.zscr_recs * sizeof(float2) + refine + tables;
     // every hipMalloc is rounded up to the allocator's granule; ~40 small tables and buffers
     w.bytes += (size_t)48 * (2 << 20);

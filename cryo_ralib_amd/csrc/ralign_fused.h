@@ -501,7 +501,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
                 if (job >= g.n_job) continue;
                 const int4 jd = jr == 0 ? jd0 : jobs_s[job];
 #ifdef RALIGN_PROFILE_SWITCHES
-                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
+                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl && grp < 64 ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
 #else
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target};
 #endif

@@ -30,7 +30,7 @@
 #define RA_DBG(g, bits) (((g).dbg & (bits)) != 0)
 // wave timeline of the fused search kernel (profiling builds, RALIGN_TIMELINE=<file>): stamp s of pass `grp`
 #define RA_STAMP(g, cond, grp, wave, s)                                                                         \
-    do { if ((g).timeline && (cond) && threadIdx.x % 64 == 0) (g).timeline[((grp) * 16 + (wave)) * 16 + (s)] = clock64(); } while (0)
+    do { if ((g).timeline && (cond) && (grp) < 64 && threadIdx.x % 64 == 0) (g).timeline[((grp) * 16 + (wave)) * 16 + (s)] = clock64(); } while (0)
 #else
 #define RA_DBG(g, bits) false
 #define RA_STAMP(g, cond, grp, wave, s) do { } while (0)

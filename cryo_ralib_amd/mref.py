@@ -310,22 +310,22 @@ class RefFreeAligner:
 
 
 def ali2d_base_gpu(stack, ou, xrng, yrng, step=1.0, ir=1, rs=1, maxit=10, device=0, index0=0, total_nima=None,
-                   center=0, chunk=0, user_func=None, nomirror=False, on_iteration=None):
+                   center=0, chunk=0, user_func=None, nomirror=False, on_iteration=None, all_stages=False, auto_stop=False):
     """mirror of ali2d_base_gpu_isac_CLEAN; returns (params records, final average, criteria).
     Rows of initial2Dparams.txt are (alpha, sx, sy, mirror) (test_reffree_gpu_align.py:561-569).
 
-    xrng / yrng / step may be lists: one stage per entry, `maxit` iterations each (SPHIRE ali2d_base; the reference's
-    copy keeps the lists and runs stage 0 only, test_reffree_gpu_align.py:355-357).  maxit = 0 means 10 iterations
-    per stage with auto-stop (:224-229): the criterion a1 = sum_mask tavg^2 "should increase; stop algorithm when it
-    decreases" (:392-396, :422-432) -- a stage ends with the iteration whose average scored below the best so far."""
+    Defaults follow the reference's GPU driver to the letter: xrng / yrng / step may be lists, but only stage 0 runs
+    (N_step = 0, test_reffree_gpu_align.py:355-357), and maxit = 0 means 10 iterations -- the driver computes and
+    broadcasts the auto-stop flag `again` (:422-433) and never tests it.
+    all_stages=True runs every stage, `maxit` iterations each (SPHIRE's ali2d_base schedule, "--xr '4 2 1 1' --ts '2 1
+    0.5 0.25'"); auto_stop=True (with maxit = 0) ends a stage with the iteration whose average scored below the best so
+    far -- the rule the reference's comments state ("a0 should increase; stop algorithm when it decreases", :392-396)."""
     al = RefFreeAligner(stack, ou, xrng, yrng, step, ir, rs, device, index0, total_nima, False, chunk, nomirror)
-    if int(maxit) == 0:
-        max_iter, auto_stop = 10, True
-    else:
-        max_iter, auto_stop = int(maxit), False
+    max_iter = 10 if int(maxit) == 0 else int(maxit)
+    auto_stop = bool(auto_stop) and int(maxit) == 0
     a0 = -1.0e22
     total_iter = 0
-    for n_step in range(len(al.stages)):
+    for n_step in range(len(al.stages) if all_stages else 1):
         al.set_stage(n_step)
         for _ in range(max_iter):
             total_iter += 1

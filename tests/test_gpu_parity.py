@@ -595,6 +595,22 @@ def test_command_line_entry_points(tmp_path):
     assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
                              "--center=0"]) == 0
     assert np.loadtxt(out2 / "initial2Dparams.txt").shape == (n, 4)
+    # an .hdf input stack: the parameters go into the headers of a COPY under outdir by default, into the stack itself
+    # only with --header_writeback
+    from cryo_ralib_amd import mdfio
+    hdf = str(tmp_path / "stack.hdf")
+    mdfio.write_mdf_stack(hdf, parts, [{"source_n": np.int32(i)} for i in range(n)])
+    before = open(hdf, "rb").read()
+    out3 = tmp_path / "out3"
+    assert cli.main_mref([hdf, str(tmp_path / "refs.mrcs"), str(out3), "--ou=12", "--xr=2", "--yr=2", "--maxit=2", "--function=none"]) == 0
+    assert open(hdf, "rb").read() == before
+    _, at = mdfio.read_mdf_stack(str(out3 / "stack.hdf"), with_attrs=True)
+    rows3 = np.loadtxt(out3 / "params.txt")
+    assert all(int(at[i]["EMAN.assign"]) == int(rows3[i, 5]) and int(at[i]["EMAN.source_n"]) == i for i in range(n))
+    assert cli.main_mref([hdf, str(tmp_path / "refs.mrcs"), str(out3), "--ou=12", "--xr=2", "--yr=2", "--maxit=2", "--function=none",
+                          "--header_writeback"]) == 0
+    _, at = mdfio.read_mdf_stack(hdf, with_attrs=True)
+    assert "EMAN.xform.align2d" in at[0] and int(at[5]["EMAN.source_n"]) == 5
 
 
 def test_class_sums_are_bitwise_reproducible():
@@ -1344,21 +1360,26 @@ def test_multi_stage_schedule_against_oracle():
             flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02, alpha_outlier_frac=0.03)
             _log_flips("stage %d it %d" % (stage, it), n, flips)
     al.close()
-    # the driver walks the stages itself
+    # the driver walks the stages itself when asked to (SPHIRE's schedule) ...
+    seen = []
+    ali2d_base_gpu(parts, ou, [2, 1], [2, 1], [1, 0.5], maxit=2, all_stages=True,
+                   on_iteration=lambda i, a, c: seen.append((i, a.stage, a.engine.num_shifts)))
+    assert seen == [(1, 0, 25), (2, 0, 25), (3, 1, 25), (4, 1, 25)]
+    # ... and runs stage 0 only by default, like the reference's GPU driver (N_step = 0, test_reffree_gpu_align.py:355-357)
     seen = []
     ali2d_base_gpu(parts, ou, [2, 1], [2, 1], [1, 0.5], maxit=2, on_iteration=lambda i, a, c: seen.append((i, a.stage, a.engine.num_shifts)))
-    assert seen == [(1, 0, 25), (2, 0, 25), (3, 1, 25), (4, 1, 25)]
+    assert seen == [(1, 0, 25), (2, 0, 25)]
 
 
 def test_auto_stop_at_maxit_zero():
-    """maxit = 0: ten iterations at most, and a stage ends with the first iteration whose criterion falls below the
-    best one so far (test_reffree_gpu_align.py:224-229, :392-396, :422-432)"""
+    """maxit = 0 with auto_stop: ten iterations at most, and a stage ends with the first iteration whose criterion falls
+    below the best one so far (the rule of the comments at test_reffree_gpu_align.py:224-229, :392-396, :422-432)"""
     from cryo_ralib_amd.mref import ali2d_base_gpu
     nx, ou, xr, n = 32, 12, 2, 150
     refs = synth.make_references(1, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
     crit = []
-    _, _, criteria = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=0, on_iteration=lambda i, a, c: crit.append(c))
+    _, _, criteria = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=0, auto_stop=True, on_iteration=lambda i, a, c: crit.append(c))
     assert crit == criteria and 1 <= len(crit) <= 10
     best = -1.0e22
     for i, c in enumerate(crit):
@@ -1371,6 +1392,9 @@ def test_auto_stop_at_maxit_zero():
     # a fixed count ignores the criterion
     _, _, c5 = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=5)
     assert len(c5) == 5
+    # the default at maxit = 0 is the reference driver's: it computes the flag `again` and never tests it -> 10 iterations
+    _, _, c10 = ali2d_base_gpu(parts, ou, xr, xr, 1.0, maxit=0)
+    assert len(c10) == 10
 
 
 @pytest.mark.parametrize("nref,nx,ou", [(13, 90, 36), (16, 90, 36), (12, 32, 12), (16, 48, 20)])

@@ -399,3 +399,17 @@ def test_header_write_back_never_loses_header_items(tmp_path, golden_dir):
     assert mdfio.write_alignment_headers(plain, plain, params) == []
     _, at3 = mdfio.read_mdf_stack(plain, with_attrs=True)
     assert bytes(at3[4]["EMAN.source_path"]) == b"a/b.hdf" and list(at3[4]["EMAN.ptcl_source_coord"]) == [3, 4]
+
+
+@pytest.mark.parametrize("argv", [["--center=3"], ["--CTF"], ["--random_method=SHC"], ["--Fourvar"], ["--mode=H"], ["--dst=90"]])
+def test_command_line_rejects_what_the_engine_does_not_implement(argv, tmp_path):
+    """options of the reference's command lines that would change the result and are not implemented end the run with an
+    error before anything is read or computed (test_reffree_gpu_align.py:918-935, test_mref_gpu_align.py:1146-1152)"""
+    from cryo_ralib_amd import cli
+    with pytest.raises(SystemExit) as e:
+        cli.main_reffree([str(tmp_path / "nostack.hdf"), str(tmp_path / "out")] + argv)
+    assert "not implemented" in str(e.value)
+    if argv[0] in ("--center=3", "--CTF"):
+        with pytest.raises(SystemExit) as e:
+            cli.main_mref([str(tmp_path / "nostack.hdf"), str(tmp_path / "norefs.hdf"), str(tmp_path / "out")] + argv)
+        assert "not implemented" in str(e.value)
