@@ -58,6 +58,7 @@ struct ra_engine {
     float *d_B = nullptr;               // [nrtile][LBP][16]
     float *d_cs = nullptr;              // [2]
     float *d_alscratch = nullptr;       // [chunk][nx*nx] aligned images of one chunk (deterministic class sums)
+    float *d_sumpart = nullptr;         // [16][2 nref][nx*nx] per-run partial class sums (few classes: class_sum_kernel with runs)
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
@@ -1095,9 +1096,21 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
             hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(256), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
                                cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
         RA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(class_sum_kernel, dim3(2 * e->cfg.nref, (npix + 255) / 256), dim3(256), (size_t)cn * sizeof(int), e->stream, npix, al,
-                           d_result + start, cn, index0 + start, d_sums, d_counts);
+        // few classes: cut every (class, parity) member list into runs so that ~1000 workgroups share the additions
+        const int nseg = 2 * e->cfg.nref, ntile = (npix + 255) / 256;
+        const int nrun = std::min(16, std::max(1, 1024 / (nseg * ntile)));
+        if (nrun > 1 && !e->d_sumpart) {
+            int rcp = dev_alloc(e, &e->d_sumpart, (size_t)16 * nseg * npix, false);
+            if (rcp) return rcp;
+        }
+        hipLaunchKernelGGL(class_sum_kernel, dim3(nseg, ntile, nrun), dim3(256), (size_t)cn * sizeof(int), e->stream, npix, al,
+                           d_result + start, cn, index0 + start, d_sums, d_counts, nrun > 1 ? e->d_sumpart : (float *)nullptr);
         RA_HIP(hipGetLastError());
+        if (nrun > 1) {
+            hipLaunchKernelGGL(class_sum_combine_kernel, dim3((unsigned)(((size_t)nseg * npix + 255) / 256)), dim3(256), 0, e->stream, npix, nseg, nrun,
+                               (const float *)e->d_sumpart, d_sums);
+            RA_HIP(hipGetLastError());
+        }
     }
     return RA_OK;
 }

@@ -1268,9 +1268,14 @@ __global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__r
 // path, test_mref_gpu_align.py:1056-1057), hence bitwise reproducible: one workgroup per
 // (class, parity, 256-pixel tile) walks the batch and adds the aligned images that belong to it.
 // Same scan-all-particles shape as the reference's cu_average_batch_m (gpu_aln_noref.cu:1232-1274).
+// With few classes a (class, parity) holds thousands of images and there are only 2 nref x tiles workgroups: the member
+// list is then cut into gridDim.z contiguous runs (`partial` != null): workgroup z adds its run in particle order into
+// partial[z][class, parity][pixel], and class_sum_combine_kernel adds the runs to the sums in run order -- a fixed
+// association ((sums + run0) + run1) + ..., bitwise reproducible run to run like the single-run case.
 __global__ __launch_bounds__(256) void class_sum_kernel(int npix, const float *__restrict__ aligned,
                                                         const ra_result *__restrict__ res, int n, int index0,
-                                                        float *__restrict__ sums, int *__restrict__ counts)
+                                                        float *__restrict__ sums, int *__restrict__ counts,
+                                                        float *__restrict__ partial)
 {
     extern __shared__ int members[];          // [n] particle indices of this (class, parity), ascending
     __shared__ int nmem;
@@ -1291,12 +1296,31 @@ __global__ __launch_bounds__(256) void class_sum_kernel(int npix, const float *_
     }
     __syncthreads();
     const int cnt = nmem;
+    const int nrun = gridDim.z, run = blockIdx.z;
+    const int j0 = (int)((long long)cnt * run / nrun), j1 = (int)((long long)cnt * (run + 1) / nrun);
     if (live) {
-        float acc = sums[(size_t)seg * npix + pix];
-        for (int j = 0; j < cnt; j++) acc += aligned[(size_t)members[j] * npix + pix];
-        sums[(size_t)seg * npix + pix] = acc;
+        float acc = partial ? 0.f : sums[(size_t)seg * npix + pix];
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {          // four loads in flight, added in particle order
+            const float a0 = aligned[(size_t)members[j] * npix + pix], a1 = aligned[(size_t)members[j + 1] * npix + pix];
+            const float a2 = aligned[(size_t)members[j + 2] * npix + pix], a3 = aligned[(size_t)members[j + 3] * npix + pix];
+            acc += a0; acc += a1; acc += a2; acc += a3;
+        }
+        for (; j < j1; j++) acc += aligned[(size_t)members[j] * npix + pix];
+        if (partial) partial[((size_t)run * gridDim.x + seg) * npix + pix] = acc;
+        else sums[(size_t)seg * npix + pix] = acc;
     }
-    if (counts && blockIdx.y == 0 && threadIdx.x == 0 && cnt) atomicAdd(counts + cls, cnt);
+    if (counts && blockIdx.y == 0 && run == 0 && threadIdx.x == 0 && cnt) atomicAdd(counts + cls, cnt);
+}
+
+__global__ __launch_bounds__(256) void class_sum_combine_kernel(int npix, int nseg, int nrun, const float *__restrict__ partial,
+                                                                float *__restrict__ sums)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nseg * npix) return;
+    float acc = sums[i];
+    for (int r = 0; r < nrun; r++) acc += partial[(size_t)r * nseg * npix + i];
+    sums[i] = acc;
 }
 
 // K5: new references from the class sums: (even + odd) * (1/count), then

@@ -41,6 +41,9 @@ def shard_range(total, world, rank):
     return mpi_start_end(total, world, rank)
 
 
+ORDERED_MAX_BYTES = 8 << 20       # gathered size up to which the rank-ordered sum replaces the all-reduce
+
+
 class ClassSumBuffer:
     """flat fp32 buffer [R][2][nx][nx] sums | [R] counts | [extra] scalars, all-reduced in place.
 
@@ -64,17 +67,22 @@ class ClassSumBuffer:
     def all_reduce(self):
         """sum over ranks; afterwards counts_i holds the global member counts on every rank.
 
-        Default ("ordered"): all-gather the per-rank buffers (648 KB each at R = 10 / 90^2) and add them in rank order,
-        ((S0 + S1) + S2) + ... -- every rank performs the same additions in the same order, so the result is bitwise
-        identical on all ranks and does not depend on which algorithm (ring, tree, direct) RCCL picks for the message
-        size or on the xGMI topology.  RALIGN_ORDERED_REDUCE=0 selects a plain RCCL all-reduce (sum)."""
+        Small buffers ("ordered", world x bytes <= ORDERED_MAX_BYTES: 648 KB per rank at R = 10 / 90^2): all-gather the
+        per-rank buffers and add them in rank order, ((S0 + S1) + S2) + ... -- every rank performs the same additions in
+        the same order, so the result is bitwise identical on all ranks and does not depend on which algorithm (ring, tree,
+        direct) RCCL picks for the message size or on the xGMI topology.  Larger buffers (3.24 MB per rank at R = 50,
+        52.4 MB at R = 100 / 256^2, where the gather would move world x the bytes): one plain RCCL all-reduce (sum) -- still
+        the same bits on every rank of a run, but the association of the float additions follows RCCL's algorithm, so
+        runs on different rank counts / topologies agree to rounding only.  RALIGN_ORDERED_REDUCE=1 / 0 forces either."""
         self.counts_f.copy_(self.counts_i.to(torch.float32))
         if dist.is_initialized() and dist.get_world_size() > 1:
             world = dist.get_world_size()
             # gloo rehearsal of several ranks on one GPU (RALIGN_DIST_BACKEND=gloo): the collective runs on a host copy
             staged = self.flat.is_cuda and dist.get_backend() == "gloo"
             work = self.flat.cpu() if staged else self.flat
-            if os.environ.get("RALIGN_ORDERED_REDUCE", "1") != "0" and world <= 64:
+            mode = os.environ.get("RALIGN_ORDERED_REDUCE", "")
+            ordered = mode == "1" or (mode != "0" and world * work.numel() * 4 <= ORDERED_MAX_BYTES)
+            if ordered and world <= 64:
                 if self._gather is None or self._gather.shape[0] != world or self._gather.device != work.device:
                     self._gather = torch.empty((world,) + work.shape, dtype=work.dtype, device=work.device)
                 dist.all_gather_into_tensor(self._gather.view(-1), work)

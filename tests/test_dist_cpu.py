@@ -89,3 +89,39 @@ def test_ordered_reduction_is_rank_order_sum_on_every_rank(tmp_path):
         o = np.load(tmp_path / ("o1_%d.npz" % r))
         np.testing.assert_array_equal(o["flat"][:want.size], want)
         np.testing.assert_array_equal(o["counts"], [6, 6])
+
+
+def _worker_threshold(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("RALIGN_ORDERED_REDUCE", None)
+    from cryo_ralib_amd import dist as rdist
+    rdist.init_from_env("gloo")
+    calls = []
+    real_gather, real_reduce = rdist.dist.all_gather_into_tensor, rdist.dist.all_reduce
+    rdist.dist.all_gather_into_tensor = lambda *a, **k: (calls.append("gather"), real_gather(*a, **k))[1]
+    rdist.dist.all_reduce = lambda *a, **k: (calls.append("reduce"), real_reduce(*a, **k))[1]
+    res = {}
+    for name, limit in (("small", rdist.ORDERED_MAX_BYTES), ("large", 1024)):
+        rdist.ORDERED_MAX_BYTES = limit
+        buf = rdist.ClassSumBuffer(3, 8, torch.device("cpu"))
+        buf.flat[:buf.nsum] = float(rank + 1)
+        buf.counts_i[:] = rank + 2
+        del calls[:]
+        buf.all_reduce()
+        res[name] = (list(calls), float(buf.flat[0]), int(buf.counts_i[0]))
+    np.save(os.path.join(out_dir, "t%d.npy" % rank), np.array([res["small"][1], res["small"][2], res["large"][1], res["large"][2],
+                                                                 res["small"][0] == ["gather"], res["large"][0] == ["reduce"]], float))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_large_buffers_take_the_plain_all_reduce(tmp_path):
+    """the rank-ordered gather + sum serves buffers up to ORDERED_MAX_BYTES (gathered size); above it -- nref = 50 and the
+    256 x 256 / nref = 100 case -- the one collective of the path is a plain all-reduce (sum), as north_star names it"""
+    world = 2
+    port = 30300 + (os.getpid() % 400)
+    mp.spawn(_worker_threshold, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        v = np.load(tmp_path / ("t%d.npy" % r))
+        assert list(v) == [3.0, 5.0, 3.0, 5.0, 1.0, 1.0]
