@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
     "ref_free_alignment_2D_filter_references", "ra_isac_get_references", "ra_legacy_bytes",
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_set_nomirror", "ra_set_mask",
-    "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_class_references", "ra_align_classes",
+    "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_refine", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
 ]
@@ -101,6 +101,7 @@ def load_library(path=None):
     L.ra_set_class_references.argtypes = [vp, vp, ctypes.c_int]
     L.ra_align_classes.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
     L.ra_state_from_params.argtypes = [vp, vp, ctypes.c_int, float_ptr, vp]
+    L.ra_set_refine.argtypes = [vp, ctypes.c_float]
     L.ra_transform_accumulate.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     L.ra_update_references.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.ra_normalize_particles.argtypes = [vp, vp, ctypes.c_int]
@@ -277,6 +278,11 @@ class Engine:
         _check(self.lib.ra_align(self.handle, self._ptr(particles, self.torch.float32), n,
                                  self._ptr(state, self.torch.float32), self._ptr(result, self.torch.int32), csp),
                "ra_align")
+
+    def set_refine(self, threshold):
+        """sub-bin angle refinement with the CPU path's arithmetic (ra_set_refine): threshold on |c3| / max |b| of prb1d,
+        < 0 = every particle, 0 = off; call before set_references"""
+        _check(self.lib.ra_set_refine(self.handle, float(threshold)), "ra_set_refine")
 
     def state_from_params(self, result, state, cs=None):
         """the reference's state round trip (ra_state_from_params): state <- inverse_transform2 of the float32 parameters

@@ -17,6 +17,7 @@
 #include "ralign_generic.h"
 #include "ralign_fused.h"
 #include "ralign_tiled.h"
+#include "ralign_exact.h"
 #include "ralign_refine.h"
 
 using namespace ralign;
@@ -58,6 +59,13 @@ struct ra_engine {
     float *d_B = nullptr;               // [nrtile][LBP][16]
     float *d_cs = nullptr;              // [2]
     float *d_alscratch = nullptr;       // [chunk][nx*nx] aligned images of one chunk (deterministic class sums)
+    // sub-bin angle refinement with the CPU path's arithmetic (ralign_exact.h)
+    float refine_thr = 0.25f;           // flag |c3| < thr x max |b|; < 0: every particle; 0: off
+    bool refine_ok = false;             // tables built and the kernels' LDS (2 lcirc floats) fits
+    size_t lds_refine = 0;
+    float *d_twx = nullptr, *d_refx = nullptr, *d_cls_refx = nullptr;
+    int *d_twxoff = nullptr, *d_rcount = nullptr;
+    RefineRec *d_rlist = nullptr;
     float *d_sumpart = nullptr;         // [16][2 nref][nx*nx] per-run partial class sums (few classes: class_sum_kernel with runs)
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
@@ -556,6 +564,57 @@ static int setup_fused(ra_engine *e)
     return RA_OK;
 }
 
+// tables and buffers of the sub-bin angle refinement (ralign_exact.h): twiddles (float) of the double-precision cos / sin for
+// every power-of-two length, as fftr_q's tables; exact reference spectra; the list of flagged particles of a chunk
+static int setup_refine(ra_engine *e)
+{
+    const Geometry &g = e->geo;
+    e->refine_ok = false;
+    if (getenv("RALIGN_REFINE")) e->refine_thr = (float)atof(getenv("RALIGN_REFINE"));
+    e->lds_refine = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float);
+    if (e->lds_refine > 160 * 1024 - 256 || (g.lcirc & 1)) return RA_OK;       // large boxes: one offset's rings exceed the LDS
+    std::vector<float> tw;
+    std::vector<int> off(32, 0);
+    for (int l = 1; (1 << l) <= g.maxrin; l++) {
+        const int n = 1 << l, h = n / 2;
+        off[l] = (int)tw.size();
+        for (int k = 0; k < h; k++) {
+            const double a = -2.0 * M_PI * k / n;
+            tw.push_back((float)cos(a)); tw.push_back((float)sin(a));
+        }
+    }
+    const float *dtw = nullptr; const int *doff = nullptr;
+    int rc;
+    if ((rc = upload(e, tw, &dtw)) || (rc = upload(e, off, &doff))) return rc;
+    e->d_twx = (float *)dtw; e->d_twxoff = (int *)doff;
+    if ((rc = dev_alloc(e, &e->d_refx, (size_t)e->cfg.nref * g.lcirc, true)) ||
+        (rc = dev_alloc(e, &e->d_rlist, (size_t)e->chunk, false)) ||
+        (rc = dev_alloc(e, &e->d_rcount, 1, true))) return rc;
+    hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)refspec_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
+    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(refine): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    e->refine_ok = true;
+    return RA_OK;
+}
+
+// finalize + (flagged particles) refine of one chunk: `cand` records with `nrtile` per particle-offset
+static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int cn, float *st, ra_result *res, const float *part,
+                               const float *refx, const int *cls)
+{
+    const bool refine = e->refine_ok && e->refine_thr != 0.f && refx;
+    if (refine) RA_HIP(hipMemsetAsync(e->d_rcount, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, cand, nrtile, cn, st, res, (const float *)e->d_cs,
+                       refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
+    RA_HIP(hipGetLastError());
+    if (refine) {
+        hipLaunchKernelGGL(refine_winner_kernel, dim3(cn), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                           (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
+                           res, cls);
+        RA_HIP(hipGetLastError());
+    }
+    return RA_OK;
+}
+
 // spectra workspace of the two-kernel path, allocated on first use (the fused kernel does not need it)
 static int ensure_unfused_ws(ra_engine *e)
 {
@@ -681,6 +740,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
             (rc = dev_alloc(e, &e->d_gcdc, (size_t)cfg->nref, true))) { ra_destroy(e); return rc; }
     }
     if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
+    if ((rc = setup_refine(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
     return RA_OK;
@@ -703,6 +763,7 @@ extern "C" void ra_destroy(ra_engine *e)
 #endif
     if (e->d_cls_refspec) (void)hipFree(e->d_cls_refspec);
     if (e->d_cls_Bf) (void)hipFree(e->d_cls_Bf);
+    if (e->d_cls_refx) (void)hipFree(e->d_cls_refx);
     for (void *p : e->owned) (void)hipFree(p);
     for (auto &pr : e->ev_ccf) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : e->ev_polar) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -728,6 +789,13 @@ extern "C" int ra_set_nomirror(ra_engine *e, int flag)
     if (!e) return RA_ERR_ARG;
     e->dg.nomirror = flag ? 1 : 0;
     return RA_OK;
+}
+extern "C" int ra_set_refine(ra_engine *e, float threshold)
+{
+    if (!e) return RA_ERR_ARG;
+    e->refine_thr = threshold;
+    e->refs_ready = false;             // the exact reference spectra are prepared by ra_set_references when the refinement is on
+    return e->refine_ok || threshold == 0.f ? RA_OK : RA_ERR_STATE;
 }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
@@ -789,6 +857,11 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
                                e->d_refspec, e->cfg.nref, e->d_Bf);
             RA_HIP(hipGetLastError());
         }
+    }
+    if (e->refine_ok && e->refine_thr != 0.f) {        // the same references with the CPU path's arithmetic, for the sub-bin angle refinement
+        hipLaunchKernelGGL(refspec_exact_kernel, dim3(e->cfg.nref), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                           (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx);
+        RA_HIP(hipGetLastError());
     }
     if (e->generic || e->fused) {
         hipLaunchKernelGGL(ref_dc_weights_kernel, dim3((e->cfg.nref + 63) / 64), dim3(64), 0, e->stream, e->dg, e->d_refspec, e->cfg.nref, e->d_gcdc);
@@ -917,8 +990,11 @@ extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int nc
         if (e->d_cls_refspec) (void)hipFree(e->d_cls_refspec);
         if (e->d_cls_Bf) (void)hipFree(e->d_cls_Bf);
         e->d_cls_refspec = nullptr; e->d_cls_Bf = nullptr; e->cls_cap = 0;
+        if (e->d_cls_refx) (void)hipFree(e->d_cls_refx);
+        e->d_cls_refx = nullptr;
         if (hipMalloc((void **)&e->d_cls_refspec, (size_t)ncls * e->geo.lring * sizeof(float)) != hipSuccess ||
-            hipMalloc((void **)&e->d_cls_Bf, ((size_t)ncls * f.b_floats + 256) * sizeof(float)) != hipSuccess) {
+            hipMalloc((void **)&e->d_cls_Bf, ((size_t)ncls * f.b_floats + 256) * sizeof(float)) != hipSuccess ||
+            (e->refine_ok && hipMalloc((void **)&e->d_cls_refx, (size_t)ncls * e->geo.lcirc * sizeof(float)) != hipSuccess)) {
             g_last_error = "out of device memory (class references)";
             return RA_ERR_NOMEM;
         }
@@ -930,6 +1006,11 @@ extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int nc
     hipLaunchKernelGGL(pack_refs_fused_kernel, dim3(std::min(64, (f.b_floats + 255) / 256), ncls), dim3(256), 0, e->stream, e->dg, f,
                        (const float *)e->d_cls_refspec, 1, e->d_cls_Bf);
     RA_HIP(hipGetLastError());
+    if (e->refine_ok && e->refine_thr != 0.f && e->d_cls_refx) {
+        hipLaunchKernelGGL(refspec_exact_kernel, dim3(ncls), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                           (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, ncls, e->d_cls_refx);
+        RA_HIP(hipGetLastError());
+    }
     e->cls_ready = ncls;
     return RA_OK;
 }
@@ -951,9 +1032,8 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
         hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f,
                            d_particles + (size_t)start * npix, (const float *)st, cn, (const float *)e->d_cls_Bf, 1, e->d_fcand, d_cls + start);
         RA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, e->d_fcand, 1, cn, st,
-                           d_result + start, e->d_cs);
-        RA_HIP(hipGetLastError());
+        int rcf = finalize_and_refine(e, e->d_fcand, 1, cn, st, d_result + start, d_particles + (size_t)start * npix, e->d_cls_refx, d_cls + start);
+        if (rcf) return rcf;
     }
     return RA_OK;
 }
@@ -990,9 +1070,8 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
                                (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, (const int *)nullptr);
             RA_HIP(hipGetLastError());
             if (evc) RA_HIP(hipEventRecord(evc->second, sp));
-            hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, e->d_fcand, 1, cn, st,
-                               d_result + start, e->d_cs);
-            RA_HIP(hipGetLastError());
+            int rcf = finalize_and_refine(e, e->d_fcand, 1, cn, st, d_result + start, d_particles + (size_t)start * npix, e->d_refx, nullptr);
+            if (rcf) return rcf;
         }
         return RA_OK;
     }
@@ -1034,9 +1113,8 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
                                e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
         if (evc) RA_HIP(hipEventRecord(evc->second, sp));
-        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, sp, e->dg, Cbuf, e->nrtile,
-                           cn, st, d_result + start, e->d_cs);
-        RA_HIP(hipGetLastError());
+        int rcf = finalize_and_refine(e, Cbuf, e->nrtile, cn, st, d_result + start, part, e->d_refx, nullptr);
+        if (rcf) return rcf;
     }
     (void)ngroup;
     return RA_OK;

@@ -1138,9 +1138,14 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
 // K3: per-particle reduction over search offsets (y outer, x inner) and reference tiles with
 // the ">=" rule of Util::multiref_polar_ali_2d, ang_n, the ormq tail and combine_params2
 // (test_mref_gpu_align.py:1043-1049).
+// record of a particle whose sub-bin angle is to be re-evaluated with the CPU path's arithmetic (ralign_exact.h)
+struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int pad; };
+
+// rlist / rcount / rthr: particles whose prb1d is ill-conditioned (|c3| < rthr x max |b|; rthr < 0: every particle) are
+// appended to rlist for refine_winner_kernel; rlist = null: none
 __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
                                 float *__restrict__ state, ra_result *__restrict__ res,
-                                const float *__restrict__ cs)
+                                const float *__restrict__ cs, RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -1181,6 +1186,17 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     res[p] = r;
     state[2 * p] = w.sxi + ixw;
     state[2 * p + 1] = w.syi + iyw;
+    if (rlist) {
+        const float *b = best.t7;
+        const float c3 = 5.f * b[0] - 3.f * b[2] - 4.f * b[3] - 3.f * b[4] + 5.f * b[6];
+        float tmax = 0.f;
+        for (int k = 0; k < 7; k++) tmax = fmaxf(tmax, fabsf(b[k]));
+        if (rthr < 0.f || fabsf(c3) < rthr * tmax) {
+            RefineRec rec;
+            rec.p = p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi; rec.pad = 0;
+            rlist[atomicAdd(rcount, 1)] = rec;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
