@@ -18,9 +18,9 @@
 //              same three routines + Applyws (refspec_exact_kernel)
 //   inverse    the 7 samples q(jtot - 3 .. jtot + 3) by direct f64 summation of the inverse real DFT (fftr_d computes all
 //              maxrin of them; the values agree to f64 rounding)
-// One wave per particle; every ring is transformed serially by one lane (the price of the CPU's operation order), so the
-// kernel runs for the particles finalize_kernel flags as ill-conditioned (|c3| < refine_thr x max |b|), or for all of
-// them when the threshold is infinite.
+// One wave per particle (the butterflies of a radix-2 stage are independent, so they are dealt to the lanes without
+// changing an operation); the kernel runs for the particles finalize_kernel flags as ill-conditioned
+// (|c3| < refine_thr x max |b|), or for all of them when the threshold is negative.
 //
 // Reference call sites restated: Util.multiref_polar_ali_2d / ormq -> Crosrng_ms -> prb1d (test_mref_gpu_align.py:1043-1044,
 // test_reffree_gpu_align.py:844-847).
@@ -30,51 +30,75 @@
 
 namespace ralign {
 
-// in-place radix-2 complex FFT of fftr_q / cfft_f (oracle/ralign_oracle.c), forward (sign -1), n a power of two;
-// tw + twoff[l] = e^{-2 pi i k / 2^l}, k < 2^(l-1), (float) of the double-precision cos / sin
-__device__ __forceinline__ void exact_cfft_fwd(float *re, float *im, int n, const float *__restrict__ tw, const int *__restrict__ twoff)
+// Frngs with fftr_q's arithmetic (rfft_fwd_f / cfft_f of oracle/ralign_oracle.c: radix-2, bit-reversal first, table
+// twiddles, split step), every ring in place in `circ`, `work` = lcirc floats of scratch.  The butterflies of one stage
+// are independent of each other, so they are dealt to the lanes without changing a single operation: each of the four
+// 16-lane groups of the wave transforms one ring at a time (rings dealt longest first, round robin), one butterfly per
+// lane and step.  tw + twoff[l] = e^{-2 pi i k / 2^l}, k < 2^(l-1), (float) of the double-precision cos / sin.
+__device__ __forceinline__ void exact_lds_sync()
 {
-#pragma clang fp contract(off)
-    for (int i = 1, j = 0; i < n; i++) {
-        int bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
-    }
-    int l = 1;
-    for (int len = 2; len <= n; len <<= 1, l++) {
-        const int half = len >> 1;
-        const float *t = tw + twoff[l];
-        for (int k = 0; k < half; k++) {
-            const float wr = t[2 * k], wi = t[2 * k + 1];
-            for (int i = k; i < n; i += len) {
-                const int j = i + half;
-                const float tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
-                re[j] = re[i] - tr; im[j] = im[i] - ti;
-                re[i] += tr; im[i] += ti;
-            }
-        }
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// rfft_fwd_f: x[n] -> packed [X0, X(n/2), Re X1, Im X1, ...] in place; wre / wim: n/2 floats each
-__device__ __forceinline__ void exact_rfft_fwd(float *x, int n, float *wre, float *wim, const float *__restrict__ tw,
-                                               const int *__restrict__ twoff)
+__device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevGeom &g, const int *__restrict__ numr,
+                                            const float *__restrict__ tw, const int *__restrict__ twoff, int lane,
+                                            const float *__restrict__ wr /* Applyws weights or null */)
 {
 #pragma clang fp contract(off)
-    const int h = n / 2;
-    const float *t = tw + twoff[31 - __clz(n)];
-    for (int i = 0; i < h; i++) { wre[i] = x[2 * i]; wim[i] = x[2 * i + 1]; }
-    exact_cfft_fwd(wre, wim, h, tw, twoff);
-    x[0] = wre[0] + wim[0];
-    x[1] = wre[0] - wim[0];
-    for (int k = 1; k < h; k++) {
-        const int m = h - k;
-        const float er = 0.5f * (wre[k] + wre[m]), ei = 0.5f * (wim[k] - wim[m]);
-        const float orr = 0.5f * (wim[k] + wim[m]), oi = -0.5f * (wre[k] - wre[m]);
-        const float c = t[2 * k], s = t[2 * k + 1];
-        x[2 * k] = er + orr * c - oi * s;
-        x[2 * k + 1] = ei + orr * s + oi * c;
+    const int l16 = lane & 15, grp = lane >> 4;
+    for (int s0 = 0; s0 < g.nring; s0 += 4) {
+        const int i = g.nring - 1 - (s0 + grp);                 // this group's ring of the slot (rings are sorted by length)
+        const bool have = i >= 0;
+        const int n = have ? numr[3 * i + 2] : 2, o = have ? numr[3 * i + 1] - 1 : 0, h = n >> 1;
+        const int lgh = 31 - __clz(h);
+        const int nmax = numr[3 * (g.nring - 1 - s0) + 2];       // the longest ring of the slot bounds the uniform loops
+        const int lgmax = 31 - __clz(nmax >> 1);
+        float *x = circ + o, *wre = work + o, *wim = work + o + h;
+        if (have)
+            for (int q = l16; q < h; q += 16) {                   // deinterleave into bit-reversed order: out[rev(q)] = in[q]
+                const int r = lgh ? (int)(__brev((unsigned)q) >> (32 - lgh)) : 0;
+                wre[r] = x[2 * q]; wim[r] = x[2 * q + 1];
+            }
+        exact_lds_sync();
+        for (int l = 1; l <= lgmax; l++) {
+            if (have && l <= lgh) {
+                const int len = 1 << l, half = len >> 1;
+                const float *t = tw + twoff[l];
+                for (int bfly = l16; bfly < (h >> 1); bfly += 16) {
+                    const int k = bfly & (half - 1), a = ((bfly >> (l - 1)) << l) + k, c = a + half;
+                    const float w_r = t[2 * k], w_i = t[2 * k + 1];
+                    const float tr = wre[c] * w_r - wim[c] * w_i, ti = wre[c] * w_i + wim[c] * w_r;
+                    wre[c] = wre[a] - tr; wim[c] = wim[a] - ti;
+                    wre[a] += tr; wim[a] += ti;
+                }
+            }
+            exact_lds_sync();
+        }
+        if (have) {
+            const float *t = tw + twoff[lgh + 1];
+            const float w = wr ? wr[i] : 1.0f;
+            for (int k = l16; k < h; k += 16) {
+                float x0, x1;
+                if (k == 0) {
+                    x0 = wre[0] + wim[0];
+                    x1 = wre[0] - wim[0];
+                    if (wr) { x0 *= w; x1 *= (n == g.maxrin) ? w : 0.5f * w; }
+                } else {
+                    const int m = h - k;
+                    const float er = 0.5f * (wre[k] + wre[m]), ei = 0.5f * (wim[k] - wim[m]);
+                    const float orr = 0.5f * (wim[k] + wim[m]), oi = -0.5f * (wre[k] - wre[m]);
+                    const float c = t[2 * k], sn = t[2 * k + 1];
+                    x0 = er + orr * c - oi * sn;
+                    x1 = ei + orr * sn + oi * c;
+                    if (wr) { x0 *= w; x1 *= w; }
+                }
+                x[2 * k] = x0; x[2 * k + 1] = x1;
+            }
+        }
+        exact_lds_sync();
     }
 }
 
@@ -92,15 +116,7 @@ __global__ __launch_bounds__(64) void refspec_exact_kernel(DevGeom g, const int 
     const float c = (float)g.cnx;
     for (int i = lane; i < g.lcirc; i += 64) circ[i] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
     __syncthreads();
-    for (int i = lane; i < g.nring; i += 64) {
-        const int n = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
-        exact_rfft_fwd(circ + o, n, work + o, work + o + n / 2, tw, twoff);
-        const float w = wr[i];
-        circ[o] *= w;
-        if (n == g.maxrin) circ[o + 1] *= w;
-        else circ[o + 1] *= 0.5f * w;
-        for (int j = 2 + o; j < n + o; j++) circ[j] *= w;
-    }
+    exact_frngs(circ, work, g, numr, tw, twoff, lane, wr);          // Frngs, then Applyws on the way out of the split step
     __syncthreads();
     for (int i = lane; i < g.lcirc; i += 64) out[(size_t)r * g.lcirc + i] = circ[i];
 }
@@ -163,10 +179,7 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
         for (int i = lane; i < g.lcirc; i += 64) { float v = circ[i]; v -= avg; v /= sgm; circ[i] = v; }
     }
     __syncthreads();
-    for (int i = lane; i < g.nring; i += 64) {
-        const int n = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
-        exact_rfft_fwd(circ + o, n, work + o, work + o + n / 2, tw, twoff);
-    }
+    exact_frngs(circ, work, g, numr, tw, twoff, lane, nullptr);
     __syncthreads();
     // Crosrng_ms: q (straight) or t (mirrored) spectrum of the winner, f32 products, f64 sums over the rings in ring order
     const int N = g.maxrin;

@@ -22,12 +22,14 @@ from . import api, dist, geometry
 
 class MrefAligner:
     def __init__(self, particles, refs, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None, state_roundtrip=True):
+                 rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None, state_roundtrip=True, refine=None):
         """particles: [n][nx][nx] float32 numpy array or CUDA tensor holding THIS rank's shard;
         refs: [R][nx][nx]; index0 = global index of particles[0] (even/odd split).
         state_roundtrip: rebuild the shift every search starts from out of the float32 (alpha, sx, sy) of the previous
         iteration with inverse_transform2, as the reference's loop does (test_mref_gpu_align.py:1024-1026); False carries
-        the exact accumulated shift instead (algebraically the same; differs by rounding at edge-limited windows)."""
+        the exact accumulated shift instead (algebraically the same; differs by rounding at edge-limited windows).
+        refine: threshold of the sub-bin angle refinement (api.Engine.set_refine; None = the engine's default, -1 = every
+        particle: alpha / sx / sy then equal the CPU path's to the last bit wherever the integer winner agrees)."""
         self.state_roundtrip = bool(state_roundtrip)
         self._have_params = False
         self.dev = torch.device("cuda", device)
@@ -43,6 +45,8 @@ class MrefAligner:
         self.engine = api.Engine(self.nx, self.ou, self.xr, self.yr, self.ts, self.nref, api.RA_MODE_MREF,
                                  first_ring=ir, ring_skip=rs, device=device, chunk=chunk)
         self.engine.use_current_stream()
+        if refine is not None:
+            self.engine.set_refine(refine)
         if mask is None:        # "mask = model_circle(last_ring, nx, nx)" unless a mask file was given (:317-321)
             self.mask = torch.from_numpy(geometry.model_circle(self.ou, self.nx, self.nx)).to(self.dev)
         else:
@@ -194,7 +198,7 @@ class RefFreeAligner:
     The engine is sized once for the stage with the most search offsets and the widest range."""
 
     def __init__(self, particles, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
-                 preprocess=False, chunk=0, nomirror=False, mask=None):
+                 preprocess=False, chunk=0, nomirror=False, mask=None, refine=None):
         self.dev = torch.device("cuda", device)
         if isinstance(particles, np.ndarray):
             particles = torch.from_numpy(np.ascontiguousarray(particles, np.float32))
@@ -217,6 +221,8 @@ class RefFreeAligner:
         self.engine = api.Engine(self.nx, self.ou, rmax, rmax, cap_step, 1, api.RA_MODE_REFFREE, first_ring=ir, ring_skip=rs,
                                  device=device, chunk=chunk)
         self.engine.use_current_stream()
+        if refine is not None:
+            self.engine.set_refine(refine)
         self.stage = -1
         self.set_stage(0)
         if nomirror:
