@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_set_nomirror", "ra_set_mask",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_refine", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
-    "ra_fsc_len", "ra_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
+    "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load_library(path=None):
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.ra_fsc_len.argtypes = [vp]
     L.ra_class_fsc.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, float_ptr]
+    L.ra_last_class_fsc.argtypes = [vp, float_ptr]
     L.ra_fit_tanh.argtypes = [float_ptr, float_ptr, ctypes.c_int, float_ptr, float_ptr]
     L.ra_class_averages.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.ra_filter_references.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, float_ptr,
@@ -343,6 +344,13 @@ class Engine:
         _check(self.lib.ra_class_fsc(self.handle, self._ptr(sums, self.torch.float32), self._ptr(counts, self.torch.int32),
                                      int(min_count), int(bool(masked)), out.ctypes.data_as(float_ptr)), "ra_class_fsc")
         return [list(map(float, out[0])), list(map(float, out[1])), list(map(float, out[2]))]
+
+    def last_class_fsc(self):
+        """per-class curves of the last class_fsc call: (fsc [nref][len], points per shell [nref][len]) (ra_last_class_fsc)"""
+        n = self.lib.ra_fsc_len(self.handle)
+        out = np.zeros((self.nref, 2, n), np.float32)
+        _check(self.lib.ra_last_class_fsc(self.handle, out.ctypes.data_as(float_ptr)), "ra_last_class_fsc")
+        return out[:, 0], out[:, 1]
 
     def class_averages(self, sums, counts, refs, min_count=4):
         _check(self.lib.ra_class_averages(self.handle, self._ptr(sums, self.torch.float32),

@@ -140,8 +140,29 @@ def main_mref(argv=None):
     maxit = int(args.maxit) if int(args.maxit) > 0 else 10
     for it in range(maxit):
         counts = al.iterate(_user_func(args.function), int(args.center))
+        # members of every class (global particle numbers), as the reference gathers them every iteration (:504-515)
+        ids = al.params()["ref_id"].astype(np.int32)
+        if world > 1:
+            import torch.distributed as td
+            parts_ids = [None] * world
+            td.all_gather_object(parts_ids, ids)
+            ids = np.concatenate(parts_ids)
         if rank == 0:
-            stackio.write_stack(os.path.join(args.outdir, "aqm%03d.%s" % (it, args.ext)), al.refs.cpu().numpy())
+            members = [np.nonzero(ids == j)[0].astype(np.int32) for j in range(al.nref)]
+            if args.ext in ("hdf", "h5"):
+                from . import mdfio
+                mdfio.write_mdf_stack(os.path.join(args.outdir, "aqm%03d.%s" % (it, args.ext)), al.refs.cpu().numpy(),
+                                      [{"members": m if m.size else np.array([-1], np.int32), "n_objects": np.int32(m.size)} for m in members])
+            else:
+                stackio.write_stack(os.path.join(args.outdir, "aqm%03d.%s" % (it, args.ext)), al.refs.cpu().numpy())
+            if al.class_fsc_curves is not None:
+                # fsc(refi[j][0], refi[j][1], 1.0, "drm%03d%04d.txt") of every class that did not vanish (:533)
+                fsc_j, npt_j = al.class_fsc_curves
+                for j in range(al.nref):
+                    if counts[j] >= 4:
+                        n_sh = fsc_j.shape[1]
+                        stackio.write_text_rows(os.path.join(args.outdir, "drm%03d%04d.txt" % (it, j)),
+                                                [(i / (2.0 * (n_sh - 1)), float(fsc_j[j, i]), float(npt_j[j, i])) for i in range(n_sh)])
             if al.filter_params:
                 print("Tangent filter:  cut-off frequency = %10.3f        fall-off = %10.3f" % al.filter_params[-1])
             print("ITERATION #%3d" % (it + 1))
@@ -197,14 +218,32 @@ def main_reffree(argv=None):
                         total_nima=total, nomirror=args.nomirror, mask=mask)
     max_iter = 10 if int(args.maxit) == 0 else int(args.maxit)
     auto_stop = args.auto_stop and int(args.maxit) == 0
+    al.track_pixel_error = True
+    if rank == 0:
+        os.makedirs(args.outdir, exist_ok=True)
     a0, it = -1.0e22, 0
+    aqc, aqf = [], []
     for n_step in range(len(al.stages) if args.all_stages else 1):
         al.set_stage(n_step)
         for _ in range(max_iter):
             it += 1
+            raw = None
+            if rank == 0 and al.iteration > 0:
+                # aqc: the average of this iteration before the user function, (ave1 + ave2) / total_nima (:380-383)
+                raw = ((al.buf.sums[0, 0] + al.buf.sums[0, 1]) / float(al.total_nima)).cpu().numpy()
             a1 = al.iterate(int(args.center), _user_func(args.function))
             if rank == 0:
                 print("Iteration #%4d   X range = %5.2f   Y range = %5.2f   Step = %5.2f   Criterion = %15.8e" % ((it,) + al.stages[n_step] + (a1,)))
+                # aqc / aqf: one stack each, image number = iteration (tavg.write_image(".../aqc.hdf", total_iter - 1), :383, :420;
+                # aqc = the average before the user function, aqf = the filtered / centred average the particles are aligned to)
+                if raw is not None:
+                    aqc.append(raw)
+                    stackio.write_stack(os.path.join(args.outdir, "aqc.%s" % args.ext), np.stack(aqc))
+                aqf.append(al.tavg[0].cpu().numpy().copy())
+                stackio.write_stack(os.path.join(args.outdir, "aqf.%s" % args.ext), np.stack(aqf))
+                if al.pixel_errors:
+                    mc, pe = al.pixel_errors[-1]
+                    print("  mirror consistent = %d of %d (this rank), mean squared pixel error = %.4f" % (mc, al.n, pe / max(mc, 1)))
             if a1 < a0:
                 if auto_stop:
                     break

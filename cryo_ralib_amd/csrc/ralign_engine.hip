@@ -1327,6 +1327,18 @@ extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_coun
     return RA_OK;
 }
 
+// the per-class curves behind the last ra_class_fsc: h_all [nref][2][nx/2+1] = {fsc, points per shell} of every class (what
+// the reference writes to drm%03d%04d.txt, test_mref_gpu_align.py:533)
+extern "C" int ra_last_class_fsc(ra_engine *e, float *h_all)
+{
+    if (!e || !h_all) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (!e->d_rffsc) { g_last_error = "ra_class_fsc has not been called"; return RA_ERR_STATE; }
+    const size_t cnt = (size_t)e->cfg.nref * 2 * (e->geo.nx / 2 + 1);
+    RA_HIP(hipMemcpyAsync(h_all, e->d_rffsc, cnt * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    RA_HIP(hipStreamSynchronize(e->stream));
+    return RA_OK;
+}
+
 // sp_filter.fit_tanh(dres, low = 0.1) with sp_utilities.amoeba (simplex maximisation); host arithmetic in
 // double like the Python original.  fsc is edited in place (zeroed after its first drop below `low`).
 namespace {

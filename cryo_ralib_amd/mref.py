@@ -59,6 +59,7 @@ class MrefAligner:
         self.rng = random.Random(rand_seed)       # seed(rand_seed) on the main node (:352)
         self.class_sizes = []
         self.filter_params, self.fsc_curves, self.centres = [], [], []     # per iteration, user_func="ref_ali2d"
+        self.class_fsc_curves = None
         if preprocess:
             self._normalize_refs_all()
             self.engine.normalize_particles(self.particles)    # :342
@@ -109,6 +110,7 @@ class MrefAligner:
         fl = max(min(0.4, fl), 0.12)
         self.filter_params.append((fl, aa))
         self.fsc_curves.append(frsc)
+        self.class_fsc_curves = self.engine.last_class_fsc()       # per class: what the reference writes to drm%03d%04d.txt (:533)
         cs = self.engine.filter_references(self.refs, fl, aa, center=1 if center == 1 else 0, normalize=True)
         self.centres.append(cs)
 
@@ -244,6 +246,8 @@ class RefFreeAligner:
         self.iteration = 0
         self.criteria = []
         self.filter_params = []
+        self.track_pixel_error = False      # the drivers' per-iteration bookkeeping (mirror-consistent count, summed pixel error)
+        self.pixel_errors = []
 
     def set_stage(self, i):
         """search window of stage i: cu_module.reset_shifts(xrng[N_step], step[N_step]) (test_reffree_gpu_align.py:357)"""
@@ -292,6 +296,9 @@ class RefFreeAligner:
             # inside ra_align (fshift(tavg, -cs[0], -cs[1]), test_reffree_gpu_align.py:403-410)
             self.engine.filter_references(self.tavg, 0.0, 0.0, center=-1, cs_in=[cs], normalize=False)
         self.cs = cs
+        old = None
+        if self.track_pixel_error and self.iteration > 0:
+            old = self.result.clone()                       # old_ali_params (test_reffree_gpu_align.py:833-838)
         self.engine.set_references(self.tavg)
         # ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0), inverse_transform2 -> sxi, syi
         # (iteration 0: the header parameters are zero, the centre of the first average is not)
@@ -305,6 +312,14 @@ class RefFreeAligner:
         sx = r[:, 1].double()
         self.buf.extra_f[0] = torch.where(mir == 0, sx, -sx).sum().float()
         self.buf.extra_f[1] = r[:, 2].double().sum().float()
+        if old is not None:
+            # pixel_error / mirror_consistent of test_reffree_gpu_align.py:523-538 with sp_pixel_error.pixel_error_2D
+            # (sin((a1 - a2) / 2) (2 r + 1))^2 + (sx1 - sx2)^2 + (sy1 - sy2)^2 (formula from SPHIRE, not in the reference tree)
+            o = old.view(torch.float32)
+            same = old[:, 3] == mir
+            da = torch.deg2rad((o[:, 0] - r[:, 0]).double())
+            err = (torch.sin(da / 2) * (2 * self.ou + 1)) ** 2 + (o[:, 1] - r[:, 1]).double() ** 2 + (o[:, 2] - r[:, 2]).double() ** 2
+            self.pixel_errors.append((int(same.sum().item()), float(err[same].sum().item())))
         self.iteration += 1
         return a1
 

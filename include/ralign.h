@@ -220,6 +220,9 @@ int  ra_fsc_len(const ra_engine *e);
  * h_fsc [3][ra_fsc_len]: frequencies, fsc, points per shell (host). */
 int  ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked,
                   float *h_fsc);
+/* per-class curves of the last ra_class_fsc: h_all [nref][2][nx/2+1] = {fsc, points per shell} (the reference writes one
+ * drm%03d%04d.txt per class and iteration, test_mref_gpu_align.py:533) */
+int  ra_last_class_fsc(ra_engine *e, float *h_all);
 /* sp_filter.fit_tanh(dres, low=0.1): host arithmetic; fsc is edited in place like the original. */
 int  ra_fit_tanh(const float *freq, float *fsc, int n, float *fl, float *aa);
 /* (even + odd) / count without normalisation (:534-535); classes below min_count untouched */

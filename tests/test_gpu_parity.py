@@ -600,6 +600,16 @@ def test_command_line_entry_points(tmp_path):
     assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
                              "--center=0"]) == 0
     assert np.loadtxt(out2 / "initial2Dparams.txt").shape == (n, 4)
+    # per-iteration artefacts of the reference's drivers: aqc / aqf stacks (reference-free), FSC curves drm%03d%04d.txt and the
+    # members of every class in the aqm headers (multi-reference with the default user function)
+    assert stackio.read_stack(str(out2 / "aqf.hdf")).shape == (3, nx, nx) and stackio.read_stack(str(out2 / "aqc.hdf")).shape == (2, nx, nx)
+    drm = np.loadtxt(out1 / "drm0020001.txt")
+    assert drm.shape == (nx // 2 + 1, 3) and drm[0, 0] == 0.0 and abs(drm[-1, 0] - 0.5) < 1e-6 and np.abs(drm[:, 1]).max() <= 1.0 + 1e-5
+    from cryo_ralib_amd import mdfio as _m
+    _, hat = _m.read_mdf_stack(str(out1 / "aqm002.hdf"), with_attrs=True)
+    mem = np.concatenate([np.atleast_1d(hat[j]["EMAN.members"]) for j in range(nref)])
+    assert sorted(mem.tolist()) == list(range(n)) and sum(int(hat[j]["EMAN.n_objects"]) for j in range(nref)) == n
+    assert all((rows1[np.atleast_1d(hat[j]["EMAN.members"]), 5] == j).all() for j in range(nref))
     # an .hdf input stack: the parameters go into the headers of a COPY under outdir by default, into the stack itself
     # only with --header_writeback
     from cryo_ralib_amd import mdfio
