@@ -138,7 +138,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=12.0):
+def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=7.0):
     """the CPU restatement of the EMAN2 path (oracle/, kind "port") timed on this host's cores on a bounded sample
     of the same workload: all cores (OpenMP over particles), and one thread (what one EMAN2 MPI rank does)."""
     import numpy as np
@@ -163,7 +163,7 @@ def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=12.0):
     rate = n0 / run(parts, threads)
     n1 = int(max(n0, min(20000, rate * target_seconds)))
     big = np.concatenate([parts] * ((n1 + n0 - 1) // n0))[:n1]
-    runs = sorted(run(big, threads) for _ in range(1 if nx > 128 else 2))
+    runs = sorted(run(big, threads) for _ in range(1 if nx > 128 else 3))
     dt = runs[len(runs) // 2]
     n2 = int(max(4, min(n1, rate / threads * 6.0)))
     dt1 = run(big[:n2], 1)

@@ -716,6 +716,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)polar_generic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
     }
     if (he == hipSuccess && !e->xf_generic) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -1100,7 +1101,13 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
-        if (e->generic && gccf_wide_blocks(e->nrtile))
+        // RALIGN_GCCF_TM=2: 2 x 7 blocks (the B stream read once per 16 instead of 8 particle-offsets) -- measured 43.2 against
+        // 43.9 ms per chunk at 256 x 256 / 100 references: the kernel is not bound by the B stream (40 spilled registers)
+        if (e->generic && gccf_wide_blocks(e->nrtile) && getenv("RALIGN_GCCF_TM") && atoi(getenv("RALIGN_GCCF_TM")) == 2)
+            hipLaunchKernelGGL((ccf_generic_kernel<2, 7>), dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
+                               Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
+                               (const float *)e->d_gcdc);
+        else if (e->generic && gccf_wide_blocks(e->nrtile))
             hipLaunchKernelGGL((ccf_generic_kernel<1, 7>), dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);

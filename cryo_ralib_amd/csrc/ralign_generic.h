@@ -323,7 +323,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 // Block shapes (TM tiles of 8 particle-offsets x TR tiles of 8 references): 2 x 2 by default; 1 x 7 when the reference
 // tiles come in (nearly) whole sevens -- 13 tiles at 100 references: the A operands are read twice instead of seven times
 // (45.2 -> 44.2 ms per chunk).  The scratch holds the largest shape.
-#define RA_GCCF_ZPAIRS_MAX (64 * 7)
+#define RA_GCCF_ZPAIRS_MAX (64 * 14)
 inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 7 * 7 - nrtile <= 1; }
 template <int TM, int TR>
 __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
