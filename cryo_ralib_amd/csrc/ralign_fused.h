@@ -28,6 +28,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ralign_geom.h"
@@ -57,6 +58,7 @@ struct FusedGeom {
     int wmap[16];                  // contraction role of wave w: bin group | share of the reference pairs << 8 (balance_waves)
     int stat_wave[4];              // the wave that reduces the Normalize_ring partials of offset slot s
     int ntile, nh;                 // search_tiled_kernel (ralign_tiled.h): reference tiles per pass, reference pairs per tile
+    int ifft_full;                 // inverse-FFT slots 32 .. go to waves 8, 9, .. in FULL calls (4 transforms each) instead of half-filled ones
 };
 
 struct FusedPlanHost {
@@ -145,6 +147,9 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
         std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
         int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
         int light[4] = {0, 1, 2, 3};
+        // (counting the inverse-FFT calls of a SIMD's waves into its load before the deal -- 8 .. 19 units per call -- measured
+        // within noise, more than that slower)
+        f.ifft_full = (getenv("RALIGN_IFFT_FULL") && atoi(getenv("RALIGN_IFFT_FULL")) == 0) ? 0 : 1;
         for (const Item &it : items) {
             int c = -1;
             for (int q = 0; q < 4; q++)
@@ -635,7 +640,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         auto ifft_round = [&](int ref_lo, int nrz) {
             // lane groups (sub, sub ^ 1) of a half-wave take spectrum slots zs and zs + 16: their LDS images are 32 banks apart
             const int j = ln & 15, sub = ln >> 4, uu = 2 * wave + (sub >> 1);
-            const int zs = (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
+            // slots 32 .. 4 rz - 1: two per wave 8 - 15 (half-filled calls, 32 banks apart), or -- ifft_full, the default -- four per
+            // wave 8, 9, .. (full calls with 2-way bank conflicts on their 35 LDS instructions: two calls of 309 vector instructions
+            // less per pass at 10 references; the phase is bound by instruction issue, not by the LDS: 4.45 -> 4.40 ms)
+            const int zs = (wave >= 8 && f.ifft_full) ? 32 + 4 * (wave - 8) + sub : (uu & 15) + 16 * (sub & 1) + 32 * (uu >> 4);
             const int o = __mul24(zs, f.rz_inv) >> 16, rr = zs - __mul24(o, f.rz);      // zs / rz, zs % rz (zs < 64, rz <= 16: exact)
             if (zs < 4 * f.rz && rr < nrz && o < nlive && !RA_DBG(g, 1))      // uniform over the 16-lane group
                 ifft_argmax<N, 1, 0>(bufs, pc + (o * nref + ref_lo + rr) - zs, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
