@@ -60,7 +60,7 @@ struct ra_engine {
     float *d_cs = nullptr;              // [2]
     float *d_alscratch = nullptr;       // [chunk][nx*nx] aligned images of one chunk (deterministic class sums)
     // sub-bin angle refinement with the CPU path's arithmetic (ralign_exact.h)
-    float refine_thr = 0.03f;           // flag |c3| < thr x max |b|; < 0: every particle; 0: off
+    float refine_thr = 0.02f;           // flag |c3| < thr x max |b|; < 0: every particle; 0: off
     bool refine_ok = false;             // tables built and the kernels' LDS (2 lcirc floats) fits
     size_t lds_refine = 0;
     float *d_twx = nullptr, *d_refx = nullptr, *d_cls_refx = nullptr;

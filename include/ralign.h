@@ -172,7 +172,7 @@ int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
  * second difference c3 amplifies the f32-vs-f64 difference of the 7 CCF samples around a FLAT peak into degrees.  Particles
  * whose |c3| < threshold x max |b| get their 7 samples re-evaluated with the CPU path's own arithmetic (bilinear samples,
  * fftr_q's radix-2 ring FFTs in f32, f64 accumulation of the ring products, f64 inverse) and alpha / sx / sy rewritten.
- * threshold < 0: every particle (+25 % of a headline iteration); 0: off; default 0.03 -- no measurable cost, no particle
+ * threshold < 0: every particle (+25 % of a headline iteration); 0: off; default 0.02 -- no measurable cost, no particle
  * beyond 2e-3 degrees of the CPU path on any tested workload (environment RALIGN_REFINE overrides the default).  Call before
  * ra_set_references.  RA_ERR_STATE when the geometry's rings exceed the LDS (large boxes: not refined). */
 int  ra_set_refine(ra_engine *e, float threshold);
