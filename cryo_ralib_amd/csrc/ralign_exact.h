@@ -8,7 +8,7 @@
 // turns the 1e-6 relative difference between an f32 and an f64 neighbourhood into degrees.
 //
 // refine_winner_kernel recomputes that neighbourhood for ONE (offset, reference, mirror) per particle with the CPU
-// path's own arithmetic (oracle/ralign_oracle.c restates the same routines):
+// path's own arithmetic:
 //   Polar2Dm   bilinear samples in Util::bilinear's operation order (bit-identical positions and values)
 //   Normalize_ring (multi-reference mode)  (v - avg) / sigma per sample in f32; avg and sigma from f64 sums -- a uniform
 //              shift / scale cancels in prb1d (both coefficient sets sum to zero, pos is a ratio), only the rounding of the
@@ -30,7 +30,7 @@
 
 namespace ralign {
 
-// Frngs with fftr_q's arithmetic (rfft_fwd_f / cfft_f of oracle/ralign_oracle.c: radix-2, bit-reversal first, table
+// Frngs with fftr_q's arithmetic (radix-2, bit-reversal first, table
 // twiddles, split step), every ring in place in `circ`, `work` = lcirc floats of scratch.  The butterflies of one stage
 // are independent of each other, so they are dealt to the lanes without changing a single operation: each of the four
 // 16-lane groups of the wave transforms one ring at a time (rings dealt longest first, round robin), one butterfly per
