@@ -1501,3 +1501,42 @@ def test_tiled_kernel_equals_fused_kernel_at_ten_references(monkeypatch):
         same &= a[fld] == b[fld]
     assert (~same).sum() <= 2 and (rel[~same] < TIE_RTOL).all()
     np.testing.assert_array_equal(sa[same], sb[same])
+
+
+def test_tiled_kernel_in_the_iteration_loop():
+    """three iterations of the host driver at nref = 24 (three reference tiles of 8 per pass, search_tiled_kernel) beside the
+    oracle loop: state round trip, class sums, reference update; every particle refined, so alpha is the oracle's bit for bit"""
+    nx, ou, nref, xr, n = 90, 36, 24, 3, 240
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5)
+    al = MrefAligner(parts, refs, ou, xr, xr, 1.0, preprocess=True, refine=-1)
+    assert al.engine.search_path == 1
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    cur = np.stack([orc.normalize_mask(r, mask, 1) for r in refs])
+    op = np.stack([orc.normalize_mask(p, mask, 0) for p in parts])
+    d = np.zeros((n, 2), np.float32)
+    prev = None
+    for it in range(3):
+        params, infos, sums, counts, d = _oracle_mref_loop_step(op, cur, rg, mask, xr, prev, d, True)
+        got_counts = al.iterate()
+        r = al.params()
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02)
+        _log_flips("tiled loop nref=24 it=%d" % it, n, flips)
+        if flips:
+            prev = np.zeros((n, 6), np.float32)
+            prev[:, 0] = r["alpha"]; prev[:, 1] = r["sx"]; prev[:, 2] = r["sy"]; prev[:, 3] = r["mirror"]
+            d = al.state.cpu().numpy().copy()
+            cur = al.refs.cpu().numpy().copy()
+            continue
+        prev = params
+        np.testing.assert_array_equal(got_counts, counts)
+        np.testing.assert_array_equal(r["alpha"], params[:, 0])
+        live = counts >= 4
+        cur = np.stack([orc.normalize_mask((sums[j, 0] + sums[j, 1]) * np.float32(1.0 / float(max(counts[j], 1))), mask, 1)
+                        if live[j] else cur[j] for j in range(nref)])
+        if live.all():
+            np.testing.assert_allclose(al.refs.cpu().numpy(), cur, rtol=0, atol=3e-6 * np.abs(cur).max())
+        else:
+            break          # a vanished class is re-seeded from the driver's RNG: covered by test_vanished_class_is_reseeded...
+    al.close()
