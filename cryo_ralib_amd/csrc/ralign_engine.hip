@@ -66,6 +66,7 @@ struct ra_engine {
     float *d_twx = nullptr, *d_refx = nullptr, *d_cls_refx = nullptr;
     int *d_twxoff = nullptr, *d_rcount = nullptr;
     RefineRec *d_rlist = nullptr;
+    int *d_members = nullptr, *d_mcount = nullptr;      // [2 nref][chunk] member lists of a chunk, [2 nref] their lengths (class_members_kernel)
     float *d_sumpart = nullptr;         // [16][2 nref][nx*nx] per-run partial class sums (few classes: class_sum_kernel with runs)
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
@@ -1165,7 +1166,7 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
             hipLaunchKernelGGL(transform_generic_kernel, dim3(n, 8), dim3(256), 0, e->stream, nx, d_particles, n, index0,
                                d_result, d_aligned, d_sums, d_counts);
         else
-            hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(256), e->lds_xf, e->stream, nx, d_particles, n, index0,
+            hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(RA_XF_THREADS), e->lds_xf, e->stream, nx, d_particles, n, index0,
                                d_result, d_aligned, d_sums, d_counts);
         RA_HIP(hipGetLastError());
         return RA_OK;
@@ -1178,18 +1179,30 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
             hipLaunchKernelGGL(transform_generic_kernel, dim3(cn, 8), dim3(256), 0, e->stream, nx, d_particles + (size_t)start * npix,
                                cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
         else
-            hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(256), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
+            hipLaunchKernelGGL(transform_kernel, dim3(cn), dim3(RA_XF_THREADS), e->lds_xf, e->stream, nx, d_particles + (size_t)start * npix,
                                cn, index0 + start, d_result + start, al, (float *)nullptr, (int *)nullptr);
         RA_HIP(hipGetLastError());
-        // few classes: cut every (class, parity) member list into runs so that ~1000 workgroups share the additions
+        // member lists once per chunk (class_members_kernel); every (class, parity) list is then cut into runs so that ~4000
+        // workgroups share the additions
         const int nseg = 2 * e->cfg.nref, ntile = (npix + 255) / 256;
-        const int nrun = std::min(16, std::max(1, 1024 / (nseg * ntile)));
+        const bool glists = (size_t)nseg * e->chunk * sizeof(int) <= ((size_t)256 << 20);
+        if (glists && !e->d_members) {
+            int rcm = dev_alloc(e, &e->d_members, (size_t)nseg * e->chunk, false);
+            if (!rcm) rcm = dev_alloc(e, &e->d_mcount, (size_t)nseg, true);
+            if (rcm) return rcm;
+        }
+        const int nrun = std::min(16, std::max(1, (glists ? 4096 : 1024) / (nseg * ntile)));
         if (nrun > 1 && !e->d_sumpart) {
             int rcp = dev_alloc(e, &e->d_sumpart, (size_t)16 * nseg * npix, false);
             if (rcp) return rcp;
         }
-        hipLaunchKernelGGL(class_sum_kernel, dim3(nseg, ntile, nrun), dim3(256), (size_t)cn * sizeof(int), e->stream, npix, al,
-                           d_result + start, cn, index0 + start, d_sums, d_counts, nrun > 1 ? e->d_sumpart : (float *)nullptr);
+        if (glists) {
+            hipLaunchKernelGGL(class_members_kernel, dim3(nseg), dim3(64), 0, e->stream, d_result + start, cn, index0 + start, e->d_members, e->d_mcount);
+            RA_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(class_sum_kernel, dim3(nseg, ntile, nrun), dim3(256), glists ? 0 : (size_t)cn * sizeof(int), e->stream, npix, al,
+                           d_result + start, cn, index0 + start, d_sums, d_counts, nrun > 1 ? e->d_sumpart : (float *)nullptr,
+                           glists ? (const int *)e->d_members : (const int *)nullptr, (const int *)e->d_mcount);
         RA_HIP(hipGetLastError());
         if (nrun > 1) {
             hipLaunchKernelGGL(class_sum_combine_kernel, dim3((unsigned)(((size_t)nseg * npix + 255) / 256)), dim3(256), 0, e->stream, npix, nseg, nrun,

@@ -1233,7 +1233,10 @@ __device__ __forceinline__ float quadri_background_1b(const float *fdata, int nx
     return f0 + dx0 * (c1 + dxb * c2 + dy0 * c5) + dy0 * (c3 + dyb * c4);
 }
 
-__global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__restrict__ particles, int n,
+// 512 threads per particle: the image fills a quarter of the LDS, so four workgroups share a CU -- with 256 threads that is four
+// waves per SIMD for a kernel paced by its chain of address -> six LDS taps -> interpolate (243 -> 200 us per 7143 particles)
+#define RA_XF_THREADS 512
+__global__ __launch_bounds__(RA_XF_THREADS) void transform_kernel(int nx, const float *__restrict__ particles, int n,
                                                         int index0, const ra_result *__restrict__ res,
                                                         float *__restrict__ aligned, float *__restrict__ sums,
                                                         int *__restrict__ counts)
@@ -1288,30 +1291,57 @@ __global__ __launch_bounds__(256) void transform_kernel(int nx, const float *__r
 // list is then cut into gridDim.z contiguous runs (`partial` != null): workgroup z adds its run in particle order into
 // partial[z][class, parity][pixel], and class_sum_combine_kernel adds the runs to the sums in run order -- a fixed
 // association ((sums + run0) + run1) + ..., bitwise reproducible run to run like the single-run case.
+// member lists of a chunk, once per chunk instead of once per workgroup of class_sum_kernel: segment = (class, parity),
+// one wave per segment compacts the particle indices in particle order (ballot + prefix count keeps the order)
+__global__ __launch_bounds__(64) void class_members_kernel(const ra_result *__restrict__ res, int n, int index0,
+                                                           int *__restrict__ members, int *__restrict__ mcount)
+{
+    const int seg = blockIdx.x, cls = seg >> 1, par = seg & 1, lane = threadIdx.x;
+    int *mem = members + (size_t)seg * n;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool mine = i < n && res[i].ref_id == cls && ((index0 + i) & 1) == par;
+        const unsigned long long m = __ballot(mine);
+        if (mine) mem[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        base += __popcll(m);
+    }
+    if (lane == 0) mcount[seg] = base;
+}
+
+// gmembers / gcount: the lists of class_members_kernel ([segments][n], [segments]); null: every workgroup compacts its own
+// list into LDS (segment counts too large for the list buffer)
 __global__ __launch_bounds__(256) void class_sum_kernel(int npix, const float *__restrict__ aligned,
                                                         const ra_result *__restrict__ res, int n, int index0,
                                                         float *__restrict__ sums, int *__restrict__ counts,
-                                                        float *__restrict__ partial)
+                                                        float *__restrict__ partial, const int *__restrict__ gmembers,
+                                                        const int *__restrict__ gcount)
 {
-    extern __shared__ int members[];          // [n] particle indices of this (class, parity), ascending
+    extern __shared__ int lmembers[];         // [n] particle indices of this (class, parity), ascending (gmembers == null only)
     __shared__ int nmem;
     const int seg = blockIdx.x, cls = seg >> 1, par = seg & 1;
     const int pix = blockIdx.y * blockDim.x + threadIdx.x;
     const bool live = pix < npix;
-    // wave 0 compacts the member list in particle order (ballot + prefix count keeps the order)
-    if (threadIdx.x < 64) {
-        int base = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + threadIdx.x;
-            const bool mine = i < n && res[i].ref_id == cls && ((index0 + i) & 1) == par;
-            const unsigned long long m = __ballot(mine);
-            if (mine) members[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = i;
-            base += __popcll(m);
+    const int *members = gmembers ? gmembers + (size_t)seg * n : lmembers;
+    int cnt;
+    if (gmembers) {
+        cnt = gcount[seg];
+    } else {
+        // wave 0 compacts the member list in particle order (ballot + prefix count keeps the order)
+        if (threadIdx.x < 64) {
+            int base = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + threadIdx.x;
+                const bool mine = i < n && res[i].ref_id == cls && ((index0 + i) & 1) == par;
+                const unsigned long long m = __ballot(mine);
+                if (mine) lmembers[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = i;
+                base += __popcll(m);
+            }
+            if (threadIdx.x == 0) nmem = base;
         }
-        if (threadIdx.x == 0) nmem = base;
+        __syncthreads();
+        cnt = nmem;
     }
-    __syncthreads();
-    const int cnt = nmem;
     const int nrun = gridDim.z, run = blockIdx.z;
     const int j0 = (int)((long long)cnt * run / nrun), j1 = (int)((long long)cnt * (run + 1) / nrun);
     if (live) {
