@@ -248,10 +248,21 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
                     const float wt = g.ringw[i];
                     float *xr = reinterpret_cast<float *>(bx);
                     float a = 0.f, q = 0.f;
-                    for (int j = lane; j < nlen; j += 64) {
-                        const float sv = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
-                        xr[j] = sv;
-                        a += sv * wt; q += sv * sv * wt;
+                    // four samples per trip: their 16 image taps (L2) are in flight together; the Normalize_ring partial
+                    // sums keep their order
+                    for (int j0 = lane; j0 < nlen; j0 += 256) {
+                        float sv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int j = min(j0 + 64 * u, nlen - 1);
+                            sv[u] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (j0 + 64 * u < nlen) {
+                                xr[j0 + 64 * u] = sv[u];
+                                a += sv[u] * wt; q += sv[u] * sv[u] * wt;
+                            }
                     }
                     av += a; sq += q;          // per-lane partial sums over the rings, reduced once below
                     wave_lds_sync();
