@@ -164,11 +164,20 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
     const float *img = particles + (size_t)rec.p * g.nx * g.nx;
     const float cx = ((float)g.cnx + rec.sxi) + g.shift_x[rec.bs], cy = ((float)g.cnx + rec.syi) + g.shift_y[rec.bs];
     double av = 0.0, sq = 0.0;
-    for (int i = lane; i < g.lcirc; i += 64) {
-        const float v = bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
-        circ[i] = v;
-        const float w = g.samp_w[i];
-        av += (double)(v * w); sq += (double)(v * v * w);
+    for (int i0 = lane; i0 < g.lcirc; i0 += 256) {          // four samples per trip: their 16 image taps are in flight together
+        float v[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 64 * u, g.lcirc - 1);
+            v[u] = bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
+            w[u] = g.samp_w[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + 64 * u < g.lcirc) {
+                circ[i0 + 64 * u] = v[u];
+                av += (double)(v[u] * w[u]); sq += (double)(v[u] * v[u] * w[u]);
+            }
     }
     if (g.mode == RA_MODE_MREF) {
         av = wave_sum_f64(av); sq = wave_sum_f64(sq);
@@ -188,19 +197,35 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
     const bool mir = rec.mirror != 0;
     for (int j = 2 * lane; j < N; j += 128) {
         double s0 = 0.0, s1 = 0.0;
-        for (int i = 0; i < g.nring; i++) {
-            const int n = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
-            const float *c = c1 + o, *d = circ + o;
-            if (j == 0) {
-                s0 += (double)(c[0] * d[0]);
-                if (n == N) s1 += (double)(c[1] * d[1]);
-            } else if (j < n) {
-                const float a1 = c[j], a2 = c[j + 1], d1 = d[j], d2 = d[j + 1];
-                const float p1 = a1 * d1, p2 = a2 * d2, p3 = a1 * d2, p4 = a2 * d1;
-                if (mir) { s0 += (double)(p1 - p2); s1 += (double)(-p3 - p4); }
-                else { s0 += (double)(p1 + p2); s1 += (double)(-p3 + p4); }
-            } else if (j == n) {
-                s0 += (double)(c[1] * d[1]);          // Nyquist coefficient of a ring shorter than maxrin: real, at index n
+        if (j == 0) {
+            for (int i = 0; i < g.nring; i++) {
+                const int n = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
+                s0 += (double)(c1[o] * circ[o]);
+                if (n == N) s1 += (double)(c1[o + 1] * circ[o + 1]);
+            }
+        } else {
+            // rings are sorted by length: those of length j contribute their (real) Nyquist coefficient at index j, the longer
+            // ones a regular complex product -- in ring order, four rings' operands in flight
+            int i = 0;
+            while (i < g.nring && numr[3 * i + 2] < j) i++;
+            for (; i < g.nring && numr[3 * i + 2] == j; i++) {
+                const int o = numr[3 * i + 1] - 1;
+                s0 += (double)(c1[o + 1] * circ[o + 1]);
+            }
+            for (; i < g.nring; i += 4) {
+                float a1[4], a2[4], d1[4], d2[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int o = numr[3 * min(i + u, g.nring - 1) + 1] - 1;
+                    a1[u] = c1[o + j]; a2[u] = c1[o + j + 1]; d1[u] = circ[o + j]; d2[u] = circ[o + j + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i + u < g.nring) {
+                        const float p1 = a1[u] * d1[u], p2 = a2[u] * d2[u], p3 = a1[u] * d2[u], p4 = a2[u] * d1[u];
+                        if (mir) { s0 += (double)(p1 - p2); s1 += (double)(-p3 - p4); }
+                        else { s0 += (double)(p1 + p2); s1 += (double)(-p3 + p4); }
+                    }
             }
         }
         spec[j] = s0; spec[j + 1] = s1;
