@@ -255,7 +255,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const int j = min(j0 + 64 * u, nlen - 1);
-                            sv[u] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+                            sv[u] = RA_DBG(g, 512) ? (float)j : bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
                     }
                     av += a; sq += q;          // per-lane partial sums over the rings, reduced once below
                     wave_lds_sync();
-                    const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
+                    const float2 *Z = (h >= 2 && !RA_DBG(g, 256)) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
                         const int k = lane + 64 * t;

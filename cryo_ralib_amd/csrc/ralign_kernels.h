@@ -137,6 +137,8 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
     // and out-of-window offsets (masked later) may leave it altogether: clamp every tap
     const int x0 = min(max(ix, 1), nx) - 1, x1 = min(x0 + 1, nx - 1);
     const int y0 = min(max(iy, 1), nx) - 1, y1 = min(y0 + 1, nx - 1);
+    // (the two taps of a row as one 4-byte-aligned 8-byte load: measured SLOWER, 15.7 -> 18.9 ms per chunk of the generic polar
+    // stage, whose time is 57 % sampling)
     float f00 = img[y0 * nx + x0], f10 = img[y0 * nx + x1], f01 = img[y1 * nx + x0], f11 = img[y1 * nx + x1];
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
