@@ -310,11 +310,16 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
                 // row offsets (bytes) of the tile's reference pairs in the wave's group block, moved back by the slots the
                 // wave pads; a pair past the last one (final tile) re-reads the last pair's rows and is never stored
                 unsigned row[NH];
+                const int ns = nq <= 4 ? 4 : nq <= 7 ? 7 : nq == 8 ? 8 : RT_NQ;      // slots of the instantiation that runs (slice right-aligned in them)
 #pragma unroll
                 for (int h = 0; h < NH; h++)
-                    row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)(((nq > 4 ? RT_NQ : 4) - nq) * 1024);
-                if (nq > 4) rt_contract<NH, RT_NQ>(a, brsrc, (unsigned)ln * 16u, row, acc);
-                else rt_contract<NH, 4>(a, brsrc, (unsigned)ln * 16u, row, acc);
+                    row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)((ns - nq) * 1024);
+                switch (ns) {          // straight-line instantiations for the ring-quad counts of the headline geometry (9, 8, 7, 4)
+                case 4: rt_contract<NH, 4>(a, brsrc, (unsigned)ln * 16u, row, acc); break;
+                case 7: rt_contract<NH, 7>(a, brsrc, (unsigned)ln * 16u, row, acc); break;
+                case 8: rt_contract<NH, 8>(a, brsrc, (unsigned)ln * 16u, row, acc); break;
+                default: rt_contract<NH, RT_NQ>(a, brsrc, (unsigned)ln * 16u, row, acc); break;
+                }
             } else {
 #pragma unroll
                 for (int h = 0; h < NH; h++) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
