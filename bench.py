@@ -311,6 +311,7 @@ def main():
     dt = rdist.max_over_ranks(dt, dev)
     ms_a, n_a, ms_b, n_b = al.engine.kernel_time(False)
     path = al.engine.search_path
+    tiled = al.engine.search_tiled
 
     if rank == 0:
         total = n * world * args.steps
@@ -318,9 +319,9 @@ def main():
         per_launch = n * args.steps / max(n_a, 1)
         kernels = {}
         if path == 1:
-            kernels[("search_tiled_kernel<%d>" if nref > 16 else "search_fused_kernel<%d>") % M] = {
+            kernels[("search_tiled_kernel<%d>" if tiled else "search_fused_kernel<%d>") % M] = {
                 "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + inverse FFT + argmax, "
-                        "particle-resident" + (", reference tiles of 10 with the A operand in registers" if nref > 16 else ""), "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
+                        "particle-resident" + (", reference tiles of <= 10 with the A operand in registers" if tiled else ""), "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
         else:
             nm = ("ccf_generic_kernel", "polar_generic_kernel") if path == 2 else ("ccf_kernel<%d>" % M, "polar_fft_kernel")
             kernels[nm[0]] = {"what": "Crosrng_ms contraction (16x16x4 MFMA) + inverse FFT + argmax", "avg_launch_ms": ms_a / max(n_a, 1),

@@ -138,7 +138,8 @@ static bool tiled_wanted(const ra_engine *e)
     // search_tiled_kernel: more references than one pass of search_fused_kernel accumulates (RALIGN_TILED=1 forces it for fewer)
     const bool force = getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) != 0;
     if (getenv("RALIGN_TILED") && !force) return false;
-    return (e->cfg.nref > RF_MAXREF || force) && e->geo.maxrin == 256 && e->geo.nring <= 4 * RT_NQ && e->cfg.nref <= 127;
+    // (from 15 references on: search_fused_kernel needs two spectra rounds per pass from 12 on and is 4 % slower at 15 and 16)
+    return (e->cfg.nref >= RT_MINREF || force) && e->geo.maxrin == 256 && e->geo.nring <= 4 * RT_NQ && e->cfg.nref <= 127;
 }
 
 static bool fused_wanted(const ra_engine *e)
@@ -408,7 +409,7 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
 static bool resident_expected(const Geometry &g, const ra_config &cfg, bool generic, size_t *b_floats)
 {
     if (generic || (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0)) return false;
-    const bool tiled = cfg.nref > RF_MAXREF && g.maxrin == 256 && g.nring <= 4 * RT_NQ && cfg.nref <= 127 &&
+    const bool tiled = cfg.nref >= RT_MINREF && g.maxrin == 256 && g.nring <= 4 * RT_NQ && cfg.nref <= 127 &&
                        !(getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) == 0);
     if (!tiled && (cfg.nref > RF_MAXREF || !(g.maxrin == 256 || g.maxrin == 128))) return false;
     if (g.numr[2] < 8 || g.nring > 64) return false;
@@ -799,6 +800,7 @@ extern "C" int ra_set_refine(ra_engine *e, float threshold)
     e->refs_ready = false;             // the exact reference spectra are prepared by ra_set_references when the refinement is on
     return e->refine_ok || threshold == 0.f ? RA_OK : RA_ERR_STATE;
 }
+extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }

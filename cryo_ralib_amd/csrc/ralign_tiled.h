@@ -27,6 +27,8 @@ namespace ralign {
 
 constexpr int RT_MAXNH = 5;        // reference pairs per tile (4 offsets x 10 references = 40 of the 47 spectrum slots)
 constexpr int RT_NQ = 9;           // ring quads of a wave's A slice (<= 36 rings)
+constexpr int RT_MINREF = 15;      // from here on the tiled kernel beats search_fused_kernel's two spectra rounds per pass (measured: 12 - 14
+                                   // references 2 % slower, 15 and 16 4 % faster)
 
 inline bool build_tiled_plan(const Geometry &g, int nref, int sbuf, size_t lds_polar_floats, FusedPlanHost &out)
 {

@@ -144,6 +144,8 @@ int  ra_lcirc(const ra_engine *e);
 /* which kernels ra_align runs for the current geometry and window: 1 = particle-resident fused search kernel,
  * 0 = polar + contraction kernel pair, 2 = size-generic kernels (large boxes) */
 int  ra_search_path(const ra_engine *e);
+/* 1 when the particle-resident path is search_tiled_kernel (reference tiles: 15 and more references), 0 otherwise */
+int  ra_search_tiled(const ra_engine *e);
 /* change the search window without re-allocating (reset_shifts analogue); the number of
  * offsets may not grow beyond what ra_create sized */
 int  ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step);
