@@ -7,7 +7,9 @@ reference update (test_mref_gpu_align.py:408-575; test_reffree_gpu_align.py:361-
 Particles are already resident in HBM when the timed region starts.  For N>1 every rank holds its own shard (weak
 scaling) and the only collective is the RCCL all-reduce of the class sums.
 
-    python bench.py --gpus 1 --steps 6 --warmup 1                       # BASELINE configs[1] (the metric's config)
+    python bench.py --gpus 1 --steps 6 --warmup 1                       # BASELINE configs[1] (the metric's config); at one GPU
+                                                                        # the line also carries short runs of the three workloads
+                                                                        # below under "other_workloads" (--no-others: headline only)
     python bench.py --workload reffree                                  # BASELINE configs[2]
     python bench.py --workload largebox                                 # BASELINE configs[4] geometry, one GPU's share
     python bench.py --workload mref50                                   # BASELINE configs[3], one GPU's share (125k particles, nref=50)
@@ -58,9 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="headline workload only (the default run appends short runs of "
+                    "reffree, mref50 and largebox under \"other_workloads\")")
     args = ap.parse_args(argv)
     cfg, nx, ou, xr, nref, n, steps, warm = WORKLOADS[args.workload]
     args.config_name = cfg
+    args.custom_geometry = any(v is not None for v in (args.particles, args.nref, args.nx, args.ou, args.xr)) or args.chunk != 0
     args.nx = args.nx or nx; args.ou = args.ou or ou; args.xr = xr if args.xr is None else args.xr
     args.nref = args.nref or nref; args.particles = args.particles or n
     args.steps = steps if args.steps is None else args.steps
@@ -254,25 +259,13 @@ def committed_traffic(kernel_substr, workload, geometry=None):
     return None, None
 
 
-def main():
-    args = parse_args()
-    world_env = os.environ.get("WORLD_SIZE")
-    if world_env is None and args.gpus > 1:
-        sys.exit(relaunch_under_launcher(args))
-    if world_env is not None and int(world_env) != args.gpus:
-        sys.exit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, world_env))
-
+def run_workload(args, rank, local, world, dev):
+    """one workload: generate the shard, warm up, time `args.steps` steps; returns the JSON line (rank 0) or None"""
     import numpy as np
     import torch
     from cryo_ralib_amd import api, dist as rdist, synth
     from cryo_ralib_amd.mref import MrefAligner, RefFreeAligner
 
-    rank, local, world = rdist.init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the alignment engine has no CPU path")
-    local = local % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     nx, ou, xr, nref, n = args.nx, args.ou, args.xr, args.nref, args.particles
     reffree = args.workload == "reffree"
     user_func = None if args.function in ("none", "None", "") else args.function
@@ -376,8 +369,50 @@ def main():
             line["parity"] = parity_block(refs_np, nx, ou, xr, nref, reffree, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(refs_np, nx, ou, xr, xr, nref, reffree)
-        print(json.dumps(line))
     al.close()
+    del al, particles
+    torch.cuda.empty_cache()
+    return line if rank == 0 else None
+
+
+# what the default run adds to the headline line: the other BASELINE configs at one GPU's share, a few steps each
+OTHER_WORKLOADS = ("reffree", "mref50", "largebox")
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(relaunch_under_launcher(args))
+    if world_env is not None and int(world_env) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, world_env))
+
+    import torch
+    from cryo_ralib_amd import dist as rdist
+
+    rank, local, world = rdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the alignment engine has no CPU path")
+    local = local % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    line = run_workload(args, rank, local, world, dev)
+    if world == 1 and args.workload == "mref" and not args.no_others and not args.custom_geometry:
+        # the other workloads, measured in the same process right after the headline (short runs, their own parity block, no
+        # CPU baseline); the headline keys above are untouched
+        others = {}
+        for w in OTHER_WORKLOADS:
+            sub = parse_args(["--workload", w, "--no-cpu-baseline", "--no-pcie", "--sigma", str(args.sigma)] +
+                             (["--no-parity"] if args.no_parity else []))
+            t0 = time.perf_counter()
+            o = run_workload(sub, rank, local, world, dev)
+            o = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "parity") if k in o}
+            o["roofline"] = {k: v for k, v in o["roofline"].items() if k != "kernels"}
+            o["wall_s"] = time.perf_counter() - t0
+            others[w] = o
+        line["other_workloads"] = others
+    if rank == 0:
+        print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
 
