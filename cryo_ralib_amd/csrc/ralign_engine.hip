@@ -68,6 +68,11 @@ struct ra_engine {
     RefineRec *d_rlist = nullptr;
     int *d_members = nullptr, *d_mcount = nullptr;      // [2 nref][chunk] member lists of a chunk, [2 nref] their lengths (class_members_kernel)
     float *d_sumpart = nullptr;         // [16][2 nref][nx*nx] per-run partial class sums (few classes: class_sum_kernel with runs)
+    // transform_sum_kernel (rot_shift2D + class sums in one pass): member lists of a whole batch and per-run partial sums
+    int *d_xs_members = nullptr, *d_xs_mcount = nullptr;
+    float *d_xs_partial = nullptr;
+    float2 *d_xs_trig = nullptr;
+    size_t xs_cap_members = 0, xs_cap_partial = 0, xs_cap_trig = 0;
     bool atomic_sums = false;           // RALIGN_ATOMIC_SUMS=1: fp32 atomics instead of particle-order sums
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
@@ -96,7 +101,8 @@ struct ra_engine {
     float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
     size_t f_cap_b = 0;
-    CandT *d_fcand = nullptr;           // [(chunk * nshift_pad + 8)][nzr]
+    CandT *d_fcand = nullptr;           // [(fcand_cap * nshift_pad + 8)] one record per particle-offset of a resident-kernel launch
+    int fcand_cap = 0, rlist_cap = 0;   // particles the candidate records / the refine list hold (grown on demand: ensure_resident_ws)
     int n_cu = 256;
     bool unfused_ws = false;            // spectra workspace of the two-kernel path allocated
     WorkspacePlan wp{};
@@ -402,6 +408,19 @@ template <typename T> static int dev_alloc(ra_engine *e, T **p, size_t count, bo
     return RA_OK;
 }
 
+// replace a device buffer by a larger one (the old one is released now, not at destroy)
+template <typename T> static int dev_grow(ra_engine *e, T **p, size_t count, bool zero)
+{
+    if (*p) {
+        auto it = std::find(e->owned.begin(), e->owned.end(), (void *)*p);
+        if (it != e->owned.end()) e->owned.erase(it);
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    return dev_alloc(e, p, count, zero);
+}
+
 // Will ra_create select a particle-resident kernel (search_fused_kernel / search_tiled_kernel) for this geometry?  The same
 // conditions as fused_wanted / tiled_wanted and the LDS estimate of build_device_geometry, evaluated without an engine, so
 // that the size checks charge what that path allocates (candidate records, the B stream) instead of the spectra panels of
@@ -590,7 +609,7 @@ static int setup_refine(ra_engine *e)
     if ((rc = upload(e, tw, &dtw)) || (rc = upload(e, off, &doff))) return rc;
     e->d_twx = (float *)dtw; e->d_twxoff = (int *)doff;
     if ((rc = dev_alloc(e, &e->d_refx, (size_t)e->cfg.nref * g.lcirc, true)) ||
-        (rc = dev_alloc(e, &e->d_rlist, (size_t)e->chunk, false)) ||
+        (rc = dev_alloc(e, &e->d_rlist, (size_t)e->chunk, false)) || (e->rlist_cap = e->chunk, 0) ||
         (rc = dev_alloc(e, &e->d_rcount, 1, true))) return rc;
     hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)refspec_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
@@ -613,6 +632,28 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
                            (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
                            res, cls);
         RA_HIP(hipGetLastError());
+    }
+    return RA_OK;
+}
+
+// One launch of a particle-resident kernel takes up to RA_RESIDENT_BATCH particles (cfg.chunk > 0: that many): every launch
+// ends with a tail in which the CUs run dry one by one, ~1 % of a 7 000-particle launch (measured: 7 launches 30.9 ms, 5 launches
+// 30.6 ms per 50 000 particles); its candidate records (2 KB per particle at 49 offsets) and the refine list grow on demand.
+#define RA_RESIDENT_BATCH 65536
+static int resident_batch(const ra_engine *e, int n)
+{
+    return std::max(1, std::min(n, e->cfg.chunk > 0 ? e->chunk : RA_RESIDENT_BATCH));
+}
+static int ensure_resident_ws(ra_engine *e, int cn)
+{
+    int rc;
+    if (cn > e->fcand_cap) {
+        if ((rc = dev_grow(e, &e->d_fcand, (size_t)cn * e->pad_cap + 8, true))) return rc;
+        e->fcand_cap = cn;
+    }
+    if (e->refine_ok && cn > e->rlist_cap) {
+        if ((rc = dev_grow(e, &e->d_rlist, (size_t)cn, false))) return rc;
+        e->rlist_cap = cn;
     }
     return RA_OK;
 }
@@ -732,11 +773,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     if ((rc = dev_alloc(e, &e->d_refspec, wp.refspec_floats, true)) ||
         (rc = dev_alloc(e, &e->d_B, wp.b_floats, true)) ||
         (rc = dev_alloc(e, &e->d_cs, 2, true)) ||
-        (rc = dev_alloc(e, &e->d_alscratch, wp.alscratch_floats, false)) ||
         (rc = dev_alloc(e, &e->d_fcand, (size_t)wp.chunk * g.nshift_pad + 8, true))) {
         ra_destroy(e);
         return rc;
     }
+    e->fcand_cap = wp.chunk;
     if (e->generic) {
         e->g_nblk = 512;       // persistent workgroups of ccf_generic_kernel (two per CU)
         if ((rc = dev_alloc(e, &e->d_gstats, (size_t)wp.chunk * g.nshift_pad + 8, true)) ||
@@ -1030,8 +1071,13 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
     const int npix = g.nx * g.nx;
     const FusedGeom f = e->fplan.f;
     fused_fn fk = select_fused(g.maxrin, 1, f.nzr, e->dg.sbuf);
-    for (int start = 0; start < n; start += e->chunk) {
-        const int cn = std::min(e->chunk, n - start);
+    const int rch = resident_batch(e, n);
+    {
+        int rcw = ensure_resident_ws(e, rch);
+        if (rcw) return rcw;
+    }
+    for (int start = 0; start < n; start += rch) {
+        const int cn = std::min(rch, n - start);
         float *st = d_state + (size_t)start * 2;
         hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f,
                            d_particles + (size_t)start * npix, (const float *)st, cn, (const float *)e->d_cls_Bf, 1, e->d_fcand, d_cls + start);
@@ -1064,8 +1110,13 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
         fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf);
-        for (int start = 0; start < n; start += e->chunk) {
-            const int cn = std::min(e->chunk, n - start);
+        const int rch = resident_batch(e, n);
+        {
+            int rcw = ensure_resident_ws(e, rch);
+            if (rcw) return rcw;
+        }
+        for (int start = 0; start < n; start += rch) {
+            const int cn = std::min(rch, n - start);
             float *st = d_state + (size_t)start * 2;
             std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
             if (evc) RA_HIP(hipEventRecord(evc->first, sp));
@@ -1156,6 +1207,72 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
     return RA_OK;
 }
 
+// rot_shift2D + class sums without the aligned stack (transform_sum_kernel): member lists of up to RA_XS_BATCH particles at
+// once, every (class, parity) list cut into runs so that ~1000 workgroups share the work
+#define RA_XS_BATCH 65536
+typedef void (*xs_fn)(int, const float *, int, int, const ra_result *, const float2 *, const int *, const int *, int, float *);
+static xs_fn select_xs(int nx)
+{
+    if (nx < 8 || nx > RA_XS_THREADS) return nullptr;
+    const int ry = RA_XS_THREADS / nx, npt = (nx + ry - 1) / ry;      // sweeps of the workgroup over the image
+    if (npt <= 1) return transform_sum_kernel<1>;
+    if (npt <= 2) return transform_sum_kernel<2>;
+    if (npt <= 4) return transform_sum_kernel<4>;
+    if (npt <= 6) return transform_sum_kernel<6>;
+    if (npt <= 9) return transform_sum_kernel<9>;
+    if (npt <= 12) return transform_sum_kernel<12>;
+    if (npt <= 16) return transform_sum_kernel<16>;
+    return nullptr;
+}
+static bool xs_usable(const ra_engine *e)
+{
+    const int npix = e->geo.nx * e->geo.nx;
+    if (e->xf_generic || e->atomic_sums || !select_xs(e->geo.nx)) return false;
+    if ((size_t)(e->geo.nx + 2) * ((e->geo.nx + 2) | 1) * sizeof(float) > 64 * 1024) return false;
+    return !(getenv("RALIGN_XSUM") && atoi(getenv("RALIGN_XSUM")) == 0);
+}
+static int transform_sum(ra_engine *e, const float *d_particles, int n, int index0, const ra_result *d_result, float *d_sums, int *d_counts)
+{
+    const int nx = e->geo.nx, npix = nx * nx, nseg = 2 * e->cfg.nref;
+    const xs_fn fn = select_xs(nx);
+    for (int start = 0; start < n; start += RA_XS_BATCH) {
+        const int cn = std::min(RA_XS_BATCH, n - start);
+        // runs per segment: ~1024 workgroups, at least ~8 members per run on average
+        int nrun = std::max(1, std::min(512, (1024 + nseg - 1) / nseg));
+        nrun = std::max(1, std::min(nrun, cn / (8 * nseg)));
+        const size_t need_m = (size_t)nseg * cn, need_p = (size_t)nrun * nseg * npix;
+        if (need_m > e->xs_cap_members) {
+            int rc = dev_grow(e, &e->d_xs_members, need_m, false);
+            if (rc) return rc;
+            e->xs_cap_members = need_m;
+        }
+        if (!e->d_xs_mcount) { int rc = dev_alloc(e, &e->d_xs_mcount, (size_t)nseg, true); if (rc) return rc; }
+        if ((size_t)cn > e->xs_cap_trig) {
+            int rc = dev_grow(e, &e->d_xs_trig, (size_t)cn, false);
+            if (rc) return rc;
+            e->xs_cap_trig = cn;
+        }
+        hipLaunchKernelGGL(transform_trig_kernel, dim3((cn + 255) / 256), dim3(256), 0, e->stream, d_result + start, cn, e->d_xs_trig);
+        RA_HIP(hipGetLastError());
+        if (need_p > e->xs_cap_partial) {
+            int rc = dev_grow(e, &e->d_xs_partial, need_p, false);
+            if (rc) return rc;
+            e->xs_cap_partial = need_p;
+        }
+        hipLaunchKernelGGL(class_members_wide_kernel, dim3(nseg), dim3(1024), 0, e->stream, d_result + start, cn, index0 + start,
+                           e->d_xs_members, e->d_xs_mcount, cn, d_counts);
+        RA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(fn, dim3(nseg, nrun), dim3(RA_XS_THREADS), (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float), e->stream, nx,
+                           d_particles + (size_t)start * npix, cn, index0 + start, d_result + start, (const float2 *)e->d_xs_trig, (const int *)e->d_xs_members,
+                           (const int *)e->d_xs_mcount, cn, e->d_xs_partial);
+        RA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(class_sum_combine_kernel, dim3((unsigned)(((size_t)nseg * npix + 255) / 256)), dim3(256), 0, e->stream, npix, nseg, nrun,
+                           (const float *)e->d_xs_partial, d_sums);
+        RA_HIP(hipGetLastError());
+    }
+    return RA_OK;
+}
+
 extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, int n, int index0,
                                        const ra_result *d_result, float *d_aligned, float *d_sums, int *d_counts)
 {
@@ -1173,7 +1290,13 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
         RA_HIP(hipGetLastError());
         return RA_OK;
     }
-    // deterministic path: aligned images of a chunk, then particle-order sums per (class, parity)
+    if (!d_aligned && xs_usable(e)) return transform_sum(e, d_particles, n, index0, d_result, d_sums, d_counts);
+    // aligned images wanted as well (or an image too large for the LDS): aligned images of a chunk, then particle-order sums per
+    // (class, parity)
+    if (!d_aligned && !e->d_alscratch) {
+        int rca = dev_alloc(e, &e->d_alscratch, e->wp.alscratch_floats, false);
+        if (rca) return rca;
+    }
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *al = d_aligned ? d_aligned + (size_t)start * npix : e->d_alscratch;

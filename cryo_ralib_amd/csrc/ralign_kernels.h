@@ -1371,6 +1371,173 @@ __global__ __launch_bounds__(256) void class_sum_combine_kernel(int npix, int ns
     sums[i] = acc;
 }
 
+// K4c: rot_shift2D and the class sums in one pass: the aligned image is never written.  Workgroup (segment =
+// (class, parity), run) walks over its contiguous share of the segment's member list IN PARTICLE ORDER: image -> LDS, every
+// thread interpolates its pixels (the arithmetic of transform_kernel, bit for bit) and adds them to accumulators it keeps in
+// registers; the next member's image is on its way from HBM meanwhile (register prefetch); cos / sin come from
+// transform_trig_kernel.  partial[run][segment][pixel] receives the run's sum; class_sum_combine_kernel adds the runs in run
+// order: a fixed association, bitwise reproducible run to run (the same shape as class_sum_kernel's runs).
+// Replaces cu_transform_batch + cu_average_batch_m / kernel_sum_oe (cuda/gpu_aln_noref.cu:1145-1197, 1232-1274;
+// test_mref_gpu_align.py:48-80, 449-453), which write and re-read the aligned stack.
+#define RA_XS_THREADS 1024
+// quadri_background_1b on a copy of the image with a wrap-around border of one pixel (row stride pst, P = pointer to the
+// element of 1-based pixel (0, 0)): the periodic neighbours ip1 / im1 / jp1 / jm1 / (ic, jc) are plain offsets.  The float
+// operations are those of quadri_background_1b in the same order; two simplifications are exact: hxc = hyc = 1 always (x >= 1
+// after the background rule, so dx0 = x - (int)x >= 0), which turns hxc * c1 into c1 and drops the terms multiplied by
+// hxc (hxc - 1) = 0.
+__device__ __forceinline__ float quadri_background_wrap(const float *P, int pst, int nx, float xx, float yy, int xnew, int ynew)
+{
+#pragma clang fp contract(off)
+    float x = xx, y = yy;
+    if ((x < 1.0f) || (x >= (float)(nx + 1)) || (y < 1.0f) || (y >= (float)(nx + 1))) { x = (float)xnew; y = (float)ynew; }
+    const int i = (int)x, j = (int)y;
+    const float dx0 = x - i, dy0 = y - j;
+    const float *q = P + j * pst + i;
+    const float f0 = q[0];
+    const float c1 = q[1] - f0;
+    const float c2 = (c1 - f0 + q[-1]) * 0.5f;
+    const float c3 = q[pst] - f0;
+    const float c4 = (c3 - f0 + q[-pst]) * 0.5f;
+    const float dxb = dx0 - 1, dyb = dy0 - 1;
+    const float c5 = q[pst + 1] - f0 - c1 - c3;
+    return f0 + dx0 * (c1 + dxb * c2 + dy0 * c5) + dy0 * (c3 + dyb * c4);
+}
+
+// Thread (tx, ty) = (tid % nx, tid / nx) owns column tx of rows ty, ty + RY, ty + 2 RY, .. (RY = 1024 / nx rows per sweep of
+// the workgroup, NPT sweeps): the column terms of the rotation -- mirror, x, x cos, x sin -- are formed once per member, pixel
+// indices are tid + k RY nx, and nothing per-pixel has to live in registers besides the accumulator and the prefetched value.
+template <int NPT>      // sweeps: NPT * (1024 / nx) >= nx
+__global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, const float *__restrict__ particles, int n, int index0,
+                                                                      const ra_result *__restrict__ res, const float2 *__restrict__ trig,
+                                                                      const int *__restrict__ members,
+                                                                      const int *__restrict__ mcount, int mstride,
+                                                                      float *__restrict__ partial)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) float img[];          // [(nx + 2)][pst]: rows / columns 0 and nx + 1 repeat nx and 1
+    const int seg = blockIdx.x, run = blockIdx.y, nrun = gridDim.y, tid = threadIdx.x, npix = nx * nx;
+    const int pst = (nx + 2) | 1;
+    const int cnt = mcount[seg];
+    const int j0 = (int)((long long)cnt * run / nrun), j1 = (int)((long long)cnt * (run + 1) / nrun);
+    const int *mem = members + (size_t)seg * mstride;
+    const unsigned nx_rcp = 0xFFFFFFFFu / (unsigned)nx + 1u;      // i / nx = (i * nx_rcp) >> 32, exact for i * nx < 2^32
+    const int RY = RA_XS_THREADS / nx, S = RY * nx;               // rows, pixels per sweep
+    const int ty = (int)__umulhi((unsigned)tid, nx_rcp), tx = tid - ty * nx;
+    const bool live = tid < S;
+    float acc[NPT], pre[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; k++) acc[k] = 0.f;
+    // wrap-around border of the padded copy: 4 nx + 4 elements, one per thread tid < 4 nx + 4 (padded (row, col) <- pixel)
+    int bdst = -1, bsrc = 0;
+    if (tid < 4 * nx + 4) {
+        int pr, pc;
+        if (tid < nx + 2) { pr = 0; pc = tid; }
+        else if (tid < 2 * nx + 4) { pr = nx + 1; pc = tid - (nx + 2); }
+        else if (tid < 3 * nx + 4) { pr = tid - (2 * nx + 4) + 1; pc = 0; }
+        else { pr = tid - (3 * nx + 4) + 1; pc = nx + 1; }
+        const int sr = pr == 0 ? nx - 1 : pr == nx + 1 ? 0 : pr - 1, sc = pc == 0 ? nx - 1 : pc == nx + 1 ? 0 : pc - 1;
+        bdst = pr * pst + pc; bsrc = sr * nx + sc;
+    }
+    float preb = 0.f;
+    const int xc = nx / 2, yc = nx / 2, mstart = 1 - nx % 2;
+    // (tid and ty pass through an empty asm in every trip of the member loop: what derives from them per sweep -- pixel
+    // indices, LDS addresses, row coordinates -- is then rebuilt with a few instructions instead of being hoisted out of the
+    // loop into ~8 registers per sweep, more than the kernel has)
+    auto fetch = [&](int j) {
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
+        const float *src = particles + (size_t)mem[j] * npix;
+#pragma unroll
+        for (int k = 0; k < NPT; k++) pre[k] = src[min(t0 + k * S, npix - 1)];
+        preb = src[bsrc];
+    };
+    if (j0 < j1) fetch(j0);
+#pragma unroll 1
+    for (int j = j0; j < j1; j++) {
+        __syncthreads();                                  // the previous member's taps are read
+        int t1 = tid, tyv = ty;
+        asm volatile("" : "+v"(t1), "+v"(tyv));
+        float *fill = img + (tyv + 1) * pst + tx + 1;
+#pragma unroll
+        for (int k = 0; k < NPT; k++)
+            if (t1 < S && t1 + k * S < npix) fill[k * RY * pst] = pre[k];
+        if (bdst >= 0) img[bdst] = preb;
+        const ra_result r = res[mem[j]];
+        const float2 cs = trig[mem[j]];
+        __syncthreads();
+        if (j + 1 < j1) fetch(j + 1);
+        float delx = r.sx, dely = r.sy;
+        while (delx >= (float)nx) delx -= nx;
+        while (delx <= -(float)nx) delx += nx;
+        while (dely >= (float)nx) dely -= nx;
+        while (dely <= -(float)nx) dely += nx;
+        const float shiftxc = xc + delx, shiftyc = yc + dely;
+        const float cang = cs.x, sang = cs.y;
+        // destination column tx; xform.mirror(x) reverses columns [1 - nx%2, nx): its source column is ix
+        const int ix = (r.mirror && tx >= mstart) ? mstart + (nx - 1) - tx : tx;
+        const float x = (float)ix - shiftxc;
+        const float xcang = x * cang, xsang = x * sang;
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            const int iy = min(tyv + k * RY, nx - 1);     // rows past the image (last sweep, idle threads) shadow the last row
+            const float y = (float)iy - shiftyc;
+            const float ycang = y * cang + yc;
+            const float ysang = -y * sang + xc;
+            const float xold = xcang + ysang;
+            const float yold = xsang + ycang;
+            acc[k] += quadri_background_wrap(img, pst, nx, xold + 1.0f, yold + 1.0f, ix + 1, iy + 1);
+        }
+    }
+    float *dst = partial + ((size_t)run * gridDim.x + seg) * npix;
+#pragma unroll
+    for (int k = 0; k < NPT; k++) { const int o = tid + k * S; if (live && o < npix) dst[o] = acc[k]; }
+}
+
+// (float)cos / sin of the angle in double, once per particle, exactly as transform_kernel forms them
+__global__ void transform_trig_kernel(const ra_result *__restrict__ res, int n, float2 *__restrict__ trig)
+{
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float ang = res[p].alpha * (float)M_PI / 180.0f;
+    trig[p] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+}
+
+// member lists of a whole batch: segment = (class, parity); 16 waves per segment, wave w compacts the particles of its
+// contiguous 1/16 of the batch in particle order (ballot + prefix count), after a counting pass that gives every wave its
+// offset.  counts: += members per class (even + odd), added once.
+__global__ __launch_bounds__(1024) void class_members_wide_kernel(const ra_result *__restrict__ res, int n, int index0,
+                                                                  int *__restrict__ members, int *__restrict__ mcount, int mstride,
+                                                                  int *__restrict__ counts)
+{
+    __shared__ int wcnt[16];
+    const int seg = blockIdx.x, cls = seg >> 1, par = seg & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((n + 15) / 16 + 63) & ~63;
+    const int lo = min(n, wave * per), hi = min(n, lo + per);
+    int c = 0;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool mine = i < hi && res[i].ref_id == cls && ((index0 + i) & 1) == par;
+        c += __popcll(__ballot(mine));
+    }
+    if (lane == 0) wcnt[wave] = c;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) base += wcnt[w]; total += wcnt[w]; }
+    int *mem = members + (size_t)seg * mstride;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool mine = i < hi && res[i].ref_id == cls && ((index0 + i) & 1) == par;
+        const unsigned long long m = __ballot(mine);
+        if (mine) mem[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        base += __popcll(m);
+    }
+    if (threadIdx.x == 0) {
+        mcount[seg] = total;
+        if (counts && total) atomicAdd(counts + cls, total);
+    }
+}
+
 // K5: new references from the class sums: (even + odd) * (1/count), then
 // normalize.mask(no_sigma=1) (test_mref_gpu_align.py:534-535, 563)
 __global__ __launch_bounds__(256) void update_refs_kernel(int nx, const float *__restrict__ sums,

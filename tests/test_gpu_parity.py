@@ -649,10 +649,18 @@ def test_command_line_entry_points(tmp_path):
     assert "EMAN.xform.align2d" in at[0] and int(at[5]["EMAN.source_n"]) == 5
 
 
+def _xs_runs(n, nseg):
+    """runs per (class, parity) list of transform_sum_kernel (ralign_engine.hip: transform_sum)"""
+    nrun = max(1, min(512, (1024 + nseg - 1) // nseg))
+    return max(1, min(nrun, n // (8 * nseg)))
+
+
 def test_class_sums_are_bitwise_reproducible():
-    """class sums are accumulated in a fixed order -- per chunk and (class, parity) the member list is cut into `nrun`
-    contiguous runs, each added in particle order (like Util.add_img on the CPU path), the runs then added to the sums in
-    run order -- so two runs agree bit for bit, and with a float32 restatement of exactly that association"""
+    """class sums are accumulated in a fixed order -- per batch and (class, parity) the member list is cut into `nrun`
+    contiguous runs, each added in particle order (like Util.add_img on the CPU path) by one workgroup of
+    transform_sum_kernel, the runs then added to the sums in run order -- so two runs agree bit for bit, and with a float32
+    restatement of exactly that association on the aligned images of transform_kernel (the two kernels interpolate bit for
+    bit alike); the path that also returns the aligned images (class_sum_kernel, 16 runs per chunk) is pinned the same way"""
     nx, ou, nref, xr, n = 90, 36, 4, 3, 300
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
@@ -670,28 +678,49 @@ def test_class_sums_are_bitwise_reproducible():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert outs[0][1].sum() == n
     # and they equal that association applied to the engine's own aligned images in float32
-    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, chunk=128)
     al = torch.zeros((n, nx, nx), device=eng.dev)
-    eng.transform_accumulate(tp, res, 3, al, None, None)
+    gs2 = torch.zeros((nref, 2, nx, nx), device=eng.dev)
+    gc2 = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
+    eng.transform_accumulate(tp, res, 3, al, gs2, gc2)          # aligned images AND sums: transform_kernel + class_sum_kernel
     eng.sync()
     a = al.cpu().numpy(); r = eng.result_to_numpy(res)
-    want = np.zeros((nref, 2, nx, nx), np.float32)
-    nrun = min(16, max(1, 4096 // (2 * nref * ((nx * nx + 255) // 256))))
-    for start in range(0, n, 128):                       # the chunks of the engines above
-        idx = np.arange(start, min(n, start + 128))
-        for c in range(nref):
-            for par in range(2):
-                mem = [i for i in idx if r["ref_id"][i] == c and (3 + i) % 2 == par]
-                for run in range(nrun):
-                    part = np.zeros((nx, nx), np.float32)
-                    for i in mem[len(mem) * run // nrun:len(mem) * (run + 1) // nrun]:
-                        part += a[i]
+    np.testing.assert_array_equal(r["ref_id"], outs[0][2]["ref_id"])
+
+    def restate(chunk, nrun_of):
+        want = np.zeros((nref, 2, nx, nx), np.float32)
+        for start in range(0, n, chunk):
+            idx = np.arange(start, min(n, start + chunk))
+            nrun = nrun_of(len(idx))
+            for c in range(nref):
+                for par in range(2):
+                    mem = [i for i in idx if r["ref_id"][i] == c and (3 + i) % 2 == par]
                     if nrun > 1:
-                        want[c, par] += part
+                        for run in range(nrun):
+                            part = np.zeros((nx, nx), np.float32)
+                            for i in mem[len(mem) * run // nrun:len(mem) * (run + 1) // nrun]:
+                                part += a[i]
+                            want[c, par] += part
                     else:
                         for i in mem:
                             want[c, par] += a[i]
+        return want
+
+    # transform_sum_kernel: one batch (n < 65536), runs from a zero partial sum even when there is one run only
+    nrun = _xs_runs(n, 2 * nref)
+    want = np.zeros((nref, 2, nx, nx), np.float32)
+    for c in range(nref):
+        for par in range(2):
+            mem = [i for i in range(n) if r["ref_id"][i] == c and (3 + i) % 2 == par]
+            for run in range(nrun):
+                part = np.zeros((nx, nx), np.float32)
+                for i in mem[len(mem) * run // nrun:len(mem) * (run + 1) // nrun]:
+                    part += a[i]
+                want[c, par] += part
     np.testing.assert_array_equal(outs[0][0], want)
+    # class_sum_kernel: chunks of 128, 16 runs
+    np.testing.assert_array_equal(gs2.cpu().numpy(), restate(128, lambda m: min(16, max(1, 4096 // (2 * nref * ((nx * nx + 255) // 256))))))
+    np.testing.assert_array_equal(gc2.cpu().numpy(), outs[0][1])
     eng.close()
 
 
