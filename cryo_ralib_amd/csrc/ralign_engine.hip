@@ -630,7 +630,7 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
     if (refine) {
         hipLaunchKernelGGL(refine_winner_kernel, dim3(cn), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                            (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
-                           res, cls);
+                           res, cls, st);
         RA_HIP(hipGetLastError());
     }
     return RA_OK;

@@ -148,22 +148,19 @@ __device__ __forceinline__ void finish_params(const DevGeom &g, float sxi, float
     *alpha_out = (float)alpha; *sx_out = (float)tx; *sy_out = (float)ty;
 }
 
-// refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls: of the chunk (indexed by rec.p)
-__global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ tw,
-                                                           const int *__restrict__ twoff, const float *__restrict__ particles,
-                                                           const float *__restrict__ refx, const RefineRec *__restrict__ list,
-                                                           const int *__restrict__ count, ra_result *__restrict__ res,
-                                                           const int *__restrict__ cls)
+// One candidate (search offset bs, reference spectrum c1, orientation mir) of particle image `img`, evaluated as the CPU path
+// evaluates it: samples, Normalize_ring, Frngs, the q or t spectrum, and the 7 CCF samples around bin `jtot` in f64.  The f32
+// search may have stopped one bin beside the f64 maximum of a flat peak: the window is re-centred on its own maximum (">=":
+// the last of equal values, as the CPU scan) until the peak sits in the middle.  Wave-uniform results.
+__device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__restrict__ numr, const float *__restrict__ tw,
+                                                const int *__restrict__ twoff, const float *__restrict__ img,
+                                                const float *__restrict__ c1, int bs, float sxi, float syi, bool mir, int &jtot,
+                                                double (&b)[7], float *circ, float *work, int lane)
 {
 #pragma clang fp contract(off)
-    if ((int)blockIdx.x >= *count) return;
-    extern __shared__ float lds[];
-    const RefineRec rec = list[blockIdx.x];
-    const int lane = threadIdx.x;
-    float *circ = lds, *work = lds + g.lcirc;
-    const float *img = particles + (size_t)rec.p * g.nx * g.nx;
-    const float cx = ((float)g.cnx + rec.sxi) + g.shift_x[rec.bs], cy = ((float)g.cnx + rec.syi) + g.shift_y[rec.bs];
+    const float cx = ((float)g.cnx + sxi) + g.shift_x[bs], cy = ((float)g.cnx + syi) + g.shift_y[bs];
     double av = 0.0, sq = 0.0;
+    __syncthreads();
     for (int i0 = lane; i0 < g.lcirc; i0 += 256) {          // four samples per trip: their 16 image taps are in flight together
         float v[4], w[4];
 #pragma unroll
@@ -190,11 +187,9 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
     __syncthreads();
     exact_frngs(circ, work, g, numr, tw, twoff, lane, nullptr);
     __syncthreads();
-    // Crosrng_ms: q (straight) or t (mirrored) spectrum of the winner, f32 products, f64 sums over the rings in ring order
+    // Crosrng_ms: q (straight) or t (mirrored) spectrum, f32 products, f64 sums over the rings in ring order
     const int N = g.maxrin;
     double *spec = reinterpret_cast<double *>(work);          // [N] doubles (the FFT work space is free again: N <= lcirc / 2)
-    const float *c1 = refx + (size_t)(cls ? cls[rec.p] : rec.ref) * g.lcirc;      // class-resident mode: the particle's own class
-    const bool mir = rec.mirror != 0;
     for (int j = 2 * lane; j < N; j += 128) {
         double s0 = 0.0, s1 = 0.0;
         if (j == 0) {
@@ -232,34 +227,94 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
     }
     __syncthreads();
     // 7 samples of the inverse real transform around the peak: x[m] = (X0 + (-1)^m X_{N/2} + 2 sum_k Re(X_k e^{+2 pi i k m / N})) / N
-    double b[7];
+    for (int trip = 0; trip < 4; trip++) {
 #pragma unroll
-    for (int t = 0; t < 7; t++) b[t] = 0.0;
-    const int m0 = rec.jtot - 1;
-    for (int k = 1 + lane; k < N / 2; k += 64) {
-        const double xr = spec[2 * k], xi = spec[2 * k + 1];
+        for (int t = 0; t < 7; t++) b[t] = 0.0;
+        const int m0 = jtot - 1;
+        for (int k = 1 + lane; k < N / 2; k += 64) {
+            const double xr = spec[2 * k], xi = spec[2 * k + 1];
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const int m = (m0 + t - 3 + N) & (N - 1);
+                const int km = (int)(((long long)k * m) & (N - 1));
+                double sn, cs;
+                sincospi(2.0 * (double)km / (double)N, &sn, &cs);
+                b[t] += xr * cs - xi * sn;
+            }
+        }
+        int kb = 3;
 #pragma unroll
         for (int t = 0; t < 7; t++) {
+            b[t] = wave_sum_f64(b[t]);
             const int m = (m0 + t - 3 + N) & (N - 1);
-            const int km = (int)(((long long)k * m) & (N - 1));
-            double sn, cs;
-            sincospi(2.0 * (double)km / (double)N, &sn, &cs);
-            b[t] += xr * cs - xi * sn;
+            b[t] = (spec[0] + ((m & 1) ? -spec[1] : spec[1]) + 2.0 * b[t]) / (double)N;
         }
-    }
+        // the CPU scan runs over j = 1 .. N with ">=": of equal values the largest bin wins (the window may wrap around N)
+        double bm = b[0];
+        int jm = ((m0 - 3 + N) & (N - 1)) + 1;
+        kb = 0;
 #pragma unroll
-    for (int t = 0; t < 7; t++) {
-        b[t] = wave_sum_f64(b[t]);
-        const int m = (m0 + t - 3 + N) & (N - 1);
-        b[t] = (spec[0] + ((m & 1) ? -spec[1] : spec[1]) + 2.0 * b[t]) / (double)N;
+        for (int t = 1; t < 7; t++) {
+            const int jt = ((m0 + t - 3 + N) & (N - 1)) + 1;
+            if (b[t] > bm || (b[t] == bm && jt > jm)) { bm = b[t]; jm = jt; kb = t; }
+        }
+        if (kb == 3) break;
+        jtot = jm;
+    }
+}
+
+// refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls, state: of the chunk (indexed by rec.p)
+__global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ tw,
+                                                           const int *__restrict__ twoff, const float *__restrict__ particles,
+                                                           const float *__restrict__ refx, const RefineRec *__restrict__ list,
+                                                           const int *__restrict__ count, ra_result *__restrict__ res,
+                                                           const int *__restrict__ cls, float *__restrict__ state)
+{
+#pragma clang fp contract(off)
+    if ((int)blockIdx.x >= *count) return;
+    extern __shared__ float lds[];
+    const RefineRec rec = list[blockIdx.x];
+    const int lane = threadIdx.x;
+    float *circ = lds, *work = lds + g.lcirc;
+    const float *img = particles + (size_t)rec.p * g.nx * g.nx;
+    const float *cbase = refx + (cls ? (size_t)cls[rec.p] * g.lcirc : (size_t)0);      // class-resident mode: the particle's own class
+    int ref = rec.ref, mirror = rec.mirror, jtot = rec.jtot, bs = rec.bs;
+    double b[7];
+    exact_candidate(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
+                    circ, work, lane);
+    if (rec.bs2 >= 0) {
+        // a second record within RA_TIE_RTOL of the winner: both peaks in the CPU path's arithmetic, and its order of the scan --
+        // offsets, then references, ascending, a later candidate wins with ">="; straight beats mirrored on equality
+        int jt2 = rec.jtot2;
+        double b2[7];
+        exact_candidate(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
+                        rec.mirror2 != 0, jt2, b2, circ, work, lane);
+        const long long o1 = ((long long)bs << 32) | ((long long)(rec.rt2 & 0xffff) << 16) | (unsigned)ref;
+        const long long o2 = ((long long)rec.bs2 << 32) | ((long long)(rec.rt2 >> 16) << 16) | (unsigned)rec.ref2;
+        bool second_wins;
+        if (o1 == o2) second_wins = rec.mirror2 ? b2[3] > b[3] : b2[3] >= b[3];      // same (offset, reference): qn >= qm keeps straight
+        else second_wins = o2 > o1 ? b2[3] >= b[3] : b2[3] > b[3];
+        if (second_wins) {
+            ref = rec.ref2; mirror = rec.mirror2; jtot = jt2; bs = rec.bs2;
+#pragma unroll
+            for (int t = 0; t < 7; t++) b[t] = b2[t];
+        }
     }
     if (lane == 0) {
         const double c2 = 49. * b[0] + 6. * b[1] - 21. * b[2] - 32. * b[3] - 27. * b[4] - 6. * b[5] + 31. * b[6];
         const double c3 = 5. * b[0] - 3. * b[2] - 4. * b[3] - 3. * b[4] + 5. * b[6];
         const float pos = (c3 != 0.0) ? (float)(c2 / (2.0 * c3) - 4) : 0.f;
         float alpha, sx, sy;
-        finish_params(g, rec.sxi, rec.syi, rec.jtot, pos, rec.bs, &alpha, &sx, &sy);
-        res[rec.p].alpha = alpha; res[rec.p].sx = sx; res[rec.p].sy = sy;
+        finish_params(g, rec.sxi, rec.syi, jtot, pos, bs, &alpha, &sx, &sy);
+        ra_result r = res[rec.p];
+        r.alpha = alpha; r.sx = sx; r.sy = sy;
+        if (jtot != rec.jtot || bs != rec.bs || ref != rec.ref || mirror != rec.mirror) {
+            // the f64 CCF orders a float tie differently: the integer assignment follows it
+            r.angle_bin = jtot; r.shift_idx = bs; r.ref_id = cls ? r.ref_id : ref; r.mirror = mirror; r.peak = (float)b[3];
+            state[2 * rec.p] = rec.sxi + g.shift_x[bs];
+            state[2 * rec.p + 1] = rec.syi + g.shift_y[bs];
+        }
+        res[rec.p] = r;
     }
 }
 

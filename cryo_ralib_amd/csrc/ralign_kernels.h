@@ -1141,7 +1141,10 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
 // the ">=" rule of Util::multiref_polar_ali_2d, ang_n, the ormq tail and combine_params2
 // (test_mref_gpu_align.py:1043-1049).
 // record of a particle whose sub-bin angle is to be re-evaluated with the CPU path's arithmetic (ralign_exact.h)
-struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int pad; };
+// (ref2, mirror2, jtot2, bs2): the runner-up of the offset / reference-tile scan when its peak is within RA_TIE_RTOL of the
+// winner's (bs2 = -1: none) -- the exact re-evaluation then decides between the two with the CPU path's ">=" order
+struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirror2, jtot2, bs2, rt2; };
+#define RA_TIE_RTOL 3.0e-6f      // f32 peaks closer than this (relative) are re-evaluated in the CPU path's arithmetic
 
 // rlist / rcount / rthr: particles whose prb1d is ill-conditioned (|c3| < rthr x max |b|; rthr < 0: every particle) are
 // appended to rlist for refine_winner_kernel; rlist = null: none
@@ -1152,10 +1155,10 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    float peak = -1.0e23f;
+    float peak = -1.0e23f, second = -1.0e23f;
     CandT best; best.val = peak; best.jtot = 1; best.refmir = 0;
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
-    int bs = 0;
+    int bs = 0, brt = 0, s2 = -1, rt2 = 0;          // (s2, rt2): the record with the second-largest peak
     const int nx1 = 2 * g.nkx + 1;
     for (int s = 0; s < g.nshift; s++) {
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
@@ -1163,7 +1166,8 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
         for (int rt = 0; rt < nrtile; rt++) {
             const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
             const float v = c->val;
-            if (v >= peak) { peak = v; best = *c; bs = s; }
+            if (v >= peak) { second = peak; s2 = bs; rt2 = brt; peak = v; best = *c; bs = s; brt = rt; }
+            else if (v >= second) { second = v; s2 = s; rt2 = rt; }
         }
     }
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
@@ -1191,11 +1195,22 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     if (rlist) {
         const float *b = best.t7;
         const float c3 = 5.f * b[0] - 3.f * b[2] - 4.f * b[3] - 3.f * b[4] + 5.f * b[6];
-        float tmax = 0.f;
-        for (int k = 0; k < 7; k++) tmax = fmaxf(tmax, fabsf(b[k]));
-        if (rthr < 0.f || fabsf(c3) < rthr * tmax) {
+        float tmax = 0.f, nb = -1.0e23f;
+        for (int k = 0; k < 7; k++) { tmax = fmaxf(tmax, fabsf(b[k])); if (k != 3) nb = fmaxf(nb, b[k]); }
+        // float ties: a neighbouring angular bin or another offset / reference tile within RA_TIE_RTOL of the winner (the f32
+        // and the f64 CCF may order them differently); refine_winner_kernel decides them in the CPU path's arithmetic
+        const float tol = RA_TIE_RTOL * fabsf(b[3]);
+        const bool tie_bin = nb >= b[3] - tol;
+        const bool tie_rec = s2 >= 0 && second >= peak - RA_TIE_RTOL * fabsf(peak);
+        if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec) {
             RefineRec rec;
-            rec.p = p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi; rec.pad = 0;
+            rec.p = p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi;
+            rec.bs2 = -1; rec.ref2 = 0; rec.mirror2 = 0; rec.jtot2 = 1; rec.rt2 = brt;
+            if (tie_rec) {
+                const CandT *c = cand + ((size_t)p * g.nshift_pad + s2) * nrtile + rt2;
+                rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = c->jtot;
+                rec.rt2 = (rt2 << 16) | brt;          // scan order of the two records: (offset, reference tile)
+            }
             rlist[atomicAdd(rcount, 1)] = rec;
         }
     }
