@@ -477,12 +477,14 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         constexpr int W = sizeof(CandT) / 4;
         if (wave == 2 && lane < nl * W) {
             const int o = lane / W, wd = lane - o * W;
-            float bv = pc[o * nref].val; int br = 0;
+            float bv = pc[o * nref].val, sv = -3.0e38f; int br = 0, sr = 0;
             for (int q3 = 1; q3 < nref; q3++) {
                 const float v = pc[o * nref + q3].val;
-                if (v >= bv) { bv = v; br = q3; }
+                if (v >= bv) { sv = bv; sr = br; bv = v; br = q3; }
+                else if (v >= sv) { sv = v; sr = q3; }
             }
             int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
+            if (wd == 1 && sv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(word, pc[o * nref + sr]);      // float tie between references
             if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
             reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
         }

@@ -854,6 +854,15 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
 // record of the two-kernel path: the 7-point neighbourhood of the maximum travels with the candidate
 // and Util::prb1d runs once per particle in finalize_kernel instead of once per pair
 struct CandT { float val; int jtot; int refmir; float t7[7]; };
+// The particle-resident kernels keep the best reference per search offset only.  When another reference of the same offset
+// comes within RA_TIE_RTOL of it, the record's jtot word carries that runner-up as well, so that finalize_kernel can hand
+// both to the exact re-evaluation: bits 0-12 jtot | 13-20 runner-up reference + 1 (0: none) | 21 its mirror flag | 22-31 its jtot
+#define RA_TIE_RTOL 3.0e-6f      // f32 peaks closer than this (relative) are re-evaluated in the CPU path's arithmetic
+__device__ __forceinline__ int cand_pack_runner(int jtot, const CandT &ru)
+{
+    return (jtot & 0x1fff) | ((((ru.refmir & 0xffff) + 1) & 0xff) << 13) | (((ru.refmir >> 16) & 1) << 21) | ((ru.jtot & 0x3ff) << 22);
+}
+__device__ __forceinline__ int cand_jtot(int w) { return w & 0x1fff; }
 
 // Util::prb1d, npoint 7: sub-bin position of the maximum relative to the centre sample
 __device__ __forceinline__ float prb1d7(const float *t)
@@ -1144,7 +1153,6 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
 // (ref2, mirror2, jtot2, bs2): the runner-up of the offset / reference-tile scan when its peak is within RA_TIE_RTOL of the
 // winner's (bs2 = -1: none) -- the exact re-evaluation then decides between the two with the CPU path's ">=" order
 struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirror2, jtot2, bs2, rt2; };
-#define RA_TIE_RTOL 3.0e-6f      // f32 peaks closer than this (relative) are re-evaluated in the CPU path's arithmetic
 
 // rlist / rcount / rthr: particles whose prb1d is ill-conditioned (|c3| < rthr x max |b|; rthr < 0: every particle) are
 // appended to rlist for refine_winner_kernel; rlist = null: none
@@ -1172,6 +1180,8 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     }
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
     // Util::prb1d on the winner's neighbourhood, then Util::ang_n, mode F
+    const int jword = best.jtot;         // jtot and, possibly, a runner-up reference of the same offset (cand_pack_runner)
+    best.jtot = cand_jtot(jword);
     const float tot = (float)best.jtot + prb1d7(best.t7);
     const float ang = fmodf(((tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
     const float ixw = g.shift_x[bs], iyw = g.shift_y[bs];
@@ -1202,13 +1212,17 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
         const float tol = RA_TIE_RTOL * fabsf(b[3]);
         const bool tie_bin = nb >= b[3] - tol;
         const bool tie_rec = s2 >= 0 && second >= peak - RA_TIE_RTOL * fabsf(peak);
-        if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec) {
+        const int runner = (jword >> 13) & 0xff;          // another reference of the winning offset within the tolerance
+        if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner) {
             RefineRec rec;
             rec.p = p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi;
             rec.bs2 = -1; rec.ref2 = 0; rec.mirror2 = 0; rec.jtot2 = 1; rec.rt2 = brt;
-            if (tie_rec) {
+            if (runner) {
+                rec.bs2 = bs; rec.ref2 = runner - 1; rec.mirror2 = (jword >> 21) & 1; rec.jtot2 = (jword >> 22) & 0x3ff;
+                rec.rt2 = (brt << 16) | brt;
+            } else if (tie_rec) {
                 const CandT *c = cand + ((size_t)p * g.nshift_pad + s2) * nrtile + rt2;
-                rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = c->jtot;
+                rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = cand_jtot(c->jtot);
                 rec.rt2 = (rt2 << 16) | brt;          // scan order of the two records: (offset, reference tile)
             }
             rlist[atomicAdd(rcount, 1)] = rec;
