@@ -208,21 +208,22 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
         if (wave == 2 && lane < nl * W) {
             const int o = lane / W, wd = lane - o * W;
             const int nrz = min(RZ, nref - t * RZ);
-            float bv = pc[o * RZ].val, sv = -3.0e38f; int br = 0, sr = 0;
+            float bv = pc[o * RZ].val; int br = 0;
             for (int q3 = 1; q3 < nrz; q3++) {
                 const float v = pc[o * RZ + q3].val;
-                if (v >= bv) { sv = bv; sr = br; bv = v; br = q3; }
-                else if (v >= sv) { sv = v; sr = q3; }
+                if (v >= bv) { bv = v; br = q3; }
             }
-            const CandT *srcr = pc + o * RZ + br, *runr = pc + o * RZ + sr;      // best record and runner-up (float ties between references)
+            const CandT *srcr = pc + o * RZ + br, *runr = pbest + o;
+            float lv = -3.0e38f;                      // the loser of (this tile's best, best of the earlier tiles)
             if (t > 0) {
                 const float pv = pbest[o].val;
-                if (!(bv >= pv)) { if (bv >= sv || nrz == 1) { runr = srcr; sv = bv; } srcr = pbest + o; bv = pv; }
-                else if (pv >= sv || nrz == 1) { runr = pbest + o; sv = pv; }
+                if (!(bv >= pv)) { runr = srcr; srcr = pbest + o; lv = bv; bv = pv; }
+                else lv = pv;
             }
             int word = reinterpret_cast<const int *>(srcr)[wd];
-            // (a runner-up carried by an earlier tile's record is dropped when this tile adds a closer one: one runner-up per offset)
-            if (wd == 1 && (nrz > 1 || t > 0) && sv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(cand_jtot(word), *runr);
+            // float tie between references of different tiles: the loser travels in the jtot word (cand_pack_runner; ties inside a
+            // tile would cost a second running maximum in this loop -- measured 3.9 % of the kernel -- and are left to the audit)
+            if (wd == 1 && lv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(cand_jtot(word), *runr);
             if (last) {
                 if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
                 reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
