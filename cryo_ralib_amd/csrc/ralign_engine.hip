@@ -61,7 +61,10 @@ struct ra_engine {
     float *d_alscratch = nullptr;       // [chunk][nx*nx] aligned images of one chunk (deterministic class sums)
     // sub-bin angle refinement with the CPU path's arithmetic (ralign_exact.h)
     float refine_thr = 0.02f;           // flag |c3| < thr x max |b|; < 0: every particle; 0: off
-    bool refine_ok = false;             // tables built and the kernels' LDS (2 lcirc floats) fits
+    bool refine_ok = false;             // tables built
+    bool refine_gm = false;             // ring buffers of the exact kernels in global memory (2 lcirc floats exceed the LDS: large boxes)
+    float *d_rscratch = nullptr;        // [refine_grid][2 lcirc] (refine_gm)
+    int refine_grid = 0;                // waves of a refine_winner_kernel launch
     size_t lds_refine = 0;
     float *d_twx = nullptr, *d_refx = nullptr, *d_cls_refx = nullptr;
     int *d_twxoff = nullptr, *d_rcount = nullptr;
@@ -593,7 +596,11 @@ static int setup_refine(ra_engine *e)
     e->refine_ok = false;
     if (getenv("RALIGN_REFINE")) e->refine_thr = (float)atof(getenv("RALIGN_REFINE"));
     e->lds_refine = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float);
-    if (e->lds_refine > 160 * 1024 - 256 || (g.lcirc & 1)) return RA_OK;       // large boxes: one offset's rings exceed the LDS
+    if (g.lcirc & 1) return RA_OK;
+    // large boxes: one offset's rings exceed the LDS (271 KB at 256 x 256 / ou = 120) -- the same kernels on global scratch
+    e->refine_gm = e->lds_refine > 160 * 1024 - 256;
+    e->refine_grid = e->refine_gm ? 256 : 2048;
+    if (e->refine_gm) e->lds_refine = 0;
     std::vector<float> tw;
     std::vector<int> off(32, 0);
     for (int l = 1; (1 << l) <= g.maxrin; l++) {
@@ -611,9 +618,13 @@ static int setup_refine(ra_engine *e)
     if ((rc = dev_alloc(e, &e->d_refx, (size_t)e->cfg.nref * g.lcirc, true)) ||
         (rc = dev_alloc(e, &e->d_rlist, (size_t)e->chunk, false)) || (e->rlist_cap = e->chunk, 0) ||
         (rc = dev_alloc(e, &e->d_rcount, 1, true))) return rc;
-    hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
-    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)refspec_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
-    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(refine): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    if (e->refine_gm) {
+        if ((rc = dev_alloc(e, &e->d_rscratch, (size_t)std::max(e->refine_grid, e->cfg.nref) * 2 * g.lcirc, false))) return rc;
+    } else {
+        hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)refspec_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
+        if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(refine): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    }
     e->refine_ok = true;
     return RA_OK;
 }
@@ -628,9 +639,15 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
                        refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
     RA_HIP(hipGetLastError());
     if (refine) {
-        hipLaunchKernelGGL(refine_winner_kernel, dim3(cn), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
-                           (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
-                           res, cls, st);
+        const int grid = std::min(cn, e->refine_grid);
+        if (e->refine_gm)
+            hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(64), 0, e->stream, e->dg, (const int *)e->d_numr,
+                               (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
+                               res, cls, st, e->d_rscratch);
+        else
+            hipLaunchKernelGGL(refine_winner_kernel<false>, dim3(grid), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                               (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
+                               res, cls, st, (float *)nullptr);
         RA_HIP(hipGetLastError());
     }
     return RA_OK;
@@ -904,8 +921,12 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
         }
     }
     if (e->refine_ok && e->refine_thr != 0.f) {        // the same references with the CPU path's arithmetic, for the sub-bin angle refinement
-        hipLaunchKernelGGL(refspec_exact_kernel, dim3(e->cfg.nref), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
-                           (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx);
+        if (e->refine_gm)
+            hipLaunchKernelGGL(refspec_exact_kernel<true>, dim3(e->cfg.nref), dim3(64), 0, e->stream, e->dg, (const int *)e->d_numr,
+                               (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx, e->d_rscratch);
+        else
+            hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(e->cfg.nref), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                               (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx, (float *)nullptr);
         RA_HIP(hipGetLastError());
     }
     if (e->generic || e->fused) {
@@ -1052,8 +1073,8 @@ extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int nc
                        (const float *)e->d_cls_refspec, 1, e->d_cls_Bf);
     RA_HIP(hipGetLastError());
     if (e->refine_ok && e->refine_thr != 0.f && e->d_cls_refx) {
-        hipLaunchKernelGGL(refspec_exact_kernel, dim3(ncls), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
-                           (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, ncls, e->d_cls_refx);
+        hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(ncls), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+                           (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, ncls, e->d_cls_refx, (float *)nullptr);
         RA_HIP(hipGetLastError());
     }
     e->cls_ready = ncls;

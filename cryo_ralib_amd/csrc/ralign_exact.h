@@ -35,14 +35,18 @@ namespace ralign {
 // are independent of each other, so they are dealt to the lanes without changing a single operation: each of the four
 // 16-lane groups of the wave transforms one ring at a time (rings dealt longest first, round robin), one butterfly per
 // lane and step.  tw + twoff[l] = e^{-2 pi i k / 2^l}, k < 2^(l-1), (float) of the double-precision cos / sin.
-__device__ __forceinline__ void exact_lds_sync()
+// GM: the ring buffers live in global memory (boxes whose rings exceed the LDS: 271 KB per offset at 256 x 256 / ou = 120);
+// the wave's lanes then hand data to each other through the CU's vector cache: all earlier vector-memory traffic retired too
+template <bool GM = false> __device__ __forceinline__ void exact_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    if constexpr (GM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <bool GM = false>
 __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevGeom &g, const int *__restrict__ numr,
                                             const float *__restrict__ tw, const int *__restrict__ twoff, int lane,
                                             const float *__restrict__ wr /* Applyws weights or null */)
@@ -62,7 +66,7 @@ __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevG
                 const int r = lgh ? (int)(__brev((unsigned)q) >> (32 - lgh)) : 0;
                 wre[r] = x[2 * q]; wim[r] = x[2 * q + 1];
             }
-        exact_lds_sync();
+        exact_lds_sync<GM>();
         for (int l = 1; l <= lgmax; l++) {
             if (have && l <= lgh) {
                 const int len = 1 << l, half = len >> 1;
@@ -75,7 +79,7 @@ __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevG
                     wre[a] += tr; wim[a] += ti;
                 }
             }
-            exact_lds_sync();
+            exact_lds_sync<GM>();
         }
         if (have) {
             const float *t = tw + twoff[lgh + 1];
@@ -98,26 +102,31 @@ __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevG
                 x[2 * k] = x0; x[2 * k + 1] = x1;
             }
         }
-        exact_lds_sync();
+        exact_lds_sync<GM>();
     }
 }
 
 // references: Polar2Dm(cnx, cny) -> Frngs -> Applyws with the CPU path's arithmetic, natural (EMAN2) ring layout [lcirc]
+// gscr (GM): [gridDim.x][2 lcirc] floats of global scratch
+template <bool GM>
 __global__ __launch_bounds__(64) void refspec_exact_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ wr,
                                                            const float *__restrict__ tw, const int *__restrict__ twoff,
-                                                           const float *__restrict__ refs, int nref, float *__restrict__ out)
+                                                           const float *__restrict__ refs, int nref, float *__restrict__ out,
+                                                           float *__restrict__ gscr)
 {
 #pragma clang fp contract(off)
     extern __shared__ float lds[];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= nref) return;
-    float *circ = lds, *work = lds + g.lcirc;
+    float *circ, *work;
+    if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
+    else { circ = lds; work = lds + g.lcirc; }
     const float *img = refs + (size_t)r * g.nx * g.nx;
     const float c = (float)g.cnx;
     for (int i = lane; i < g.lcirc; i += 64) circ[i] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
-    __syncthreads();
-    exact_frngs(circ, work, g, numr, tw, twoff, lane, wr);          // Frngs, then Applyws on the way out of the split step
-    __syncthreads();
+    exact_lds_sync<GM>();
+    exact_frngs<GM>(circ, work, g, numr, tw, twoff, lane, wr);          // Frngs, then Applyws on the way out of the split step
+    exact_lds_sync<GM>();
     for (int i = lane; i < g.lcirc; i += 64) out[(size_t)r * g.lcirc + i] = circ[i];
 }
 
@@ -152,6 +161,7 @@ __device__ __forceinline__ void finish_params(const DevGeom &g, float sxi, float
 // evaluates it: samples, Normalize_ring, Frngs, the q or t spectrum, and the 7 CCF samples around bin `jtot` in f64.  The f32
 // search may have stopped one bin beside the f64 maximum of a flat peak: the window is re-centred on its own maximum (">=":
 // the last of equal values, as the CPU scan) until the peak sits in the middle.  Wave-uniform results.
+template <bool GM>
 __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__restrict__ numr, const float *__restrict__ tw,
                                                 const int *__restrict__ twoff, const float *__restrict__ img,
                                                 const float *__restrict__ c1, int bs, float sxi, float syi, bool mir, int &jtot,
@@ -160,7 +170,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 #pragma clang fp contract(off)
     const float cx = ((float)g.cnx + sxi) + g.shift_x[bs], cy = ((float)g.cnx + syi) + g.shift_y[bs];
     double av = 0.0, sq = 0.0;
-    __syncthreads();
+    exact_lds_sync<GM>();
     for (int i0 = lane; i0 < g.lcirc; i0 += 256) {          // four samples per trip: their 16 image taps are in flight together
         float v[4], w[4];
 #pragma unroll
@@ -181,12 +191,12 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
         const float nn = g.nn_weight, avf = (float)av, sqf = (float)sq;
         const float avg = avf / nn;
         const float sgm = sqrtf((sqf - avf * avf / nn) / nn);
-        __syncthreads();
+        exact_lds_sync<GM>();
         for (int i = lane; i < g.lcirc; i += 64) { float v = circ[i]; v -= avg; v /= sgm; circ[i] = v; }
     }
-    __syncthreads();
-    exact_frngs(circ, work, g, numr, tw, twoff, lane, nullptr);
-    __syncthreads();
+    exact_lds_sync<GM>();
+    exact_frngs<GM>(circ, work, g, numr, tw, twoff, lane, nullptr);
+    exact_lds_sync<GM>();
     // Crosrng_ms: q (straight) or t (mirrored) spectrum, f32 products, f64 sums over the rings in ring order
     const int N = g.maxrin;
     double *spec = reinterpret_cast<double *>(work);          // [N] doubles (the FFT work space is free again: N <= lcirc / 2)
@@ -225,7 +235,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
         }
         spec[j] = s0; spec[j + 1] = s1;
     }
-    __syncthreads();
+    exact_lds_sync<GM>();
     // 7 samples of the inverse real transform around the peak: x[m] = (X0 + (-1)^m X_{N/2} + 2 sum_k Re(X_k e^{+2 pi i k m / N})) / N
     for (int trip = 0; trip < 4; trip++) {
 #pragma unroll
@@ -264,31 +274,36 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 }
 
 // refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls, state: of the chunk (indexed by rec.p)
+// GM: the flagged particles are dealt to gridDim.x waves (each with 2 lcirc floats of global scratch in gscr)
+template <bool GM>
 __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ tw,
                                                            const int *__restrict__ twoff, const float *__restrict__ particles,
                                                            const float *__restrict__ refx, const RefineRec *__restrict__ list,
                                                            const int *__restrict__ count, ra_result *__restrict__ res,
-                                                           const int *__restrict__ cls, float *__restrict__ state)
+                                                           const int *__restrict__ cls, float *__restrict__ state,
+                                                           float *__restrict__ gscr)
 {
 #pragma clang fp contract(off)
-    if ((int)blockIdx.x >= *count) return;
     extern __shared__ float lds[];
-    const RefineRec rec = list[blockIdx.x];
     const int lane = threadIdx.x;
-    float *circ = lds, *work = lds + g.lcirc;
+    float *circ, *work;
+    if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
+    else { circ = lds; work = lds + g.lcirc; }
+    for (int item = blockIdx.x; item < *count; item += gridDim.x) {
+    const RefineRec rec = list[item];
     const float *img = particles + (size_t)rec.p * g.nx * g.nx;
     const float *cbase = refx + (cls ? (size_t)cls[rec.p] * g.lcirc : (size_t)0);      // class-resident mode: the particle's own class
     int ref = rec.ref, mirror = rec.mirror, jtot = rec.jtot, bs = rec.bs;
     double b[7];
-    exact_candidate(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
-                    circ, work, lane);
+    exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
+                        circ, work, lane);
     if (rec.bs2 >= 0) {
         // a second record within RA_TIE_RTOL of the winner: both peaks in the CPU path's arithmetic, and its order of the scan --
         // offsets, then references, ascending, a later candidate wins with ">="; straight beats mirrored on equality
         int jt2 = rec.jtot2;
         double b2[7];
-        exact_candidate(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
-                        rec.mirror2 != 0, jt2, b2, circ, work, lane);
+        exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
+                            rec.mirror2 != 0, jt2, b2, circ, work, lane);
         const long long o1 = ((long long)bs << 32) | ((long long)(rec.rt2 & 0xffff) << 16) | (unsigned)ref;
         const long long o2 = ((long long)rec.bs2 << 32) | ((long long)(rec.rt2 >> 16) << 16) | (unsigned)rec.ref2;
         bool second_wins;
@@ -315,6 +330,7 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
             state[2 * rec.p + 1] = rec.syi + g.shift_y[bs];
         }
         res[rec.p] = r;
+    }
     }
 }
 

@@ -97,6 +97,20 @@ class ClassSumBuffer:
         return self
 
 
+def broadcast(t, src=0):
+    """in-place broadcast of tensor `t` from rank `src` (bcast_EMData_to_all, test_mref_gpu_align.py:572-575); under the gloo
+    rehearsal of several ranks on one GPU the collective runs on a host copy, like ClassSumBuffer.all_reduce"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

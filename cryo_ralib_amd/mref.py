@@ -118,9 +118,8 @@ class MrefAligner:
         for j in vanished:
             # "if vanished, put a random image (only from main node!) there" (:523-528)
             k = self.rng.randint(0, self.n - 1)
-            img = self.particles[k].clone()
-            if dist.dist.is_initialized() and dist.dist.get_world_size() > 1:
-                dist.dist.broadcast(img, src=self.main_node)
+            img = self.particles[min(k, self.n - 1)].clone()       # (other ranks: any image of the right shape, overwritten)
+            dist.broadcast(img, src=self.main_node)
             self.refs[j].copy_(img)
 
     def reduce_and_update(self, user_func=None, center=1):

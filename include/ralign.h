@@ -174,9 +174,13 @@ int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
  * second difference c3 amplifies the f32-vs-f64 difference of the 7 CCF samples around a FLAT peak into degrees.  Particles
  * whose |c3| < threshold x max |b| get their 7 samples re-evaluated with the CPU path's own arithmetic (bilinear samples,
  * fftr_q's radix-2 ring FFTs in f32, f64 accumulation of the ring products, f64 inverse) and alpha / sx / sy rewritten.
+ * With the refinement on (threshold != 0), float ties are decided the same way: a neighbouring angular bin, another search
+ * offset or another reference whose f32 peak lies within 3e-6 (relative) of the winner's is re-evaluated too, and the CPU
+ * path's ">=" order picks the integer assignment (angle_bin, shift_idx, ref_id, mirror, peak and d_state follow).
  * threshold < 0: every particle (+25 % of a headline iteration); 0: off; default 0.02 -- no measurable cost, no particle
  * beyond 2e-3 degrees of the CPU path on any tested workload (environment RALIGN_REFINE overrides the default).  Call before
- * ra_set_references.  RA_ERR_STATE when the geometry's rings exceed the LDS (large boxes: not refined). */
+ * ra_set_references.  Geometries whose rings exceed the LDS (256 x 256 / ou = 120: 271 KB per offset) run the same kernels on
+ * global scratch.  RA_ERR_STATE only when the ring layout has an odd length (never with Numrinit's powers of two). */
 int  ra_set_refine(ra_engine *e, float threshold);
 /* the reference's state round trip: rebuild the shift the next search starts from (d_state [n][2]) from the float32
  * parameters of the previous iteration in d_result -- inverse_transform2(alpha, sx, sy) in RA_MODE_MREF

@@ -66,3 +66,84 @@ def test_two_ranks_class_sum_exchange(tmp_path, backend):
     s1 = al.buf.sums.cpu().numpy()
     assert np.abs(s1 - a["sums"]).max() <= 4e-6 * np.abs(s1).max()       # n float additions re-associated once
     al.close()
+
+
+def _worker_loop(rank, world, port, out_dir, nx, ou, xr, n):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from cryo_ralib_amd import dist as rdist
+    from cryo_ralib_amd.mref import MrefAligner
+    r, local, w = rdist.init_from_env("gloo")
+    parts, refs2 = _vanishing_case(nx, ou, xr, n)
+    lo, hi = rdist.shard_range(n, w, r)
+    al = MrefAligner(parts[lo:hi], refs2, ou, xr, xr, 1.0, device=0, index0=lo, total_nima=n, preprocess=True, myid=r, main_node=0)
+    out = {"lo": lo, "hi": hi}
+    for it in range(2):
+        counts = al.iterate()
+        al.engine.sync()
+        out["counts%d" % it] = counts.copy()
+        out["sums%d" % it] = al.buf.sums.cpu().numpy().copy()
+        out["refs%d" % it] = al.refs.cpu().numpy().copy()
+        out["params%d" % it] = al.params().copy()
+    np.savez(os.path.join(out_dir, "l%d.npz" % r), **out)
+    al.close()
+    torch.distributed.destroy_process_group()
+
+
+def _vanishing_case(nx, ou, xr, n):
+    """two of four references anti-correlated with every particle: their classes stay empty and are re-seeded"""
+    from cryo_ralib_amd import synth
+    refs = synth.make_references(4, nx, ou)
+    parts, _ = synth.make_particles(refs[:2], n, xr, xr, 0.25, ou=ou)
+    refs2 = refs.copy()
+    refs2[2] = -refs[0]; refs2[3] = -refs[1]
+    return parts, refs2
+
+
+@pytest.mark.timeout(600)
+def test_three_ranks_uneven_shards_and_reseed_broadcast(tmp_path):
+    """three ranks rehearsed on one GPU (gloo, collectives staged through host memory) over 61 particles -- shards of 20, 21
+    and 20 (MPI_start_end) -- through two iterations of the host driver in which two classes vanish: the even / odd split
+    follows the GLOBAL particle index (index0), so sums and counts equal the one-rank run's; the re-seeded references are the
+    main node's draw (random.seed(rand_seed); randint(0, nima - 1) over ITS shard, test_mref_gpu_align.py:523-528), broadcast
+    to every rank; all ranks hold identical references afterwards"""
+    import random
+    from cryo_ralib_amd import dist as rdist
+    from cryo_ralib_amd.mref import MrefAligner
+    nx, ou, xr, n, world = 32, 12, 2, 61, 3
+    port = 30100 + (os.getpid() % 200)
+    mp.spawn(_worker_loop, args=(world, port, str(tmp_path), nx, ou, xr, n), nprocs=world, join=True)
+    outs = [np.load(tmp_path / ("l%d.npz" % r)) for r in range(world)]
+    assert [(int(o["lo"]), int(o["hi"])) for o in outs] == [rdist.shard_range(n, world, r) for r in range(world)]
+    assert [int(o["hi"]) - int(o["lo"]) for o in outs] == [20, 21, 20]
+    for it in range(2):
+        for o in outs[1:]:
+            np.testing.assert_array_equal(o["sums%d" % it], outs[0]["sums%d" % it])
+            np.testing.assert_array_equal(o["counts%d" % it], outs[0]["counts%d" % it])
+            np.testing.assert_array_equal(o["refs%d" % it], outs[0]["refs%d" % it])
+        assert outs[0]["counts%d" % it].sum() == n
+    # iteration 0 against one rank over the whole stack
+    parts, refs2 = _vanishing_case(nx, ou, xr, n)
+    al = MrefAligner(parts, refs2, ou, xr, xr, 1.0, preprocess=True)
+    al.search()
+    al.buf.all_reduce()
+    one = al.params()
+    both = np.concatenate([o["params0"] for o in outs])
+    for f in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+        np.testing.assert_array_equal(one[f], both[f])
+    counts = al.buf.counts_i.cpu().numpy()
+    np.testing.assert_array_equal(counts, outs[0]["counts0"])
+    assert (counts[2:] < 4).all() and (counts[:2] >= 4).all()
+    s1 = al.buf.sums.cpu().numpy()
+    assert np.abs(s1 - outs[0]["sums0"]).max() <= 4e-6 * np.abs(s1).max()       # per (class, parity): the same images, re-associated
+    # the re-seeded classes: the main node's particles k0, k1 of its own shard (20 particles), normalised under the mask
+    rng = random.Random(1000)
+    lo0, hi0 = rdist.shard_range(n, world, 0)
+    want = al.refs.clone()
+    for j in (2, 3):
+        want[j] = al.particles[lo0 + rng.randint(0, hi0 - lo0 - 1)]
+    al.refs = want
+    al._normalize_refs([2, 3])
+    np.testing.assert_allclose(outs[0]["refs0"][2:], al.refs[2:].cpu().numpy(), rtol=0, atol=1e-6)
+    al.close()
