@@ -61,6 +61,7 @@ EXPORTED_SYMBOLS = [
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_refine", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
+    "ra_state_from_params_dev", "ra_class_fsc_fit", "ra_filter_references_dev",
 ]
 
 _lib = None
@@ -103,6 +104,9 @@ def load_library(path=None):
     L.ra_align_classes.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
     L.ra_state_from_params.argtypes = [vp, vp, ctypes.c_int, float_ptr, vp]
     L.ra_set_refine.argtypes = [vp, ctypes.c_float]
+    L.ra_state_from_params_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+    L.ra_class_fsc_fit.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp]
+    L.ra_filter_references_dev.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp]
     L.ra_transform_accumulate.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     L.ra_update_references.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.ra_normalize_particles.argtypes = [vp, vp, ctypes.c_int]
@@ -301,6 +305,14 @@ class Engine:
         _check(self.lib.ra_state_from_params(self.handle, self._ptr(result, self.torch.int32), n, csp,
                                              self._ptr(state, self.torch.float32)), "ra_state_from_params")
 
+    def state_from_params_dev(self, result, state, cs_dev):
+        """state_from_params with the centre correction in a CUDA tensor [2] (no host value in the path)"""
+        n = result.shape[0]
+        assert state.shape == (n, 2) and result.shape == (n, 8) and cs_dev.numel() == 2
+        _check(self.lib.ra_state_from_params_dev(self.handle, self._ptr(result, self.torch.int32), n,
+                                                 self._ptr(cs_dev, self.torch.float32), self._ptr(state, self.torch.float32)),
+               "ra_state_from_params_dev")
+
     def set_class_references(self, refs):
         """class-resident mode: one reference per class, [ncls][nx][nx] (ra_set_class_references)"""
         assert refs.shape[1:] == (self.nx, self.nx)
@@ -361,6 +373,26 @@ class Engine:
         _check(self.lib.ra_class_averages(self.handle, self._ptr(sums, self.torch.float32),
                                           self._ptr(counts, self.torch.int32), int(min_count),
                                           self._ptr(refs, self.torch.float32)), "ra_class_averages")
+
+    def class_fsc_fit(self, sums, counts, fit, curve, min_count=4, masked=False, fl_lo=0.12, fl_hi=0.4, aa_hi=0.2):
+        """class_fsc + fit_tanh + the clamps of ref_ali2d on the device: fit [5] and curve [3][fsc_len] are CUDA float tensors the
+        kernels fill (ra_class_fsc_fit); nothing is read back here"""
+        n = self.lib.ra_fsc_len(self.handle)
+        assert fit.numel() >= 5 and curve.numel() >= 3 * n
+        _check(self.lib.ra_class_fsc_fit(self.handle, self._ptr(sums, self.torch.float32), self._ptr(counts, self.torch.int32),
+                                         int(min_count), int(bool(masked)), float(fl_lo), float(fl_hi), float(aa_hi),
+                                         self._ptr(fit, self.torch.float32), self._ptr(curve, self.torch.float32)), "ra_class_fsc_fit")
+
+    def filter_references_dev(self, imgs, flaa=None, center=0, cs_in=None, normalize=True, cs_out=None):
+        """filter_references with (fl, aa), the centres of center = -1 and the applied centres in CUDA tensors; asynchronous"""
+        m = imgs.shape[0]
+        _check(self.lib.ra_filter_references_dev(self.handle, self._ptr(imgs, self.torch.float32), m,
+                                                 self._ptr(flaa, self.torch.float32), int(center), self._ptr(cs_in, self.torch.float32),
+                                                 int(bool(normalize)), self._ptr(cs_out, self.torch.float32)), "ra_filter_references_dev")
+
+    @property
+    def fsc_len(self):
+        return self.lib.ra_fsc_len(self.handle)
 
     def filter_references(self, imgs, fl, aa, center=0, cs_in=None, normalize=True):
         """in place on imgs [m][nx][nx]; returns the applied centres [m][2]"""

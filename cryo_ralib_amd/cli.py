@@ -15,7 +15,7 @@ centring on the device; any other name is rejected.  An optional mask file repla
 .hdf input stack the parameters also go into headers (EMAN.xform.align2d / assign / ID): of a copy of the stack under
 outdir by default, of the input stack itself with --header_writeback (the reference's behaviour).
 Options that would change the result and are not implemented (--CTF, --center 2..5, --random_method, --Fourvar,
---dst != 0, --mode other than F) end the run with an error; --MPI / --EQ select paths with the same results and are only noted.
+--dst != 0, --mode other than F, --randomize, --orient) end the run with an error; --MPI / --EQ select paths with the same results and are only noted.
 """
 import argparse
 import os
@@ -97,6 +97,12 @@ def _reject_unimplemented(args, reffree):
             bad.append("--mode %s (implemented: F, full rings)" % args.mode)
         if args.dst != 0:
             bad.append("--dst %g (angular restriction, Crosrng_ms_delta)" % args.dst)
+        # sub-options of the "friedel" mode (test_reffree_gpu_align.py:933-934): accepted like the reference's parser does,
+        # an error when set -- the reference's driver never reads them, the SPHIRE code they belong to is not on this path
+        if args.randomize:
+            bad.append("--randomize")
+        if args.orient:
+            bad.append("--orient")
     if bad:
         raise SystemExit("not implemented by the MI355X engine: " + "; ".join(bad))
 
@@ -105,6 +111,10 @@ def _write_headers(mdfio, args, params, assign=None, ids=None):
     """xform.align2d / assign / ID headers: into a copy of the stack under outdir (default) or, with --header_writeback,
     into the input stack itself (refused, with the reason, when that would lose header items)"""
     dst = args.stack if args.header_writeback else os.path.join(args.outdir, os.path.basename(args.stack))
+    if not args.header_writeback and os.path.abspath(dst) == os.path.abspath(args.stack):
+        # the input stack lives in outdir: the copy must not replace it behind the user's back
+        stem, ext = os.path.splitext(os.path.basename(args.stack))
+        dst = os.path.join(args.outdir, stem + "_aligned" + ext)
     lost = mdfio.write_alignment_headers(args.stack, dst, params, assign=assign, ids=ids)
     if lost:
         print("warning: %s does not carry the header items %s of %s (types this writer cannot encode)" % (dst, ", ".join(lost), args.stack),
@@ -217,6 +227,7 @@ def main_reffree(argv=None):
     p.add_argument("--nomirror", action="store_true"); p.add_argument("--dst", type=float, default=0.0)
     p.add_argument("--Fourvar", action="store_true"); p.add_argument("--mode", default="F")
     p.add_argument("--random_method", default="")
+    p.add_argument("--randomize", action="store_true"); p.add_argument("--orient", action="store_true")
     p.add_argument("--all_stages", action="store_true", help="run every stage of --xr/--ts lists (SPHIRE ali2d_base); the reference's "
                    "GPU driver runs stage 0 only, which is the default here")
     p.add_argument("--auto_stop", action="store_true", help="with --maxit 0: stop a stage when the criterion decreases (the rule the "
@@ -250,18 +261,14 @@ def main_reffree(argv=None):
         al.set_stage(n_step)
         for _ in range(max_iter):
             it += 1
-            raw = None
-            if rank == 0 and al.iteration > 0:
-                # aqc: the average of this iteration before the user function, (ave1 + ave2) / total_nima (:380-383)
-                raw = ((al.buf.sums[0, 0] + al.buf.sums[0, 1]) / float(al.total_nima)).cpu().numpy()
             a1 = al.iterate(int(args.center), ufunc)
             if rank == 0:
                 print("Iteration #%4d   X range = %5.2f   Y range = %5.2f   Step = %5.2f   Criterion = %15.8e" % ((it,) + al.stages[n_step] + (a1,)))
                 # aqc / aqf: one stack each, image number = iteration (tavg.write_image(".../aqc.hdf", total_iter - 1), :383, :420;
-                # aqc = the average before the user function, aqf = the filtered / centred average the particles are aligned to)
-                if raw is not None:
-                    aqc.append(raw)
-                    stackio.write_stack(os.path.join(args.outdir, "aqc.%s" % args.ext), np.stack(aqc))
+                # aqc = the average REDUCED OVER THE RANKS before the user function, (ave1 + ave2) / total_nima, of every iteration
+                # including the raw sum_oe average of the first; aqf = the filtered / centred average the particles are aligned to)
+                aqc.append(al.raw_avg.cpu().numpy().copy())
+                stackio.write_stack(os.path.join(args.outdir, "aqc.%s" % args.ext), np.stack(aqc))
                 aqf.append(al.tavg[0].cpu().numpy().copy())
                 stackio.write_stack(os.path.join(args.outdir, "aqf.%s" % args.ext), np.stack(aqf))
                 if al.pixel_errors:

@@ -470,7 +470,9 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.refspec_floats = (size_t)cfg.nref * g.lring;
     w.b_floats = (size_t)nrtile * g.LBP * 16;
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
-    w.zscr_recs = generic ? (size_t)512 * RA_GCCF_ZPAIRS_MAX * g.maxrin : 0;
+    // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup (x 14 only for the 2 x 7 blocks of RALIGN_GCCF_TM=2)
+    const bool wide2 = getenv("RALIGN_GCCF_TM") && atoi(getenv("RALIGN_GCCF_TM")) == 2;
+    w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * g.maxrin : 0;
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
@@ -481,7 +483,17 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     const size_t fcand = (size_t)chunk * g.nshift_pad + 8;
     const size_t search_ws = resident ? bf * (sizeof(float) + sizeof(int)) + fcand * sizeof(CandT)      // B stream + its gather table
                                       : w.a_floats * sizeof(float) + (w.cand_recs + fcand) * sizeof(CandT);
-    w.bytes = (w.refspec_floats + w.b_floats + w.alscratch_floats + 2) * sizeof(float) + search_ws +
+    // rot_shift2D + class sums: member lists, per-run partial sums and cos / sin of a batch (transform_sum_kernel), or -- images
+    // that do not fit the LDS -- the aligned images of a chunk, their member lists and 16 runs of partial sums
+    const size_t npix = (size_t)g.nx * g.nx, nseg = 2 * (size_t)cfg.nref;
+    const bool xs = (size_t)(g.nx + 2) * ((g.nx + 2) | 1) * sizeof(float) <= 64 * 1024 && g.nx <= 1024;
+    const size_t sums_ws = xs ? nseg * chunk * sizeof(int) + std::min<size_t>(512, (1024 + nseg - 1) / nseg) * nseg * npix * sizeof(float) + (size_t)chunk * sizeof(float2)
+                              : w.alscratch_floats * sizeof(float) + nseg * chunk * sizeof(int) + 16 * nseg * npix * sizeof(float);
+    // sub-bin refinement (ralign_exact.h): exact reference spectra, the list of flagged particles, global ring buffers of large boxes
+    const size_t lds_ref = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float);
+    const size_t exact_ws = (size_t)cfg.nref * g.lcirc * sizeof(float) + (size_t)chunk * sizeof(RefineRec) +
+                            (lds_ref > 160 * 1024 - 256 ? (size_t)std::max(256, cfg.nref) * 2 * g.lcirc * sizeof(float) : 0);
+    w.bytes = (w.refspec_floats + w.b_floats + 2) * sizeof(float) + search_ws + sums_ws + exact_ws +
               w.zscr_recs * sizeof(float2) + refine + tables;
     // every hipMalloc is rounded up to the allocator's granule; ~40 small tables and buffers
     w.bytes += (size_t)48 * (2 << 20);
@@ -856,6 +868,7 @@ extern "C" int ra_set_refine(ra_engine *e, float threshold)
     if (!e) return RA_ERR_ARG;
     e->refine_thr = threshold;
     e->refs_ready = false;             // the exact reference spectra are prepared by ra_set_references when the refinement is on
+    e->cls_ready = 0;                  // ... and those of the class-resident mode by ra_set_class_references
     return e->refine_ok || threshold == 0.f ? RA_OK : RA_ERR_STATE;
 }
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
@@ -1038,6 +1051,18 @@ extern "C" int ra_state_from_params(ra_engine *e, const ra_result *d_result, int
     const float zero[2] = {0.f, 0.f};
     RA_HIP(hipMemcpyAsync(e->d_cs, cs ? cs : zero, 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(state_from_params_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->cfg.mode, (const float *)e->d_cs, d_result, d_state);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+// the same with the centre correction in device memory (d_cs [2], e.g. the reduced shift sums of the average-centre rule
+// divided by the particle count on the device): no host value, no copy
+extern "C" int ra_state_from_params_dev(ra_engine *e, const ra_result *d_result, int n, const float *d_cs, float *d_state)
+{
+    if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    if (n == 0) return RA_OK;
+    if (!d_result || !d_state || !d_cs) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    hipLaunchKernelGGL(state_from_params_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->cfg.mode, d_cs, d_result, d_state);
     RA_HIP(hipGetLastError());
     return RA_OK;
 }
@@ -1448,10 +1473,10 @@ static int forward_dft(ra_engine *e, const float *d_imgs, int nimg, const float 
 
 extern "C" int ra_fsc_len(const ra_engine *e) { return e ? e->geo.nx / 2 + 1 : RA_ERR_ARG; }
 
-extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked, float *h_fsc)
+// fsc / fsc_mask of the even and odd sum of every class: e->d_rffsc [nref][2][nx/2+1] = {fsc, points per shell}
+static int class_fsc_kernels(ra_engine *e, const float *d_sums, int masked)
 {
-    if (!e || !d_sums || !d_counts || !h_fsc) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    const int R = e->cfg.nref, nx = e->geo.nx, len = nx / 2 + 1;
+    const int R = e->cfg.nref, nx = e->geo.nx;
     int rc = ensure_refine_ws(e, 2 * R);
     if (rc) return rc;
     if (masked) {
@@ -1459,16 +1484,40 @@ extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_coun
         RA_HIP(hipGetLastError());
     }
     if ((rc = forward_dft(e, d_sums, 2 * R, masked ? e->dg.mask : nullptr, masked ? e->d_rfmean : nullptr))) return rc;
-    {
-        // as many row parts per shell as 1024 threads and 60 KB of LDS allow
-        const int len = nx / 2 + 1;
-        int nparts = std::max(1, RA_FSC_THREADS / len);
-        while (nparts > 1 && (size_t)nparts * len * 4 * sizeof(double) > 60 * 1024) nparts--;
-        const int threads = std::min(RA_FSC_THREADS, nparts * len);
-        const size_t lds = (size_t)nparts * len * 4 * sizeof(double);
-        hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(threads), lds, e->stream, nx, e->d_rfF, e->d_rffsc);
-    }
+    // as many row parts per shell as 1024 threads and 60 KB of LDS allow
+    const int len = nx / 2 + 1;
+    int nparts = std::max(1, RA_FSC_THREADS / len);
+    while (nparts > 1 && (size_t)nparts * len * 4 * sizeof(double) > 60 * 1024) nparts--;
+    const int threads = std::min(RA_FSC_THREADS, nparts * len);
+    const size_t lds = (size_t)nparts * len * 4 * sizeof(double);
+    hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(threads), lds, e->stream, nx, e->d_rfF, e->d_rffsc);
     RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+// Average FSC of the live classes and the tangent-filter fit entirely on the device (fsc_fit_kernel): nothing comes back to
+// the host, ra_filter_references_dev takes (fl, aa) from d_fit.  d_fit [5] = {fl, aa clamped, fl, aa fitted, status},
+// d_curve [3][nx/2+1] = {frequency, fsc as fit_tanh leaves it, points}; the caller copies them to the host when it wants them
+// (bookkeeping).  Asynchronous on the engine's stream.
+extern "C" int ra_class_fsc_fit(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked, float fl_lo,
+                                float fl_hi, float aa_hi, float *d_fit, float *d_curve)
+{
+    if (!e || !d_sums || !d_counts || !d_fit || !d_curve) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    int rc = class_fsc_kernels(e, d_sums, masked);
+    if (rc) return rc;
+    const int len = e->geo.nx / 2 + 1;
+    hipLaunchKernelGGL(fsc_fit_kernel, dim3(1), dim3(64), (size_t)len * (sizeof(double) + 2 * sizeof(float)), e->stream, e->geo.nx, e->cfg.nref,
+                       (const float *)e->d_rffsc, d_counts, min_count, fl_lo, fl_hi, aa_hi, d_fit, d_curve);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
+extern "C" int ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked, float *h_fsc)
+{
+    if (!e || !d_sums || !d_counts || !h_fsc) { g_last_error = "null argument"; return RA_ERR_ARG; }
+    const int R = e->cfg.nref, nx = e->geo.nx, len = nx / 2 + 1;
+    int rc = class_fsc_kernels(e, d_sums, masked);
+    if (rc) return rc;
     std::vector<float> all((size_t)R * 2 * len);
     std::vector<int> counts(R);
     RA_HIP(hipMemcpyAsync(all.data(), e->d_rffsc, all.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -1588,18 +1637,16 @@ extern "C" int ra_class_averages(ra_engine *e, const float *d_sums, const int *d
     return RA_OK;
 }
 
-extern "C" int ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
-                                    const float *h_cs_in, int normalize, float *h_cs_out)
+// filt_tanl + center_2D + (normalize.mask) of nimg images in place; fl / aa by value or (d_flaa != null) from device memory;
+// centres: center = -1 reads d_cs_in [nimg][2] (device), the applied centres land in e->d_rfcs
+static int filter_references_core(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, const float *d_flaa, int center,
+                                  const float *d_cs_in, int normalize)
 {
-    if (!e || !d_imgs || nimg < 1) { g_last_error = "bad argument"; return RA_ERR_ARG; }
-    if (center == -1 && !h_cs_in) { g_last_error = "center = -1 needs the shift list"; return RA_ERR_ARG; }
     const int nx = e->geo.nx;
-    int rc = ensure_refine_ws(e, nimg);
-    if (rc) return rc;
-    if (center == -1) RA_HIP(hipMemcpyAsync(e->d_rfcs, h_cs_in, (size_t)nimg * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc;
     if ((rc = forward_dft(e, d_imgs, nimg, nullptr, nullptr))) return rc;
     hipLaunchKernelGGL(filter_center_kernel, dim3(nimg), dim3(256), 0, e->stream, nx, e->d_rfF, fl, aa, center,
-                       center == -1 ? e->d_rfcs : (const float *)nullptr, e->d_rfcs);
+                       center == -1 ? d_cs_in : (const float *)nullptr, e->d_rfcs, d_flaa);
     RA_HIP(hipGetLastError());
     hipLaunchKernelGGL(dft_cols_kernel<1>, dim3(nimg, nx), dim3(64), 0, e->stream, nx, e->d_rfF, e->d_rftw, e->d_rfT);
     RA_HIP(hipGetLastError());
@@ -1609,10 +1656,36 @@ extern "C" int ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float
         hipLaunchKernelGGL(normalize_mask_kernel, dim3(nimg), dim3(256), 0, e->stream, nx * nx, e->dg.mask, d_imgs);
         RA_HIP(hipGetLastError());
     }
+    return RA_OK;
+}
+
+extern "C" int ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
+                                    const float *h_cs_in, int normalize, float *h_cs_out)
+{
+    if (!e || !d_imgs || nimg < 1) { g_last_error = "bad argument"; return RA_ERR_ARG; }
+    if (center == -1 && !h_cs_in) { g_last_error = "center = -1 needs the shift list"; return RA_ERR_ARG; }
+    int rc = ensure_refine_ws(e, nimg);
+    if (rc) return rc;
+    if (center == -1) RA_HIP(hipMemcpyAsync(e->d_rfcs, h_cs_in, (size_t)nimg * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if ((rc = filter_references_core(e, d_imgs, nimg, fl, aa, nullptr, center, e->d_rfcs, normalize))) return rc;
     if (h_cs_out) {
         RA_HIP(hipMemcpyAsync(h_cs_out, e->d_rfcs, (size_t)nimg * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         RA_HIP(hipStreamSynchronize(e->stream));
     }
+    return RA_OK;
+}
+
+// the same without a host value in the path: (fl, aa) = d_flaa[0..1] (ra_class_fsc_fit's d_fit; null: no filter), the centres
+// of center = -1 from d_cs_in [nimg][2], the applied centres to d_cs_out [nimg][2] (device, may be null).  Asynchronous.
+extern "C" int ra_filter_references_dev(ra_engine *e, float *d_imgs, int nimg, const float *d_flaa, int center,
+                                        const float *d_cs_in, int normalize, float *d_cs_out)
+{
+    if (!e || !d_imgs || nimg < 1) { g_last_error = "bad argument"; return RA_ERR_ARG; }
+    if (center == -1 && !d_cs_in) { g_last_error = "center = -1 needs the shift list"; return RA_ERR_ARG; }
+    int rc = ensure_refine_ws(e, nimg);
+    if (rc) return rc;
+    if ((rc = filter_references_core(e, d_imgs, nimg, 0.f, 0.f, d_flaa, center, d_cs_in, normalize))) return rc;
+    if (d_cs_out) RA_HIP(hipMemcpyAsync(d_cs_out, e->d_rfcs, (size_t)nimg * 2 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     return RA_OK;
 }
 

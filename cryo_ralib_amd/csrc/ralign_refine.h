@@ -139,14 +139,132 @@ __global__ __launch_bounds__(RA_FSC_THREADS) void fsc_kernel(int nx, const doubl
     }
 }
 
+// Average FSC curve of the live classes and sp_filter.fit_tanh(dres, low = 0.1) with sp_utilities.amoeba on the DEVICE, so that
+// the reference update of an iteration needs no host round trip (the host fit is ~210 us of libm tanh between two
+// synchronisations).  One wave; lane i evaluates frequency point i (i + 64, ...) of the objective, the points are summed by
+// index like the host loop (ra_fit_tanh), the simplex logic is the host routine statement for statement, in double.
+// in:  fsc_all [nref][2][len] (fsc_kernel), counts [nref]
+// out: fit = {fl, aa after the caller's clamps fl_lo <= fl <= fl_hi, aa <= aa_hi; fl, aa as fitted; status (0 ok, 1: every class
+//      below min_count)}, curve [3][len] = {frequency, averaged fsc as fit_tanh leaves it (zeroed behind its first drop below
+//      `low`), points per shell of the last live class}: what sp_statistics.fsc returns and test_mref_gpu_align.py:537-548 averages
+__global__ __launch_bounds__(64) void fsc_fit_kernel(int nx, int nref, const float *__restrict__ fsc_all, const int *__restrict__ counts,
+                                                     int min_count, float fl_lo, float fl_hi, float aa_hi, float *__restrict__ fit,
+                                                     float *__restrict__ curve)
+{
+    extern __shared__ double fit_lds[];          // [len] terms of the objective | [len] freq | [len] fsc (floats behind)
+    const int len = nx / 2 + 1, lane = threadIdx.x;
+    double *term = fit_lds;
+    float *freq = reinterpret_cast<float *>(fit_lds + len), *fsc = freq + len;
+    int live = 0, last = -1;
+    for (int j = 0; j < nref; j++)
+        if (counts[j] >= min_count) { live++; last = j; }
+    if (live == 0) {
+        if (lane == 0) { fit[0] = fl_hi; fit[1] = aa_hi; fit[2] = fit[3] = 0.f; fit[4] = 1.f; }
+        return;
+    }
+    // ave_fsc / c_fsc of the reference's loop; kept only if its sum is not 0 (ra_class_fsc)
+    for (int i = lane; i < len; i += 64) {
+        double a = 0.0;
+        for (int j = 0; j < nref; j++)
+            if (counts[j] >= min_count) a += fsc_all[((size_t)j * 2) * len + i];
+        term[i] = a;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < len; i++) tot += term[i];
+    for (int i = lane; i < len; i += 64) {
+        freq[i] = (float)((double)i / (2.0 * (nx / 2)));
+        fsc[i] = (tot != 0.0) ? (float)(term[i] / live) : fsc_all[((size_t)last * 2) * len + i];
+        curve[i] = freq[i];
+        curve[2 * len + i] = fsc_all[((size_t)last * 2 + 1) * len + i];
+    }
+    __syncthreads();
+    const int n = len;
+    const double low = 0.1;
+    // "setzero": everything behind the first i >= 1 with 2 fsc / (1 + fsc) < low
+    int first = n;
+    for (int i = 1; i < n; i++)
+        if (2 * (double)fsc[i] / (1.0 + fsc[i]) < low) { first = i; break; }
+    __syncthreads();
+    for (int i = first + lane; i < n; i += 64) fsc[i] = 0.0f;
+    __syncthreads();
+    double f0 = -1.0;
+    for (int i = 1; i < n - 1; i++)
+        if (2 * (double)fsc[i] / (1.0 + fsc[i]) < 0.5) { f0 = freq[i - 1]; break; }
+    float fl, aa;
+    if (f0 < 0.0) {
+        if (fsc[n - 1] < 0.5f) { fl = 0.5f; aa = 0.2f; } else { fl = 0.49f; aa = 0.1f; }
+    } else {
+        auto func = [&](const double *a) -> double {
+            __syncthreads();
+            if (lane == 0 && fsc[0] < 0.0f) fsc[0] *= -1.0f;
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const double r = fsc[i], f = 2 * r / (1.0 + r);
+                double qt = 0;
+                if (a[0] != 0 && a[1] != 0)
+                    qt = f - 0.5 * (tanh(M_PI * (freq[i] + a[0]) / 2.0 / a[1] / a[0]) - tanh(M_PI * (freq[i] - a[0]) / 2.0 / a[1] / a[0]));
+                term[i] = qt * qt;
+            }
+            __syncthreads();
+            double v = 0.0;
+            for (int i = 0; i < n; i++) v -= term[i];
+            return v;
+        };
+        const double scale[2] = {0.05, 0.05}, ftol = 1.e-4, xtol = 1.e-4;
+        double sx[3][2] = {{f0, 0.1}, {f0 + scale[0], 0.1}, {f0, 0.1 + scale[1]}}, fv[3];
+        for (int i = 0; i < 3; i++) fv[i] = func(sx[i]);
+        int iteration = 0, best = 0;
+        while (true) {
+            int worst = 0; best = 0;
+            for (int i = 0; i < 3; i++) { if (fv[i] > fv[best]) best = i; if (fv[i] < fv[worst]) worst = i; }
+            double pavg[2] = {0, 0};
+            for (int i = 0; i < 3; i++) if (i != worst) { pavg[0] += sx[i][0]; pavg[1] += sx[i][1]; }
+            pavg[0] /= 2; pavg[1] /= 2;
+            const double simscale = (fabs(pavg[0] - sx[worst][0]) / scale[0] + fabs(pavg[1] - sx[worst][1]) / scale[1]) / 2;
+            const double fscale = (fabs(fv[best]) + fabs(fv[worst])) / 2.0;
+            const double frange = fscale != 0.0 ? fabs(fv[best] - fv[worst]) / fscale : 0.0;
+            if ((frange < ftol && simscale < xtol) || iteration >= 500) break;
+            double pnew[2] = {2.0 * pavg[0] - sx[worst][0], 2.0 * pavg[1] - sx[worst][1]};
+            double fnew = func(pnew);
+            if (fnew <= fv[worst]) {           // worse than the worst: shrink towards the best
+                for (int i = 0; i < 3; i++)
+                    if (i != best && i != worst) {
+                        sx[i][0] = 0.5 * sx[best][0] + 0.5 * sx[i][0]; sx[i][1] = 0.5 * sx[best][1] + 0.5 * sx[i][1];
+                        fv[i] = func(sx[i]);
+                    }
+                pnew[0] = 0.5 * sx[best][0] + 0.5 * sx[worst][0]; pnew[1] = 0.5 * sx[best][1] + 0.5 * sx[worst][1];
+                fnew = func(pnew);
+            } else if (fnew >= fv[best]) {     // better than the best: try to expand
+                double p2[2] = {3.0 * pavg[0] - 2.0 * sx[worst][0], 3.0 * pavg[1] - 2.0 * sx[worst][1]};
+                const double f2 = func(p2);
+                if (f2 > fnew) { pnew[0] = p2[0]; pnew[1] = p2[1]; fnew = f2; }
+            }
+            sx[worst][0] = pnew[0]; sx[worst][1] = pnew[1]; fv[worst] = fnew;
+            iteration++;
+        }
+        fl = (float)sx[best][0]; aa = (float)sx[best][1];
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) curve[len + i] = fsc[i];
+    if (lane == 0) {
+        fit[2] = fl; fit[3] = aa; fit[4] = 0.f;
+        // the clamps of sp_user_functions.ref_ali2d (aa = min(aa, 0.2); fl = max(min(0.4, fl), 0.12); notebook/00 log)
+        fit[1] = fminf(aa, aa_hi);
+        fit[0] = fmaxf(fminf(fl_hi, fl), fl_lo);
+    }
+}
+
 // filt_tanl on the half spectrum, then center_2D: center = 1 -> phase_cog of the FILTERED image read off
 // its (0,1) and (1,0) Fourier coefficients, center = -1 -> the shift cs_in (average-centre rule of the
 // reference-free driver), center = 0 -> none; the shift by -cs is applied as a phase ramp (fshift).
+// flaa != null: fl, aa = flaa[0], flaa[1] (device memory: fsc_fit_kernel's result)
 __global__ void filter_center_kernel(int nx, double2 *__restrict__ F, float fl, float aa, int center,
-                                     const float *__restrict__ cs_in, float *__restrict__ cs_out)
+                                     const float *__restrict__ cs_in, float *__restrict__ cs_out, const float *__restrict__ flaa)
 {
     __shared__ double cs[2];
     const int nxh = nx / 2 + 1, m = blockIdx.x, tid = threadIdx.x;
+    if (flaa) { fl = flaa[0]; aa = flaa[1]; }
     double2 *f = F + (size_t)m * nx * nxh;
     const double c = M_PI / (2.0 * (double)aa * (double)fl);
     if (fl > 0.f)

@@ -326,7 +326,10 @@ class _Writer:
         if value.dtype.kind == "U":
             value = np.char.encode(value)
         if value.dtype.kind == "S":
-            dt = np.dtype("S%d" % (value.dtype.itemsize + 1))      # room for the terminating NUL (numpy strips trailing NULs)
+            # the longest NUL-stripped value plus its terminating NUL (a value read back from a file already carries the stored
+            # NUL in its itemsize: sizing from itemsize + 1 would grow the type by one byte per round trip)
+            longest = max([len(v) for v in np.atleast_1d(value).ravel().tolist()] + [0])
+            dt = np.dtype("S%d" % (longest + 1))
         elif value.dtype.kind == "f":
             dt = np.dtype("<f8") if value.dtype.itemsize == 8 else np.dtype("<f4")
         elif value.dtype.kind in "iu":
@@ -439,7 +442,8 @@ def write_alignment_headers(src, dst, params, assign=None, ids=None):
     re-encode: attributes of a type it does not decode (variable-length strings such as EMAN.ctf, compounds), attributes
     with more than one dimension, or pixel data that are not float32 -- with dst == src (in-place replacement of the
     user's stack) always, with a new dst unless the attribute can simply be left out there (reported in the return value).
-    Returns the sorted names of the attributes that were NOT carried into a new dst ([] when everything was)."""
+    Returns the sorted names of the attributes that were NOT carried into a new dst ([] when everything was), followed by a
+    note per pixel type that was re-encoded as float32 there."""
     import os
     report = {}
     arr, attrs = read_mdf_stack(src, with_attrs=True, report=report)
@@ -471,7 +475,8 @@ def write_alignment_headers(src, dst, params, assign=None, ids=None):
             os.remove(tmp)
         raise
     os.replace(tmp, dst)
-    return sorted(lost)
+    # pixel data of another type were re-encoded as float32 in the new file: reported with the attributes that were left out
+    return sorted(lost) + ["<pixel data %s re-encoded as float32>" % t for t in sorted(report.get("pixel_types", ()))]
 
 
 def write_mdf_stack(path, arr, extra_attrs=None):

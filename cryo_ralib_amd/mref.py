@@ -20,6 +20,49 @@ import torch
 from . import api, dist, geometry
 
 
+class _Pending:
+    """a device value on its way to the host: copied into pinned memory on the current stream, with an event behind the copy.
+    get() waits for THAT event only (hipEventSynchronize, not a stream synchronisation): kernels queued after the copy keep the
+    GPU busy while the host reads the value."""
+
+    def __init__(self, t):
+        self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.host.copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(t.device))
+
+    def get(self):
+        self.event.synchronize()
+        return self.host.numpy()
+
+
+def _fit_params(a):
+    """(fl, aa) of the device fit as Python floats, with ref_ali2d's clamps in double like the host code they replace
+    (the device applied them in float32: 0.2f is 0.20000000298)"""
+    return max(min(0.4, float(a[0])), 0.12), min(float(a[1]), 0.2)
+
+
+class _Lagged:
+    """per-iteration bookkeeping lists (class sizes, filter parameters, FSC curves, centres) whose entries are read back from
+    the device only when somebody looks at them"""
+
+    def __init__(self):
+        self._done, self._todo = [], []
+
+    def push(self, pending, convert):
+        self._todo.append((pending, convert))
+
+    def append(self, value):
+        self.resolve()
+        self._done.append(value)
+
+    def resolve(self):
+        for pending, convert in self._todo:
+            self._done.append(convert(pending.get()))
+        self._todo = []
+        return self._done
+
+
 class MrefAligner:
     def __init__(self, particles, refs, ou, xr, yr, ts=1.0, ir=1, rs=1, device=0, index0=0, total_nima=None,
                  rand_seed=1000, preprocess=True, chunk=0, myid=0, main_node=0, mask=None, state_roundtrip=True, refine=None):
@@ -57,9 +100,14 @@ class MrefAligner:
         self.buf = dist.ClassSumBuffer(self.nref, self.nx, self.dev)
         self.iteration = 0
         self.rng = random.Random(rand_seed)       # seed(rand_seed) on the main node (:352)
-        self.class_sizes = []
-        self.filter_params, self.fsc_curves, self.centres = [], [], []     # per iteration, user_func="ref_ali2d"
-        self.class_fsc_curves = None
+        self._class_sizes = _Lagged()
+        self._filter_params, self._fsc_curves, self._centres = _Lagged(), _Lagged(), _Lagged()     # per iteration, user_func="ref_ali2d"
+        self._have_class_fsc = False
+        # device-side results of the reference update (ra_class_fsc_fit / ra_filter_references_dev): nothing of it comes back to
+        # the host inside an iteration
+        self._fit = torch.zeros(8, device=self.dev)
+        self._curve = torch.zeros(3 * self.engine.fsc_len, device=self.dev)
+        self._cs_out = torch.zeros((self.nref, 2), device=self.dev)
         if preprocess:
             self._normalize_refs_all()
             self.engine.normalize_particles(self.particles)    # :342
@@ -97,22 +145,27 @@ class MrefAligner:
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
                                          self.buf.counts_i)
 
-    def _ref_ali2d(self, counts, vanished, center):
-        """the default user function on the device: fsc per class (:531), averaged (:537-548),
-        sp_user_functions.ref_ali2d = fit_tanh + clamps + filt_tanl + center_2D(center), normalize.mask (:563)"""
-        if len(vanished) == self.nref:
-            raise api.EngineError("every class vanished: no FSC to fit the filter to")
-        frsc = self.engine.class_fsc(self.buf.sums, self.buf.counts_i, 4, masked=False)
-        self.engine.class_averages(self.buf.sums, self.buf.counts_i, self.refs, 4)
-        self._reseed(vanished)
-        fl, aa = api.fit_tanh(frsc)
-        aa = min(aa, 0.2)
-        fl = max(min(0.4, fl), 0.12)
-        self.filter_params.append((fl, aa))
-        self.fsc_curves.append(frsc)
-        self.class_fsc_curves = self.engine.last_class_fsc()       # per class: what the reference writes to drm%03d%04d.txt (:533)
-        cs = self.engine.filter_references(self.refs, fl, aa, center=1 if center == 1 else 0, normalize=True)
-        self.centres.append(cs)
+    # per-iteration records; read back lazily (the values are device results of iterations that may still be running)
+    @property
+    def class_sizes(self):
+        return self._class_sizes.resolve()
+
+    @property
+    def filter_params(self):
+        return self._filter_params.resolve()
+
+    @property
+    def fsc_curves(self):
+        return self._fsc_curves.resolve()
+
+    @property
+    def centres(self):
+        return self._centres.resolve()
+
+    @property
+    def class_fsc_curves(self):
+        """per class: what the reference writes to drm%03d%04d.txt (:533) for the last iteration (fetched on demand)"""
+        return self.engine.last_class_fsc() if self._have_class_fsc else None
 
     def _reseed(self, vanished):
         for j in vanished:
@@ -123,16 +176,36 @@ class MrefAligner:
             self.refs[j].copy_(img)
 
     def reduce_and_update(self, user_func=None, center=1):
-        """cross-rank sum (:495-499) then the reference update every rank repeats (:517-575)."""
+        """cross-rank sum (:495-499) then the reference update every rank repeats (:517-575).
+
+        No stream synchronisation: the class sizes (vanished-class rule: the reference draws from its RNG only when a class
+        vanished, so the host has to see them) travel to pinned memory behind an event, and the host looks at them after it has
+        queued the kernels that do not depend on them; with user_func="ref_ali2d" the FSC, fit_tanh, its clamps, the filter and
+        the centring stay on the device (ra_class_fsc_fit / ra_filter_references_dev)."""
         self.buf.all_reduce()
-        counts = self.buf.counts_i.cpu().numpy()
-        self.class_sizes.append(counts.copy())
+        pc = _Pending(self.buf.counts_i)
+        if user_func == "ref_ali2d":
+            # the default user function on the device: fsc per class (:531), averaged (:537-548), sp_user_functions.ref_ali2d =
+            # fit_tanh + clamps + filt_tanl + center_2D(center), normalize.mask (:563)
+            self.engine.class_fsc_fit(self.buf.sums, self.buf.counts_i, self._fit, self._curve, 4, masked=False)
+            self.engine.class_averages(self.buf.sums, self.buf.counts_i, self.refs, 4)
+            self._have_class_fsc = True
+        else:
+            self.engine.update_references(self.buf.sums, self.buf.counts_i, self.refs, 4)
+        counts = pc.get().copy()
+        self._class_sizes.append(counts.copy())
         vanished = [j for j in range(self.nref) if counts[j] < 4]
         if user_func == "ref_ali2d":
-            self._ref_ali2d(counts, vanished, center)
+            if len(vanished) == self.nref:
+                raise api.EngineError("every class vanished: no FSC to fit the filter to")
+            self._reseed(vanished)
+            self.engine.filter_references_dev(self.refs, self._fit, center=1 if center == 1 else 0, normalize=True, cs_out=self._cs_out)
+            n = self.engine.fsc_len
+            self._filter_params.push(_Pending(self._fit[:2]), _fit_params)
+            self._fsc_curves.push(_Pending(self._curve), lambda a: [list(map(float, a[:n])), list(map(float, a[n:2 * n])), list(map(float, a[2 * n:3 * n]))])
+            self._centres.push(_Pending(self._cs_out), lambda a: a.copy())
             self.iteration += 1
             return counts
-        self.engine.update_references(self.buf.sums, self.buf.counts_i, self.refs, 4)
         self._reseed(vanished)
         if user_func is not None:
             self.refs = user_func(self.refs, self.buf, counts)
@@ -241,10 +314,13 @@ class RefFreeAligner:
         self.result = self.engine.new_result(self.n)
         self.buf = dist.ClassSumBuffer(1, self.nx, self.dev, extra=2)
         self.tavg = torch.zeros((1, self.nx, self.nx), device=self.dev)
-        self.cs = [0.0, 0.0]
+        self.raw_avg = None
+        self._cs_dev = torch.zeros((1, 2), device=self.dev)      # centre correction of the current iteration (device)
+        self._cs_pending = None
+        self._fit = torch.zeros(8, device=self.dev)
+        self._curve = torch.zeros(3 * self.engine.fsc_len, device=self.dev)
         self.iteration = 0
-        self.criteria = []
-        self.filter_params = []
+        self._criteria, self._filter_params = _Lagged(), _Lagged()
         self.track_pixel_error = False      # the drivers' per-iteration bookkeeping (mirror-consistent count, summed pixel error)
         self.pixel_errors = []
 
@@ -263,45 +339,63 @@ class RefFreeAligner:
         self.buf.sums[0, 1] = self.particles[par == 1].sum(0)
         self.buf.counts_i[0] = self.n
 
+    @property
+    def criteria(self):
+        return self._criteria.resolve()
+
+    @property
+    def filter_params(self):
+        return self._filter_params.resolve()
+
+    @property
+    def cs(self):
+        """centre correction (cs[0], cs[1]) applied in the last iteration"""
+        if self._cs_pending is None:
+            return [0.0, 0.0]
+        a = self._cs_pending.get()
+        return [float(a[0, 0]), float(a[0, 1])]
+
     def iterate(self, center=0, user_func=None):
-        """one iteration of ali2d_base_gpu_isac_CLEAN (:361-540).  user_func="ref_ali2d": fsc_mask (:384),
-        the tangent filter, and the centring of the average (fshift by the average centre for center=-1,
-        :403-410; center_2D method for center > 0) on the device; None keeps the raw average."""
+        """one iteration of ali2d_base_gpu_isac_CLEAN (:361-540).  user_func="ref_ali2d": fsc_mask (:384), fit_tanh and its
+        clamps, the tangent filter, and the centring of the average (fshift by the average centre for center=-1, :403-410;
+        center_2D method for center > 0) on the device; None keeps the raw average.
+
+        Nothing the iteration computes passes through the host: the criterion, the centre and the filter parameters are device
+        values (read back behind events, after the iteration's kernels are queued), so the stream is never synchronised."""
         if self.iteration == 0:
             self._sum_oe_raw()
         self.buf.all_reduce()
         # tavg = (ave1 + ave2) / total_nima (:380); criterion a1 = sum_mask tavg^2 (:396)
         self.tavg[0] = (self.buf.sums[0, 0] + self.buf.sums[0, 1]) / float(self.total_nima)
-        a1 = float((self.tavg[0][self.mask > 0.5] ** 2).sum().item())
-        self.criteria.append(a1)
-        cs = [0.0, 0.0]
+        # the average as reduced over the ranks, before the user function and the centring: what the reference writes to
+        # aqc.hdf at image total_iter - 1 in every iteration, iteration 0 (sum_oe of the raw stack) included (:365-383)
+        self.raw_avg = self.tavg[0].clone()
+        pa1 = _Pending((self.tavg[0][self.mask > 0.5] ** 2).sum().reshape(1))
+        self._cs_dev.zero_()
         if center == -1 and self.iteration > 0:
-            # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410); with user_func the average is
-            # shifted by -cs on the device (fshift), the particle parameters are corrected inside ra_align
-            cs = [float(self.buf.extra_f[0].item()) / self.total_nima, float(self.buf.extra_f[1].item()) / self.total_nima]
+            # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410) in double, rounded to float32 once like the host value
+            # it replaces; with user_func the average is shifted by -cs on the device (fshift), the particle parameters are
+            # corrected inside ra_state_from_params
+            self._cs_dev[0] = (self.buf.extra_f[:2].double() / float(self.total_nima)).float()
         if user_func == "ref_ali2d":
-            frsc = self.engine.class_fsc(self.buf.sums, self.buf.counts_i, 1, masked=True)
-            fl, aa = api.fit_tanh(frsc)
-            aa = min(aa, 0.2)
-            fl = max(min(0.4, fl), 0.12)
-            self.filter_params.append((fl, aa))
+            self.engine.class_fsc_fit(self.buf.sums, self.buf.counts_i, self._fit, self._curve, 1, masked=True)
+            self._filter_params.push(_Pending(self._fit[:2]), _fit_params)
             if center == -1:
-                self.engine.filter_references(self.tavg, fl, aa, center=-1, cs_in=[cs], normalize=False)
+                self.engine.filter_references_dev(self.tavg, self._fit, center=-1, cs_in=self._cs_dev, normalize=False)
             else:
-                got = self.engine.filter_references(self.tavg, fl, aa, center=1 if center == 1 else 0, normalize=False)
-                cs = [float(got[0, 0]), float(got[0, 1])]
-        elif center == -1 and (cs[0] or cs[1]):
+                self.engine.filter_references_dev(self.tavg, self._fit, center=1 if center == 1 else 0, normalize=False, cs_out=self._cs_dev)
+        elif center == -1 and self.iteration > 0:
             # no user function: the average is still shifted by -cs, together with the parameter correction
-            # inside ra_align (fshift(tavg, -cs[0], -cs[1]), test_reffree_gpu_align.py:403-410)
-            self.engine.filter_references(self.tavg, 0.0, 0.0, center=-1, cs_in=[cs], normalize=False)
-        self.cs = cs
+            # (fshift(tavg, -cs[0], -cs[1]), test_reffree_gpu_align.py:403-410)
+            self.engine.filter_references_dev(self.tavg, None, center=-1, cs_in=self._cs_dev, normalize=False)
+        self._cs_pending = _Pending(self._cs_dev)
         old = None
         if self.track_pixel_error and self.iteration > 0:
             old = self.result.clone()                       # old_ali_params (test_reffree_gpu_align.py:833-838)
         self.engine.set_references(self.tavg)
         # ali2d_single_iter: combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0), inverse_transform2 -> sxi, syi
         # (iteration 0: the header parameters are zero, the centre of the first average is not)
-        self.engine.state_from_params(self.result, self.state, cs)
+        self.engine.state_from_params_dev(self.result, self.state, self._cs_dev)
         self.engine.align(self.particles, self.state, self.result, None)
         self.buf.zero_()
         self.engine.transform_accumulate(self.particles, self.result, self.index0, None, self.buf.sums,
@@ -320,6 +414,9 @@ class RefFreeAligner:
             err = (torch.sin(da / 2) * (2 * self.ou + 1)) ** 2 + (o[:, 1] - r[:, 1]).double() ** 2 + (o[:, 2] - r[:, 2]).double() ** 2
             self.pixel_errors.append((int(same.sum().item()), float(err[same].sum().item())))
         self.iteration += 1
+        # the criterion was computed before the search was queued: reading it now costs the GPU nothing
+        a1 = float(pa1.get()[0])
+        self._criteria.append(a1)
         return a1
 
     def params(self):

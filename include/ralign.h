@@ -189,6 +189,8 @@ int  ra_set_refine(ra_engine *e, float threshold);
  * (then without cs) to follow the reference's loop to the rounding of the header values; without it ra_align
  * continues from the exact d_state it left. */
 int  ra_state_from_params(ra_engine *e, const ra_result *d_result, int n, const float *cs, float *d_state);
+/* the same with the centre correction in device memory (d_cs [2]): no host value in the path, nothing to wait for */
+int  ra_state_from_params_dev(ra_engine *e, const ra_result *d_result, int n, const float *d_cs, float *d_state);
 /* class-resident alignment (the ISAC mode behind ref_free_alignment_2D, cuda/gpu_aln_noref.cu:559-782): every particle
  * against the average of its own class, all classes in one launch.  ra_set_class_references prepares ncls references
  * (d_refs [ncls][nx][nx] device); ra_align_classes aligns particle i to reference d_cls[i] (device, [n]); results and
@@ -231,6 +233,12 @@ int  ra_class_fsc(ra_engine *e, const float *d_sums, const int *d_counts, int mi
 int  ra_last_class_fsc(ra_engine *e, float *h_all);
 /* sp_filter.fit_tanh(dres, low=0.1): host arithmetic; fsc is edited in place like the original. */
 int  ra_fit_tanh(const float *freq, float *fsc, int n, float *fl, float *aa);
+/* ra_class_fsc + the average over the live classes + fit_tanh + the clamps of ref_ali2d (fl_lo <= fl <= fl_hi, aa <= aa_hi) on
+ * the DEVICE (test_mref_gpu_align.py:531-548, sp_user_functions.ref_ali2d): d_fit [5] = {fl, aa clamped; fl, aa as fitted;
+ * status (1: every class below min_count)}, d_curve [3][nx/2+1] = {frequency, fsc as fit_tanh leaves it, points per shell}.
+ * Asynchronous, no host round trip: ra_filter_references_dev reads (fl, aa) from d_fit. */
+int  ra_class_fsc_fit(ra_engine *e, const float *d_sums, const int *d_counts, int min_count, int masked, float fl_lo,
+                      float fl_hi, float aa_hi, float *d_fit, float *d_curve);
 /* (even + odd) / count without normalisation (:534-535); classes below min_count untouched */
 int  ra_class_averages(ra_engine *e, const float *d_sums, const int *d_counts, int min_count,
                        float *d_refs);
@@ -240,6 +248,10 @@ int  ra_class_averages(ra_engine *e, const float *d_sums, const int *d_counts, i
  * model_circle(last_ring) if normalize != 0 (:563).  h_cs_out [nimg][2] (may be NULL) = applied centres. */
 int  ra_filter_references(ra_engine *e, float *d_imgs, int nimg, float fl, float aa, int center,
                           const float *h_cs_in, int normalize, float *h_cs_out);
+/* the same with every input in device memory: (fl, aa) = d_flaa[0..1] (NULL: no filter), centres of center = -1 from
+ * d_cs_in [nimg][2], applied centres to d_cs_out [nimg][2] (device, may be NULL).  Asynchronous. */
+int  ra_filter_references_dev(ra_engine *e, float *d_imgs, int nimg, const float *d_flaa, int center,
+                              const float *d_cs_in, int normalize, float *d_cs_out);
 
 /* class-resident mode only (extension, no counterpart in the reference header, where the averages stay in
  * device textures): copy the current class averages [ref_num][nx][nx] to host memory */

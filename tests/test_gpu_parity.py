@@ -623,7 +623,7 @@ def test_command_line_entry_points(tmp_path):
     assert np.loadtxt(out2 / "initial2Dparams.txt").shape == (n, 4)
     # per-iteration artefacts of the reference's drivers: aqc / aqf stacks (reference-free), FSC curves drm%03d%04d.txt and the
     # members of every class in the aqm headers (multi-reference with the default user function)
-    assert stackio.read_stack(str(out2 / "aqf.hdf")).shape == (3, nx, nx) and stackio.read_stack(str(out2 / "aqc.hdf")).shape == (2, nx, nx)
+    assert stackio.read_stack(str(out2 / "aqf.hdf")).shape == (3, nx, nx) and stackio.read_stack(str(out2 / "aqc.hdf")).shape == (3, nx, nx)      # one image per iteration, the first included (:383)
     drm = np.loadtxt(out1 / "drm0020001.txt")
     assert drm.shape == (nx // 2 + 1, 3) and drm[0, 0] == 0.0 and abs(drm[-1, 0] - 0.5) < 1e-6 and np.abs(drm[:, 1]).max() <= 1.0 + 1e-5
     from cryo_ralib_amd import mdfio as _m

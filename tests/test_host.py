@@ -399,9 +399,17 @@ def test_header_write_back_never_loses_header_items(tmp_path, golden_dir):
     assert mdfio.write_alignment_headers(plain, plain, params) == []
     _, at3 = mdfio.read_mdf_stack(plain, with_attrs=True)
     assert bytes(at3[4]["EMAN.source_path"]) == b"a/b.hdf" and list(at3[4]["EMAN.ptcl_source_coord"]) == [3, 4]
+    # ... and a string attribute keeps its stored size over repeated write-backs (value + terminating NUL)
+    size1, size_after_first = at3[4]["EMAN.source_path"].dtype.itemsize, os.path.getsize(plain)
+    for _ in range(3):
+        assert mdfio.write_alignment_headers(plain, plain, params) == []
+    _, at4 = mdfio.read_mdf_stack(plain, with_attrs=True)
+    assert at4[4]["EMAN.source_path"].dtype.itemsize == size1 <= len(b"a/b.hdf") + 1 and bytes(at4[4]["EMAN.source_path"]) == b"a/b.hdf"
+    assert os.path.getsize(plain) == size_after_first
 
 
-@pytest.mark.parametrize("argv", [["--center=3"], ["--CTF"], ["--random_method=SHC"], ["--Fourvar"], ["--mode=H"], ["--dst=90"]])
+@pytest.mark.parametrize("argv", [["--center=3"], ["--CTF"], ["--random_method=SHC"], ["--Fourvar"], ["--mode=H"], ["--dst=90"],
+                                  ["--randomize"], ["--orient"]])
 def test_command_line_rejects_what_the_engine_does_not_implement(argv, tmp_path):
     """options of the reference's command lines that would change the result and are not implemented end the run with an
     error before anything is read or computed (test_reffree_gpu_align.py:918-935, test_mref_gpu_align.py:1146-1152)"""

@@ -147,3 +147,48 @@ def test_three_ranks_uneven_shards_and_reseed_broadcast(tmp_path):
     al._normalize_refs([2, 3])
     np.testing.assert_allclose(outs[0]["refs0"][2:], al.refs[2:].cpu().numpy(), rtol=0, atol=1e-6)
     al.close()
+
+
+def _worker_reffree(rank, world, port, out_dir, nx, ou, xr, n):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from cryo_ralib_amd import dist as rdist, synth
+    from cryo_ralib_amd.mref import RefFreeAligner
+    r, local, w = rdist.init_from_env("gloo")
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    lo, hi = rdist.shard_range(n, w, r)
+    al = RefFreeAligner(parts[lo:hi], ou, xr, xr, 1.0, device=0, index0=lo, total_nima=n)
+    raws = []
+    for it in range(3):
+        al.iterate(-1, "ref_ali2d")
+        raws.append(al.raw_avg.cpu().numpy().copy())
+    np.savez(os.path.join(out_dir, "f%d.npz" % r), raw=np.stack(raws), tavg=al.tavg.cpu().numpy())
+    al.close()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_reference_free_raw_average_is_the_reduced_one(tmp_path):
+    """aqc.hdf holds (ave1 + ave2) / total_nima AFTER reduce_EMData_to_root, for every iteration including the sum_oe average
+    of the first (test_reffree_gpu_align.py:365-383): two ranks (gloo rehearsal on one GPU) keep the same raw average in
+    RefFreeAligner.raw_avg as one rank over the whole stack, on both ranks, in all three iterations"""
+    from cryo_ralib_amd import synth
+    from cryo_ralib_amd.mref import RefFreeAligner
+    nx, ou, xr, n = 32, 12, 2, 75
+    port = 30500 + (os.getpid() % 200)
+    mp.spawn(_worker_reffree, args=(2, port, str(tmp_path), nx, ou, xr, n), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+    np.testing.assert_array_equal(a["raw"], b["raw"])
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    al = RefFreeAligner(parts, ou, xr, xr, 1.0)
+    for it in range(3):
+        al.iterate(-1, "ref_ali2d")
+        one = al.raw_avg.cpu().numpy()
+        assert np.abs(one).max() > 0
+        np.testing.assert_allclose(a["raw"][it], one, rtol=0, atol=2e-5 * np.abs(one).max())
+    # iteration 0's raw average is the plain mean of the stack
+    np.testing.assert_allclose(a["raw"][0], parts.mean(0), rtol=0, atol=1e-5 * np.abs(parts).max())
+    al.close()
