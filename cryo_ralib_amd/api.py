@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_refine", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
-    "ra_state_from_params_dev", "ra_class_fsc_fit", "ra_filter_references_dev",
+    "ra_state_from_params_dev", "ra_class_fsc_fit", "ra_filter_references_dev", "ra_last_refine_count",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def load_library(path=None):
     L.ra_align_classes.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
     L.ra_state_from_params.argtypes = [vp, vp, ctypes.c_int, float_ptr, vp]
     L.ra_set_refine.argtypes = [vp, ctypes.c_float]
+    L.ra_last_refine_count.argtypes = [vp]
     L.ra_state_from_params_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     L.ra_class_fsc_fit.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp]
     L.ra_filter_references_dev.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp]
@@ -304,6 +305,10 @@ class Engine:
             csp = (ctypes.c_float * 2)(float(cs[0]), float(cs[1]))
         _check(self.lib.ra_state_from_params(self.handle, self._ptr(result, self.torch.int32), n, csp,
                                              self._ptr(state, self.torch.float32)), "ra_state_from_params")
+
+    def last_refine_count(self):
+        """particles the last search launch re-evaluated in the CPU path's arithmetic (diagnostics; synchronises)"""
+        return self.lib.ra_last_refine_count(self.handle)
 
     def state_from_params_dev(self, result, state, cs_dev):
         """state_from_params with the centre correction in a CUDA tensor [2] (no host value in the path)"""

@@ -94,6 +94,7 @@ struct ra_engine {
     int rf_cap = 0;                     // images the workspace holds
     double2 *d_rfT = nullptr, *d_rfF = nullptr, *d_rftw = nullptr;
     float *d_rfmean = nullptr, *d_rffsc = nullptr, *d_rfcs = nullptr;
+    const int *d_fsc_off = nullptr, *d_fsc_idx = nullptr;      // coefficients of every Fourier shell (fsc_shell_table)
     bool refs_ready = false;
     // particle-resident search kernel (ralign_fused.h)
     FusedPlanHost fplan;
@@ -653,11 +654,11 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
     if (refine) {
         const int grid = std::min(cn, e->refine_grid);
         if (e->refine_gm)
-            hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(64), 0, e->stream, e->dg, (const int *)e->d_numr,
+            hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(RA_EXACT_THREADS), 0, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
                                res, cls, st, e->d_rscratch);
         else
-            hipLaunchKernelGGL(refine_winner_kernel<false>, dim3(grid), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+            hipLaunchKernelGGL(refine_winner_kernel<false>, dim3(grid), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
                                res, cls, st, (float *)nullptr);
         RA_HIP(hipGetLastError());
@@ -871,6 +872,15 @@ extern "C" int ra_set_refine(ra_engine *e, float threshold)
     e->cls_ready = 0;                  // ... and those of the class-resident mode by ra_set_class_references
     return e->refine_ok || threshold == 0.f ? RA_OK : RA_ERR_STATE;
 }
+// particles the last search launch handed to refine_winner_kernel (flat peaks and float ties); synchronises the stream
+extern "C" int ra_last_refine_count(ra_engine *e)
+{
+    if (!e) return RA_ERR_ARG;
+    if (!e->refine_ok || !e->d_rcount) return 0;
+    int h = 0;
+    if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&h, e->d_rcount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return RA_ERR_HIP;
+    return h;
+}
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
@@ -935,10 +945,10 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     }
     if (e->refine_ok && e->refine_thr != 0.f) {        // the same references with the CPU path's arithmetic, for the sub-bin angle refinement
         if (e->refine_gm)
-            hipLaunchKernelGGL(refspec_exact_kernel<true>, dim3(e->cfg.nref), dim3(64), 0, e->stream, e->dg, (const int *)e->d_numr,
+            hipLaunchKernelGGL(refspec_exact_kernel<true>, dim3(e->cfg.nref), dim3(RA_EXACT_THREADS), 0, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx, e->d_rscratch);
         else
-            hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(e->cfg.nref), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+            hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(e->cfg.nref), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx, (float *)nullptr);
         RA_HIP(hipGetLastError());
     }
@@ -1098,7 +1108,7 @@ extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int nc
                        (const float *)e->d_cls_refspec, 1, e->d_cls_Bf);
     RA_HIP(hipGetLastError());
     if (e->refine_ok && e->refine_thr != 0.f && e->d_cls_refx) {
-        hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(ncls), dim3(64), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
+        hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(ncls), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                            (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, ncls, e->d_cls_refx, (float *)nullptr);
         RA_HIP(hipGetLastError());
     }
@@ -1484,13 +1494,18 @@ static int class_fsc_kernels(ra_engine *e, const float *d_sums, int masked)
         RA_HIP(hipGetLastError());
     }
     if ((rc = forward_dft(e, d_sums, 2 * R, masked ? e->dg.mask : nullptr, masked ? e->d_rfmean : nullptr))) return rc;
-    // as many row parts per shell as 1024 threads and 60 KB of LDS allow
     const int len = nx / 2 + 1;
-    int nparts = std::max(1, RA_FSC_THREADS / len);
-    while (nparts > 1 && (size_t)nparts * len * 4 * sizeof(double) > 60 * 1024) nparts--;
-    const int threads = std::min(RA_FSC_THREADS, nparts * len);
-    const size_t lds = (size_t)nparts * len * 4 * sizeof(double);
-    hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(threads), lds, e->stream, nx, e->d_rfF, e->d_rffsc);
+    if (!e->d_fsc_off) {          // the coefficients of every shell, in scan order
+        std::vector<int> off, idx;
+        fsc_shell_table(nx, off, idx);
+        const int *p0 = nullptr, *p1 = nullptr;
+        if ((rc = upload(e, off, &p0)) || (rc = upload(e, idx, &p1))) return rc;
+        e->d_fsc_off = p0; e->d_fsc_idx = p1;
+    }
+    const int threads = std::min(1024, (RA_FSC_PARTS * len + 63) / 64 * 64);
+    const size_t lds = (size_t)RA_FSC_PARTS * len * 4 * sizeof(double);
+    if (lds > 64 * 1024) RA_HIP(hipFuncSetAttribute((const void *)fsc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fsc_kernel, dim3(R), dim3(threads), lds, e->stream, nx, e->d_rfF, e->d_fsc_off, e->d_fsc_idx, e->d_rffsc);
     RA_HIP(hipGetLastError());
     return RA_OK;
 }

@@ -35,15 +35,25 @@ namespace ralign {
 // are independent of each other, so they are dealt to the lanes without changing a single operation: each of the four
 // 16-lane groups of the wave transforms one ring at a time (rings dealt longest first, round robin), one butterfly per
 // lane and step.  tw + twoff[l] = e^{-2 pi i k / 2^l}, k < 2^(l-1), (float) of the double-precision cos / sin.
-// GM: the ring buffers live in global memory (boxes whose rings exceed the LDS: 271 KB per offset at 256 x 256 / ou = 120);
-// the wave's lanes then hand data to each other through the CU's vector cache: all earlier vector-memory traffic retired too
+// RA_EXACT_THREADS threads (4 waves) work on one image: 16 groups of 16 lanes, one ring per group and step.
+// GM: the ring buffers live in global memory (boxes whose rings exceed the LDS: 271 KB per offset at 256 x 256 / ou = 120); the
+// workgroup's threads then hand data to each other through the CU's vector cache.
+#define RA_EXACT_THREADS 256
 template <bool GM = false> __device__ __forceinline__ void exact_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if constexpr (GM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (GM) __threadfence_block();
+    __syncthreads();
+}
+
+// sum over the workgroup in a fixed order: butterfly inside a wave, the waves in wave order (red: LDS scratch of 4 doubles)
+__device__ __forceinline__ double block_sum_f64(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 template <bool GM = false>
@@ -52,8 +62,8 @@ __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevG
                                             const float *__restrict__ wr /* Applyws weights or null */)
 {
 #pragma clang fp contract(off)
-    const int l16 = lane & 15, grp = lane >> 4;
-    for (int s0 = 0; s0 < g.nring; s0 += 4) {
+    const int l16 = lane & 15, grp = lane >> 4;          // lane = thread of the workgroup: 16 ring groups
+    for (int s0 = 0; s0 < g.nring; s0 += RA_EXACT_THREADS / 16) {
         const int i = g.nring - 1 - (s0 + grp);                 // this group's ring of the slot (rings are sorted by length)
         const bool have = i >= 0;
         const int n = have ? numr[3 * i + 2] : 2, o = have ? numr[3 * i + 1] - 1 : 0, h = n >> 1;
@@ -109,7 +119,7 @@ __device__ __forceinline__ void exact_frngs(float *circ, float *work, const DevG
 // references: Polar2Dm(cnx, cny) -> Frngs -> Applyws with the CPU path's arithmetic, natural (EMAN2) ring layout [lcirc]
 // gscr (GM): [gridDim.x][2 lcirc] floats of global scratch
 template <bool GM>
-__global__ __launch_bounds__(64) void refspec_exact_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ wr,
+__global__ __launch_bounds__(RA_EXACT_THREADS) void refspec_exact_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ wr,
                                                            const float *__restrict__ tw, const int *__restrict__ twoff,
                                                            const float *__restrict__ refs, int nref, float *__restrict__ out,
                                                            float *__restrict__ gscr)
@@ -123,18 +133,11 @@ __global__ __launch_bounds__(64) void refspec_exact_kernel(DevGeom g, const int 
     else { circ = lds; work = lds + g.lcirc; }
     const float *img = refs + (size_t)r * g.nx * g.nx;
     const float c = (float)g.cnx;
-    for (int i = lane; i < g.lcirc; i += 64) circ[i] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
+    for (int i = lane; i < g.lcirc; i += RA_EXACT_THREADS) circ[i] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
     exact_lds_sync<GM>();
     exact_frngs<GM>(circ, work, g, numr, tw, twoff, lane, wr);          // Frngs, then Applyws on the way out of the split step
     exact_lds_sync<GM>();
-    for (int i = lane; i < g.lcirc; i += 64) out[(size_t)r * g.lcirc + i] = circ[i];
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    for (int i = lane; i < g.lcirc; i += RA_EXACT_THREADS) out[(size_t)r * g.lcirc + i] = circ[i];
 }
 
 // tail of finalize_kernel for a given sub-bin position: Util::ang_n (mode F), the ormq shift rotation, combine_params2
@@ -165,34 +168,35 @@ template <bool GM>
 __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__restrict__ numr, const float *__restrict__ tw,
                                                 const int *__restrict__ twoff, const float *__restrict__ img,
                                                 const float *__restrict__ c1, int bs, float sxi, float syi, bool mir, int &jtot,
-                                                double (&b)[7], float *circ, float *work, int lane)
+                                                double (&b)[7], float *circ, float *work, int lane, double *red)
 {
 #pragma clang fp contract(off)
     const float cx = ((float)g.cnx + sxi) + g.shift_x[bs], cy = ((float)g.cnx + syi) + g.shift_y[bs];
     double av = 0.0, sq = 0.0;
     exact_lds_sync<GM>();
-    for (int i0 = lane; i0 < g.lcirc; i0 += 256) {          // four samples per trip: their 16 image taps are in flight together
+    constexpr int T = RA_EXACT_THREADS;
+    for (int i0 = lane; i0 < g.lcirc; i0 += 4 * T) {        // four samples per trip: their 16 image taps are in flight together
         float v[4], w[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = min(i0 + 64 * u, g.lcirc - 1);
+            const int i = min(i0 + T * u, g.lcirc - 1);
             v[u] = bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
             w[u] = g.samp_w[i];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (i0 + 64 * u < g.lcirc) {
-                circ[i0 + 64 * u] = v[u];
+            if (i0 + T * u < g.lcirc) {
+                circ[i0 + T * u] = v[u];
                 av += (double)(v[u] * w[u]); sq += (double)(v[u] * v[u] * w[u]);
             }
     }
     if (g.mode == RA_MODE_MREF) {
-        av = wave_sum_f64(av); sq = wave_sum_f64(sq);
+        av = block_sum_f64(av, red); sq = block_sum_f64(sq, red);
         const float nn = g.nn_weight, avf = (float)av, sqf = (float)sq;
         const float avg = avf / nn;
         const float sgm = sqrtf((sqf - avf * avf / nn) / nn);
         exact_lds_sync<GM>();
-        for (int i = lane; i < g.lcirc; i += 64) { float v = circ[i]; v -= avg; v /= sgm; circ[i] = v; }
+        for (int i = lane; i < g.lcirc; i += T) { float v = circ[i]; v -= avg; v /= sgm; circ[i] = v; }
     }
     exact_lds_sync<GM>();
     exact_frngs<GM>(circ, work, g, numr, tw, twoff, lane, nullptr);
@@ -200,7 +204,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
     // Crosrng_ms: q (straight) or t (mirrored) spectrum, f32 products, f64 sums over the rings in ring order
     const int N = g.maxrin;
     double *spec = reinterpret_cast<double *>(work);          // [N] doubles (the FFT work space is free again: N <= lcirc / 2)
-    for (int j = 2 * lane; j < N; j += 128) {
+    for (int j = 2 * lane; j < N; j += 2 * T) {
         double s0 = 0.0, s1 = 0.0;
         if (j == 0) {
             for (int i = 0; i < g.nring; i++) {
@@ -241,7 +245,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 #pragma unroll
         for (int t = 0; t < 7; t++) b[t] = 0.0;
         const int m0 = jtot - 1;
-        for (int k = 1 + lane; k < N / 2; k += 64) {
+        for (int k = 1 + lane; k < N / 2; k += T) {
             const double xr = spec[2 * k], xi = spec[2 * k + 1];
 #pragma unroll
             for (int t = 0; t < 7; t++) {
@@ -255,7 +259,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
         int kb = 3;
 #pragma unroll
         for (int t = 0; t < 7; t++) {
-            b[t] = wave_sum_f64(b[t]);
+            b[t] = block_sum_f64(b[t], red);
             const int m = (m0 + t - 3 + N) & (N - 1);
             b[t] = (spec[0] + ((m & 1) ? -spec[1] : spec[1]) + 2.0 * b[t]) / (double)N;
         }
@@ -276,7 +280,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 // refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls, state: of the chunk (indexed by rec.p)
 // GM: the flagged particles are dealt to gridDim.x waves (each with 2 lcirc floats of global scratch in gscr)
 template <bool GM>
-__global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ tw,
+__global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom g, const int *__restrict__ numr, const float *__restrict__ tw,
                                                            const int *__restrict__ twoff, const float *__restrict__ particles,
                                                            const float *__restrict__ refx, const RefineRec *__restrict__ list,
                                                            const int *__restrict__ count, ra_result *__restrict__ res,
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
 {
 #pragma clang fp contract(off)
     extern __shared__ float lds[];
+    __shared__ double red[4];
     const int lane = threadIdx.x;
     float *circ, *work;
     if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
@@ -296,14 +301,14 @@ __global__ __launch_bounds__(64) void refine_winner_kernel(DevGeom g, const int 
     int ref = rec.ref, mirror = rec.mirror, jtot = rec.jtot, bs = rec.bs;
     double b[7];
     exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
-                        circ, work, lane);
+                        circ, work, lane, red);
     if (rec.bs2 >= 0) {
         // a second record within RA_TIE_RTOL of the winner: both peaks in the CPU path's arithmetic, and its order of the scan --
         // offsets, then references, ascending, a later candidate wins with ">="; straight beats mirrored on equality
         int jt2 = rec.jtot2;
         double b2[7];
         exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
-                            rec.mirror2 != 0, jt2, b2, circ, work, lane);
+                            rec.mirror2 != 0, jt2, b2, circ, work, lane, red);
         const long long o1 = ((long long)bs << 32) | ((long long)(rec.rt2 & 0xffff) << 16) | (unsigned)ref;
         const long long o2 = ((long long)rec.bs2 << 32) | ((long long)(rec.rt2 >> 16) << 16) | (unsigned)rec.ref2;
         bool second_wins;

@@ -8,6 +8,7 @@
 // Images are small (90^2 ... 256^2) and few (R ... 2R per iteration), so the 2-D transforms are
 // separable direct DFTs with double accumulation -- any image size, no FFT plan, exact to f32.
 #pragma once
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -96,41 +97,51 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(int npix, const float 
 // Fourier shell correlation of image pairs (2c, 2c+1).
 // EMData::calc_fourier_shell_correlation, w = 1: shell = round(inc * sqrt((kx/nx2)^2 + (ky/ny2)^2)),
 // inc = nx/2; the kx = 0 column counts ky >= 0 only.  out[c][0][r] = fsc, out[c][1][r] = points.
-// Thread (part, r) sums shell r over the rows of its part in row order, the parts are added in part order: fixed
-// summation order (bitwise reproducible), blockDim / (inc + 1) times shorter than one thread per shell.
-#define RA_FSC_THREADS 1024
-__global__ __launch_bounds__(RA_FSC_THREADS) void fsc_kernel(int nx, const double2 *__restrict__ F, float *__restrict__ out)
+// shell_off [len + 1], shell_idx: the coefficients (ky * nxh + kx) of every shell in scan order (ky outer, kx inner), built once
+// on the host (fsc_shell_table).  Thread (q, r) sums quarter q of shell r's list in list order, the quarters are added in
+// order: a fixed summation order (bitwise reproducible run to run).
+#define RA_FSC_PARTS 4
+inline void fsc_shell_table(int nx, std::vector<int> &off, std::vector<int> &idx)
 {
-    extern __shared__ double fsc_part[];        // [nparts][len][4]
-    const int nxh = nx / 2 + 1, c = blockIdx.x, inc = nx / 2, len = inc + 1;
-    const double2 *f = F + (size_t)(2 * c) * nx * nxh, *g = f + (size_t)nx * nxh;
+    const int nxh = nx / 2 + 1, inc = nx / 2, len = inc + 1;
     const float d2 = 1.0f / (float)inc / (float)inc;
-    const int nparts = max(1, (int)blockDim.x / len);
-    const int part = nparts > 1 ? threadIdx.x / len : 0, r0 = threadIdx.x - part * len;
-    const int rstep = nparts > 1 ? len : blockDim.x;        // a single part: the threads stride over the shells
-    if (part < nparts)
-    for (int r = r0; r < len; r += rstep) {
-        double ret = 0, n1 = 0, n2 = 0, lr = 0;
-        const int ky0 = (int)((long)nx * part / nparts), ky1 = (int)((long)nx * (part + 1) / nparts);
-        for (int ky = ky0; ky < ky1; ky++) {
-            const int kys = ky > inc ? ky - nx : ky;
-            for (int kx = 0; kx < nxh; kx++) {
-                if (kx == 0 && kys < 0) continue;
-                const float argx = 0.5f * sqrtf((float)(kys * kys) * d2 + (float)(kx * kx) * d2);
-                const int rr = (int)floorf((float)inc * 2.0f * argx + 0.5f);
-                if (rr != r) continue;
-                const double2 a = f[ky * nxh + kx], b = g[ky * nxh + kx];
-                ret += a.x * b.x + a.y * b.y; n1 += a.x * a.x + a.y * a.y; n2 += b.x * b.x + b.y * b.y; lr += 2;
-            }
+    std::vector<std::vector<int>> lists(len);
+    for (int ky = 0; ky < nx; ky++) {
+        const int kys = ky > inc ? ky - nx : ky;
+        for (int kx = 0; kx < nxh; kx++) {
+            if (kx == 0 && kys < 0) continue;
+            const float argx = 0.5f * sqrtf((float)(kys * kys) * d2 + (float)(kx * kx) * d2);
+            const int rr = (int)floorf((float)inc * 2.0f * argx + 0.5f);
+            if (rr < len) lists[rr].push_back(ky * nxh + kx);
         }
-        double *dst = fsc_part + ((size_t)part * len + r) * 4;
+    }
+    off.assign(1, 0); idx.clear();
+    for (int r = 0; r < len; r++) { idx.insert(idx.end(), lists[r].begin(), lists[r].end()); off.push_back((int)idx.size()); }
+}
+
+__global__ void fsc_kernel(int nx, const double2 *__restrict__ F, const int *__restrict__ shell_off, const int *__restrict__ shell_idx,
+                           float *__restrict__ out)
+{
+    extern __shared__ double fsc_part[];        // [RA_FSC_PARTS][len][4]
+    const int nxh = nx / 2 + 1, c = blockIdx.x, len = nx / 2 + 1;
+    const double2 *f = F + (size_t)(2 * c) * nx * nxh, *g = f + (size_t)nx * nxh;
+    for (int t = threadIdx.x; t < RA_FSC_PARTS * len; t += blockDim.x) {
+        const int q = t / len, r = t - q * len;
+        const int o0 = shell_off[r], cnt = shell_off[r + 1] - o0;
+        const int j0 = o0 + cnt * q / RA_FSC_PARTS, j1 = o0 + cnt * (q + 1) / RA_FSC_PARTS;
+        double ret = 0, n1 = 0, n2 = 0, lr = 0;
+        for (int j = j0; j < j1; j++) {
+            const int i = shell_idx[j];
+            const double2 a = f[i], b = g[i];
+            ret += a.x * b.x + a.y * b.y; n1 += a.x * a.x + a.y * a.y; n2 += b.x * b.x + b.y * b.y; lr += 2;
+        }
+        double *dst = fsc_part + ((size_t)q * len + r) * 4;
         dst[0] = ret; dst[1] = n1; dst[2] = n2; dst[3] = lr;
     }
     __syncthreads();
-    if (part == 0)
-    for (int r = r0; r < len; r += rstep) {
+    for (int r = threadIdx.x; r < len; r += blockDim.x) {
         double ret = 0, n1 = 0, n2 = 0, lr = 0;
-        for (int q = 0; q < nparts; q++) {
+        for (int q = 0; q < RA_FSC_PARTS; q++) {
             const double *src = fsc_part + ((size_t)q * len + r) * 4;
             ret += src[0]; n1 += src[1]; n2 += src[2]; lr += src[3];
         }
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(RA_FSC_THREADS) void fsc_kernel(int nx, const doubl
 // Average FSC curve of the live classes and sp_filter.fit_tanh(dres, low = 0.1) with sp_utilities.amoeba on the DEVICE, so that
 // the reference update of an iteration needs no host round trip (the host fit is ~210 us of libm tanh between two
 // synchronisations).  One wave; lane i evaluates frequency point i (i + 64, ...) of the objective, the points are summed by
-// index like the host loop (ra_fit_tanh), the simplex logic is the host routine statement for statement, in double.
+// lane and then over the wave, the simplex logic is the host routine (ra_fit_tanh) statement for statement, in double.
 // in:  fsc_all [nref][2][len] (fsc_kernel), counts [nref]
 // out: fit = {fl, aa after the caller's clamps fl_lo <= fl <= fl_hi, aa <= aa_hi; fl, aa as fitted; status (0 ok, 1: every class
 //      below min_count)}, curve [3][len] = {frequency, averaged fsc as fit_tanh leaves it (zeroed behind its first drop below
@@ -199,16 +210,18 @@ __global__ __launch_bounds__(64) void fsc_fit_kernel(int nx, int nref, const flo
             __syncthreads();
             if (lane == 0 && fsc[0] < 0.0f) fsc[0] *= -1.0f;
             __syncthreads();
+            // (the host sums the points by index; here a lane sums its own and the lanes are added by a butterfly -- the same
+            // terms in another association: the fit agrees with the host's to ~1e-7, its tolerances are 1e-4)
+            double v = 0.0;
             for (int i = lane; i < n; i += 64) {
                 const double r = fsc[i], f = 2 * r / (1.0 + r);
                 double qt = 0;
                 if (a[0] != 0 && a[1] != 0)
                     qt = f - 0.5 * (tanh(M_PI * (freq[i] + a[0]) / 2.0 / a[1] / a[0]) - tanh(M_PI * (freq[i] - a[0]) / 2.0 / a[1] / a[0]));
-                term[i] = qt * qt;
+                v -= qt * qt;
             }
-            __syncthreads();
-            double v = 0.0;
-            for (int i = 0; i < n; i++) v -= term[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             return v;
         };
         const double scale[2] = {0.05, 0.05}, ftol = 1.e-4, xtol = 1.e-4;

@@ -182,6 +182,8 @@ int  ra_align(ra_engine *e, const float *d_particles, int n, float *d_state,
  * ra_set_references.  Geometries whose rings exceed the LDS (256 x 256 / ou = 120: 271 KB per offset) run the same kernels on
  * global scratch.  RA_ERR_STATE only when the ring layout has an odd length (never with Numrinit's powers of two). */
 int  ra_set_refine(ra_engine *e, float threshold);
+/* particles the last search launch re-evaluated (flat peaks and float ties); synchronises the stream (diagnostics) */
+int  ra_last_refine_count(ra_engine *e);
 /* the reference's state round trip: rebuild the shift the next search starts from (d_state [n][2]) from the float32
  * parameters of the previous iteration in d_result -- inverse_transform2(alpha, sx, sy) in RA_MODE_MREF
  * (test_mref_gpu_align.py:1024-1026), combine_params2(alpha, sx, sy, mirror, 0, -cs[0], -cs[1], 0) then
