@@ -790,6 +790,11 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
+        if (g.maxrin == 1024) {
+            const int lds2 = (int)(((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2));
+            if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        }
     }
     if (he == hipSuccess && !e->xf_generic) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
     if (he == hipSuccess) he = hipFuncSetAttribute((const void *)class_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -1217,6 +1222,29 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             hipLaunchKernelGGL((ccf_generic_kernel<2, 7>), dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);
+        else if (e->generic && g.maxrin == 1024 && !(getenv("RALIGN_GCCF_SPLIT") && atoi(getenv("RALIGN_GCCF_SPLIT")) == 0)) {
+            // maxrin 1024: contraction and inverse transforms as two kernels per slice of g_nblk blocks (the scratch holds one slice)
+            const bool wide = gccf_wide_blocks(e->nrtile);
+            const int TMv = wide ? 1 : 2, TRv = wide ? 7 : 2;
+            const int n_mt2 = (n_mtile + TMv - 1) / TMv, n_rt2 = (e->nrtile + TRv - 1) / TRv, ntask = n_mt2 * n_rt2;
+            const size_t lds2 = ((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2);
+            for (int task0 = 0; task0 < ntask; task0 += e->g_nblk) {
+                const int nt = std::min(e->g_nblk, ntask - task0);
+                const int grid2 = std::min(nt * TMv * TRv * 8, 2 * e->n_cu);
+                if (wide) {
+                    hipLaunchKernelGGL((ccf_generic_kernel<1, 7, true>), dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile,
+                                       e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
+                    hipLaunchKernelGGL((gccf_ifft_kernel<1, 7>), dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref,
+                                       Cbuf, (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
+                } else {
+                    hipLaunchKernelGGL((ccf_generic_kernel<2, 2, true>), dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile,
+                                       e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
+                    hipLaunchKernelGGL((gccf_ifft_kernel<2, 2>), dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref,
+                                       Cbuf, (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
+                }
+                RA_HIP(hipGetLastError());
+            }
+        }
         else if (e->generic && gccf_wide_blocks(e->nrtile))
             hipLaunchKernelGGL((ccf_generic_kernel<1, 7>), dim3(std::min(n_mtile, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,

@@ -138,6 +138,88 @@ __device__ __forceinline__ void wave_fft_dif(float2 *x, int h, const float2 *__r
         wave_lds_sync();
     }
 }
+// Inverse FFT of N = R12 * R12 * R3 complex points (1024 = 16 x 16 x 4) by one wave, three register stages with two LDS
+// transposes in between (wave_fft_dif runs five radix-4 stages through the LDS, each with a wave hand-off):
+//   n = R12 R3 n1 + R3 n2 + n3,  k = k1 + R12 k2 + R12^2 k3
+//   A [k1; n2 n3] = sum_n1 x W_R12^{n1 k1},           lane = (n2, n3):   x[64 n1 + lane], then * W_{R12^2}^{n2 k1}
+//   B [k1 k2; n3] = sum_n2 A W_R12^{n2 k2},           lane = (k1, n3):   then * W_N^{n3 (k1 + R12 k2)}
+//   X [k]         = sum_n3 B W_R3^{n3 k3},            lane takes R12^2 / 64 pairs (k1, k2), in place
+// x: the pair's LDS image, rows of 64 complex padded by R3 (row stride 64 + R3: the stride-R3 reads of stage B spread over
+// the banks); the transform ends in the same image, element k in slot ifft3_slot(k) (the 7-point neighbourhood of the peak is
+// read from it).  tw[m] = e^{-2 pi i m / N} (conjugated here: inverse, unscaled).  Running maxima of Re (q) and Im (t) with the
+// largest index winning ties, as ccf_generic_kernel's scan.
+template <int R12, int R3>
+__device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__restrict__ tw, int lane, float &bq, int &iq, float &bt, int &it)
+{
+    constexpr int N = R12 * R12 * R3, RS = 64 + R3, LG3 = R3 == 4 ? 2 : 3;
+    static_assert(R12 * R3 == 64, "one wave: R12 * R3 lanes per stage");
+    float2 v[R12];
+    // ---- stage A: DFT-R12 over n1, twiddle W_{R12^2}^{n2 k1} = W_N^{R3 n2 k1}
+#pragma unroll
+    for (int n1 = 0; n1 < R12; n1++) v[n1] = x[n1 * RS + lane];
+    Dft<1, R12>::run(v);
+    {
+        const int m1 = lane & ~(R3 - 1);            // R3 n2
+#pragma unroll
+        for (int k1 = 1; k1 < R12; k1++) {
+            const float2 w = tw[(m1 * k1) & (N - 1)];
+            v[k1] = cmul(v[k1], make_float2(w.x, -w.y));
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < R12; k1++) x[k1 * RS + lane] = v[k1];
+    wave_lds_sync();
+    // ---- stage B: lane = (k1, n3): DFT-R12 over n2, twiddle W_N^{n3 (k1 + R12 k2)}
+    {
+        const int k1 = lane >> LG3, n3 = lane & (R3 - 1);
+#pragma unroll
+        for (int n2 = 0; n2 < R12; n2++) v[n2] = x[k1 * RS + n2 * R3 + n3];
+        Dft<1, R12>::run(v);
+        const int b0 = n3 * k1, st = n3 * R12;
+#pragma unroll
+        for (int k2 = 0; k2 < R12; k2++) {
+            const float2 w = tw[(b0 + st * k2) & (N - 1)];
+            v[k2] = cmul(v[k2], make_float2(w.x, -w.y));       // n3 = 0: w = 1
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < R12; k2++) x[k1 * RS + k2 * R3 + n3] = v[k2];
+    }
+    wave_lds_sync();
+    // ---- stage C: pair (k1, k2) = (c * 64 + lane) / R12, % R12: DFT-R3 over n3 in place -- X[k1 + R12 k2 + R12^2 k3] takes the
+    // slot of B[k1 k2; n3 = k3] (ifft3_slot) -- and running maxima
+    bq = -1.0e20f; bt = -1.0e20f; iq = -1; it = -1;
+    constexpr int NC = R12 * R12 / 64;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int pr = c * 64 + lane, k1 = pr / R12, k2 = pr % R12;
+        float2 xo[R3];
+#pragma unroll
+        for (int n3 = 0; n3 < R3; n3++) xo[n3] = x[k1 * RS + k2 * R3 + n3];
+        Dft<1, R3>::run(xo);
+#pragma unroll
+        for (int k3 = 0; k3 < R3; k3++) {
+            const int k = k1 + R12 * k2 + R12 * R12 * k3;
+            const float2 z = xo[k3];
+            if (z.x > bq || (z.x == bq && k > iq)) { bq = z.x; iq = k; }
+            if (z.y > bt || (z.y == bt && k > it)) { bt = z.y; it = k; }
+            x[k1 * RS + k2 * R3 + k3] = z;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oq = __shfl_xor(bq, o); const int oiq = __shfl_xor(iq, o);
+        const float ot = __shfl_xor(bt, o); const int oit = __shfl_xor(it, o);
+        if (oq > bq || (oq == bq && oiq > iq)) { bq = oq; iq = oiq; }
+        if (ot > bt || (ot == bt && oit > it)) { bt = ot; it = oit; }
+    }
+    wave_lds_sync();
+}
+// LDS slot of output element k of wave_ifft3_argmax<16, 4> (N = 1024); complex slots per pair of its image
+__device__ __forceinline__ int ifft3_slot(int k) { return (k & 15) * 68 + ((k >> 4) & 15) * 4 + (k >> 8); }
+#define RA_IFFT3_PSTRIDE (16 * 68)
+
 // frequency index held at position p of a wave_fft_dif output of h points, and its inverse
 __device__ __forceinline__ int dif_index_of_pos(int p, int h)
 {
@@ -336,12 +418,16 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 // (45.2 -> 44.2 ms per chunk).  The scratch holds the largest shape.
 #define RA_GCCF_ZPAIRS_MAX (64 * 14)
 inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 7 * 7 - nrtile <= 1; }
-template <int TM, int TR>
+// SPLIT (maxrin 1024): the kernel only contracts -- block task0 + blockIdx.x of the slice [task0, task0 + ntask) of the
+// (mt2, rt2) blocks, spectra to zscr[blockIdx.x] -- and gccf_ifft_kernel transforms the slice afterwards: two kernels with
+// their own register budgets and occupancies instead of two phases that share 128 registers and a barrier.
+template <int TM, int TR, bool SPLIT = false>
 __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
                                                                       float2 *__restrict__ zscr, int P,
-                                                                      const float2 *__restrict__ stats, const float *__restrict__ cdc)
+                                                                      const float2 *__restrict__ stats, const float *__restrict__ cdc,
+                                                                      int task0 = 0, int ntask = 0)
 {
     extern __shared__ __align__(16) float lds[];
     __shared__ CandT pc[64];
@@ -353,12 +439,16 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
     float2 *xb = reinterpret_cast<float2 *>(lds);
     const int pstride = N + 1;              // complex slots per pair: one N-point buffer (in-place transform) + 1 (bank skew)
     float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
-    for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
-    __syncthreads();
+    if constexpr (!SPLIT) {
+        for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
+        __syncthreads();
+    }
 
     const int n_mt2 = (n_mtile + TM - 1) / TM, n_rt2 = (nrtile + TR - 1) / TR;
-    for (int mt2 = blockIdx.x; mt2 < n_mt2; mt2 += gridDim.x) {
-        for (int rt2 = 0; rt2 < n_rt2; rt2++) {
+    const int task = task0 + (int)blockIdx.x;          // SPLIT: one block per workgroup
+    if (SPLIT && (int)blockIdx.x >= ntask) return;
+    for (int mt2 = SPLIT ? task / n_rt2 : (int)blockIdx.x; mt2 < n_mt2; mt2 += SPLIT ? n_mt2 : (int)gridDim.x) {
+        for (int rt2 = SPLIT ? task % n_rt2 : 0; rt2 < n_rt2; rt2 += SPLIT ? n_rt2 : 1) {
             // ---- phase 1: contraction per Fourier bin (operand layout of ccf_kernel), TM x TR tiles per operand fetch
             if (!RA_DBG(g, 2)) {
                 const int r16 = lane & 15, kk = lane >> 4, odd = lane & 1;
@@ -462,6 +552,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                         }
                 }
             }
+            if constexpr (SPLIT) continue;
             __syncthreads();
             // ---- phase 2: inverse FFT + argmax tile by tile, P pairs per batch, one wave per pair
             const int lgp = 31 - __clz(P);
@@ -547,6 +638,77 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                 }
                 __syncthreads();
             }
+        }
+    }
+}
+
+// Second half of the split contraction (maxrin 1024): inverse FFT + argmax + best reference per particle-offset for the blocks
+// [task0, task0 + ntask) whose CCF spectra gccf's SPLIT instantiation left in zscr[task - task0][N][64 TM TR].  A batch = the 8
+// references of one particle-offset of one 8 x 8 tile (8 consecutive pairs: one 64-byte piece per Fourier bin of the scratch):
+// scratch -> LDS (row-padded images of wave_ifft3_argmax), one transform per wave in registers, the batch's best reference
+// (ascending, ">=": later wins) scaled by 1/sigma to `cand`.  Persistent workgroups walk the batches; two per CU.
+template <int TM, int TR>
+__global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g, int n_mtile, int nrtile, int nref, CandT *__restrict__ cand,
+                                                                    const float2 *__restrict__ zscr, const float2 *__restrict__ stats,
+                                                                    int task0, int ntask)
+{
+    extern __shared__ __align__(16) float lds[];
+    __shared__ CandT pc[8];
+    constexpr int N = 1024, ZPAIRS = 64 * TM * TR, NW = RA_GCCF_THREADS / 64, PS = RA_IFFT3_PSTRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *xb = reinterpret_cast<float2 *>(lds);             // [8 pairs][PS]
+    float2 *tw_s = xb + (size_t)NW * PS;
+    for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
+    const int n_rt2 = (nrtile + TR - 1) / TR;
+    const int nbatch = ntask * TM * TR * 8;
+    for (int bt_ = blockIdx.x; bt_ < nbatch; bt_ += gridDim.x) {
+        const int tl = bt_ / (TM * TR * 8), rem = bt_ - tl * (TM * TR * 8), sub = rem >> 3, o = rem & 7;
+        const int task = task0 + tl, mt2 = task / n_rt2, rt2 = task - mt2 * n_rt2;
+        const int mtile = TM * mt2 + sub / TR, rtile = TR * rt2 + sub % TR;
+        if (mtile >= n_mtile || rtile >= nrtile) continue;          // uniform over the workgroup
+        const int ref0 = rtile * g.rpt, nvalid = min(g.rpt, nref - ref0);
+        // scratch [k][pairs] -> LDS [pair][k]: pairs sub * 64 + 8 o .. + 7 are 64 contiguous bytes per bin
+        const float2 *src = zscr + (size_t)tl * ZPAIRS * N + sub * 64 + 8 * o;
+        __syncthreads();                                   // the previous batch's records and images are consumed
+#pragma unroll
+        for (int u0 = 0; u0 < 8 * N; u0 += 8 * RA_GCCF_THREADS) {
+            float2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = u0 + u * RA_GCCF_THREADS + tid;
+                t[u] = src[(size_t)(idx >> 3) * ZPAIRS + (idx & 7)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = u0 + u * RA_GCCF_THREADS + tid, kq = idx >> 3;
+                xb[(size_t)(idx & 7) * PS + (kq >> 6) * 68 + (kq & 63)] = t[u];
+            }
+        }
+        __syncthreads();
+        if (wave < nvalid) {
+            float2 *x = xb + (size_t)wave * PS;
+            float bq, bt; int iq, it;
+            wave_ifft3_argmax<16, 4>(x, tw_s, lane, bq, iq, bt, it);
+            const bool mir = !g.nomirror && !(bq >= bt);        // qn >= qm keeps the straight match; nomirror: straight only
+            const int jt = mir ? it : iq;
+            CandT *dst = pc + wave;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
+            if (lane < 7) {
+                const float2 zz = x[ifft3_slot((jt + lane - 3 + N) & (N - 1))];
+                dst->t7[lane] = mir ? zz.y : zz.x;
+            }
+            if (lane == 0) { dst->val = mir ? bt : bq; dst->jtot = jt + 1; dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + wave); }
+        }
+        __syncthreads();
+        // best reference of the batch (ascending reference, ">=": later wins), dword-wise copy, * 1/sigma
+        if (tid < (int)(sizeof(CandT) / 4)) {
+            float bv = pc[0].val; int br = 0;
+            for (int rr = 1; rr < nvalid; rr++) {
+                const float v = pc[rr].val;
+                if (v >= bv) { bv = v; br = rr; }
+            }
+            int word = reinterpret_cast<const int *>(pc + br)[tid];
+            if (tid == 0 || tid >= 3) word = __float_as_int(__int_as_float(word) * stats[(size_t)mtile * 8 + o].y);
+            reinterpret_cast<int *>(cand + ((size_t)mtile * 8 + o) * nrtile + rtile)[tid] = word;
         }
     }
 }
