@@ -648,8 +648,12 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
 {
     const bool refine = e->refine_ok && e->refine_thr != 0.f && refx;
     if (refine) RA_HIP(hipMemsetAsync(e->d_rcount, 0, sizeof(int), e->stream));
-    hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, cand, nrtile, cn, st, res, (const float *)e->d_cs,
-                       refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
+    if ((size_t)e->geo.nshift * nrtile >= 256)          // many records per particle: one wave each
+        hipLaunchKernelGGL(finalize_wave_kernel, dim3(cn), dim3(64), 0, e->stream, e->dg, cand, nrtile, cn, st, res,
+                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
+    else
+        hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, cand, nrtile, cn, st, res, (const float *)e->d_cs,
+                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
     RA_HIP(hipGetLastError());
     if (refine) {
         const int grid = std::min(cn, e->refine_grid);

@@ -1156,28 +1156,15 @@ struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirro
 
 // rlist / rcount / rthr: particles whose prb1d is ill-conditioned (|c3| < rthr x max |b|; rthr < 0: every particle) are
 // appended to rlist for refine_winner_kernel; rlist = null: none
-__global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
-                                float *__restrict__ state, ra_result *__restrict__ res,
-                                const float *__restrict__ cs, RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
+// everything behind the scan over the records: prb1d / ang_n / ormq tail / combine_params2 of the winner (bs, brt), the result
+// record and the new state, and the hand-over to refine_winner_kernel (flat peaks and float ties; (s2, rt2) = the record with the
+// second-largest peak, s2 < 0: none)
+__device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__restrict__ cand, int nrtile, int p, const Window &w,
+                                              CandT best, int bs, int brt, float second, int s2, int rt2, float *__restrict__ state,
+                                              ra_result *__restrict__ res, RefineRec *__restrict__ rlist, int *__restrict__ rcount,
+                                              float rthr)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    float peak = -1.0e23f, second = -1.0e23f;
-    CandT best; best.val = peak; best.jtot = 1; best.refmir = 0;
-    for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
-    int bs = 0, brt = 0, s2 = -1, rt2 = 0;          // (s2, rt2): the record with the second-largest peak
-    const int nx1 = 2 * g.nkx + 1;
-    for (int s = 0; s < g.nshift; s++) {
-        const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
-        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
-        for (int rt = 0; rt < nrtile; rt++) {
-            const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
-            const float v = c->val;
-            if (v >= peak) { second = peak; s2 = bs; rt2 = brt; peak = v; best = *c; bs = s; brt = rt; }
-            else if (v >= second) { second = v; s2 = s; rt2 = rt; }
-        }
-    }
+    const float peak = best.val;
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
     // Util::prb1d on the winner's neighbourhood, then Util::ang_n, mode F
     const int jword = best.jtot;         // jtot and, possibly, a runner-up reference of the same offset (cand_pack_runner)
@@ -1228,6 +1215,73 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
             rlist[atomicAdd(rcount, 1)] = rec;
         }
     }
+}
+
+__global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
+                                float *__restrict__ state, ra_result *__restrict__ res,
+                                const float *__restrict__ cs, RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    float peak = -1.0e23f, second = -1.0e23f;
+    CandT best; best.val = peak; best.jtot = 1; best.refmir = 0;
+    for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
+    int bs = 0, brt = 0, s2 = -1, rt2 = 0;          // (s2, rt2): the record with the second-largest peak
+    const int nx1 = 2 * g.nkx + 1;
+    for (int s = 0; s < g.nshift; s++) {
+        const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
+        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
+        for (int rt = 0; rt < nrtile; rt++) {
+            const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
+            const float v = c->val;
+            if (v >= peak) { second = peak; s2 = bs; rt2 = brt; peak = v; best = *c; bs = s; brt = rt; }
+            else if (v >= second) { second = v; s2 = s; rt2 = rt; }
+        }
+    }
+    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr);
+}
+
+// the same with one WAVE per particle, for paths that leave many records per particle (the generic kernels: 121 offsets x 13
+// reference tiles at 256 x 256 / 100 references, where one thread per particle scans 63 KB on its own): lane l scans records
+// l, l + 64, .. in scan order (offsets, then reference tiles), the lanes' (best, second) pairs are merged with the order of the
+// sequential ">=" scan -- of equal peaks the later record wins -- and lane 0 finishes the particle
+__global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
+                                                           float *__restrict__ state, ra_result *__restrict__ res,
+                                                           RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n) return;
+    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    const int nx1 = 2 * g.nkx + 1, nrec = g.nshift * nrtile;
+    float bv = -1.0e23f, sv = -1.0e23f;
+    int bi = -1, si = -1;                              // linear record index s * nrtile + rt of the best / second record
+    for (int li = lane; li < nrec; li += 64) {
+        const int s = li / nrtile;
+        const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
+        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
+        const float v = cand[(size_t)p * g.nshift_pad * nrtile + li].val;
+        if (v >= bv) { sv = bv; si = bi; bv = v; bi = li; }
+        else if (v >= sv) { sv = v; si = li; }
+    }
+    auto better = [](float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia > ib); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float obv = __shfl_xor(bv, o), osv = __shfl_xor(sv, o);
+        const int obi = __shfl_xor(bi, o), osi = __shfl_xor(si, o);
+        // new best = the better of the two bests; new second = the better of (the other best, the two seconds)
+        float lv, cv; int lix, cix;
+        if (better(obv, obi, bv, bi)) { lv = bv; lix = bi; bv = obv; bi = obi; } else { lv = obv; lix = obi; }
+        if (better(osv, osi, sv, si)) { cv = osv; cix = osi; } else { cv = sv; cix = si; }
+        if (better(lv, lix, cv, cix)) { sv = lv; si = lix; } else { sv = cv; si = cix; }
+    }
+    if (lane != 0) return;
+    CandT best; best.val = -1.0e23f; best.jtot = 1; best.refmir = 0;
+    for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
+    int bs = 0, brt = 0;
+    if (bi >= 0) { best = cand[(size_t)p * g.nshift_pad * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
+    const int s2 = si >= 0 ? si / nrtile : -1, rt2 = si >= 0 ? si - s2 * nrtile : 0;
+    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr);
 }
 
 // ------------------------------------------------------------------------------------------
