@@ -517,11 +517,27 @@ static ccf_fn select_ccf(int maxrin)
 }
 
 typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
-static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf)
+static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack = false)
 {
     if (nref > RF_MAXREF) return nullptr;
     const int nrp = (nref + 1) / 2;
     const bool one = nzr == 1;      // one store / inverse-FFT round per pass
+    if (pack) {                     // dense offset stream over the workgroup's particles (maxrin 256, one round per pass)
+        if (maxrin != 256 || !one) return nullptr;
+        if (sbuf == RF_SBUF_FIXED)
+            switch ((nrp + 1) / 2) {
+            case 1: return search_fused_kernel<256, 1, true, RF_SBUF_FIXED, true>;
+            case 2: return search_fused_kernel<256, 2, true, RF_SBUF_FIXED, true>;
+            case 3: return search_fused_kernel<256, 3, true, RF_SBUF_FIXED, true>;
+            default: return search_fused_kernel<256, 4, true, RF_SBUF_FIXED, true>;
+            }
+        switch ((nrp + 1) / 2) {
+        case 1: return search_fused_kernel<256, 1, true, 0, true>;
+        case 2: return search_fused_kernel<256, 2, true, 0, true>;
+        case 3: return search_fused_kernel<256, 3, true, 0, true>;
+        default: return search_fused_kernel<256, 4, true, 0, true>;
+        }
+    }
     if (maxrin == 256) {
         if (one && sbuf == RF_SBUF_FIXED)      // compile-time ring-buffer stride
             switch ((nrp + 1) / 2) {
@@ -572,6 +588,15 @@ template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap
     return RA_OK;
 }
 
+// dense offset stream (search_fused_kernel's PACK): pays when the last pass of a particle would carry padding offsets
+// (RALIGN_PACK=0: off)
+static bool pack_ok(const ra_engine *e)
+{
+    if (!e->fused || e->tiled || (getenv("RALIGN_PACK") && atoi(getenv("RALIGN_PACK")) == 0)) return false;
+    if (e->geo.nshift % 4 == 0) return false;
+    return select_fused(e->geo.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, true) != nullptr;
+}
+
 // plan of the particle-resident search kernel (ralign_fused.h) and its tables.  It covers every search window of a
 // geometry the LDS-resident kernels cover, up to RF_MAXREF references; everything else keeps the two-kernel path.
 static int setup_fused(ra_engine *e)
@@ -593,9 +618,12 @@ static int setup_fused(ra_engine *e)
     if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
-    const fused_fn fk = e->tiled ? select_tiled(fp.f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf);
-    hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
-    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    for (int pk = 0; pk < (e->tiled ? 1 : 2); pk++) {
+        const fused_fn fk = e->tiled ? select_tiled(fp.f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf, pk != 0);
+        if (!fk) continue;
+        hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+        if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    }
     if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: %s plan: %zu bytes of LDS (polar part %zu), sbuf %d, pst %d, nzr %d, rz %d\n", e->tiled ? "tiled" : "fused", fp.lds_bytes, e->lds_polar, e->dg.sbuf, e->dg.pst, fp.f.nzr, fp.f.rz);
     e->fused = true;
     return RA_OK;
@@ -1174,7 +1202,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
         const FusedGeom f = e->fplan.f;
-        fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf);
+        fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, pack_ok(e));
         const int rch = resident_batch(e, n);
         {
             int rcw = ensure_resident_ws(e, rch);

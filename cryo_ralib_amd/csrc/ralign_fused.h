@@ -386,7 +386,8 @@ struct PassSync {
 // allows) or 0 = g.sbuf.  With a constant stride the second offset pair of every A operand is an immediate offset of its
 // read (ds_read2st64_b32: both offset pairs in one instruction): 4 instead of 8 address and LDS instructions per ring quad.
 #define RF_SBUF_FIXED 6432       // >= the stride at ou = 36 (6416); 8 x 6432 bytes is a multiple of 256
-template <int N, int NRPW, bool ONE, int SB>
+// PACK: the offsets of consecutive particles of a workgroup fill the passes without padding (see the pass loop)
+template <int N, int NRPW, bool ONE, int SB, bool PACK = false>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
                                                                   const float *__restrict__ Bf0, int nref,
@@ -445,35 +446,47 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
     constexpr int NU = 2 * NRPW;
     const int xm = f.wmap[wave] & 255, rp0 = (f.wmap[wave] >> 8) * NRPW;
 
-    const int ngroup = g.nshift_pad / 4;
-#pragma unroll 1
-    for (int p = blockIdx.x; p < n; p += gridDim.x) {
-    RF_LDS_BARRIER();                           // the previous particle's last pass has left the image and `red`
-    const float *src = particles + (size_t)p * g.nx * g.nx;
-    const float *Bf = cls ? Bf0 + (size_t)cls[p] * f.b_floats : Bf0;
-    for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
-        const int y = row - g.bd;
-        const bool yin = y >= 0 && y < g.nx;
-        for (int c = lane; c < g.pst; c += 64) {
-            const int x = c - g.bd;
-            img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
+    // The workgroup's particles p(i) = blockIdx.x + i gridDim.x form one stream of search offsets, SPP slots per particle, cut into
+    // passes of 4.  PACK = false: SPP = nshift_pad, every particle starts a pass and the last pass of a particle carries padding
+    // (49 offsets = 12 passes + 1/4: the 13th costs as much as a full one -- every phase has a latency floor -- 7.3 % of the time for
+    // 2 % of the work).  PACK = true: SPP = nshift, the stream is dense -- 4 particles x 49 offsets = 49 full passes -- and a pass
+    // may hold the last offsets of one particle and the first of the next: its ring jobs then run twice, over the slots of the
+    // resident image, and after the next image has replaced it over the rest.  Everything behind the sampling is per slot
+    // (centres, Normalize_ring statistics, spectra, records), so the results are the same to the bit.
+    const int SPP = PACK ? g.nshift : g.nshift_pad;
+    const int npw = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nslots = npw * SPP, npass = (nslots + 3) >> 2;
+    auto particle_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    auto load_image = [&](int i) {
+        const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
+        for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
+            const int y = row - g.bd;
+            const bool yin = y >= 0 && y < g.nx;
+            for (int c = lane; c < g.pst; c += 64) {
+                const int x = c - g.bd;
+                img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
+            }
         }
-    }
-    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
-    if (tid < 4) {                              // sampling centres of pass 0 (those of pass g + 1 are written at the end of pass g)
-        const int si = min((int)tid, g.nshift - 1);
-        red[16 + 2 * tid] = cxf + g.shift_x[si];
-        red[17 + 2 * tid] = cyf + g.shift_y[si];
+    };
+    // sampling centre of slot k of the pass that starts at (particle i0, offset s0): lanes 0 .. 3 of one wave
+    auto write_centre = [&](int i0, int s0, int k) {
+        int i = i0, sk = s0 + k;
+        if (sk >= SPP) { sk -= SPP; i++; }
+        i = min(i, npw - 1);
+        const int pk = particle_of(i);
+        const Window wk = particle_window(g, state[2 * pk], state[2 * pk + 1]);
+        const int si = min(sk, g.nshift - 1);
+        red[16 + 2 * k] = ((float)g.cnx + wk.sxi) + g.shift_x[si];
+        red[17 + 2 * k] = ((float)g.cnx + wk.syi) + g.shift_y[si];
         red[7] = 0.f;
-    }
+    };
+    // this wave's job of round 0 is the same in every pass
     RF_LDS_BARRIER();
-    // this wave's job of round 0 is the same in every pass: fetched once per particle, not once per pass
     const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its end is the arrival counter, not a barrier
-    // best reference per offset of pass gr (ascending reference, ">=": later wins), scaled by 1/sigma; by wave 2: an old
-    // wave -- it gets through its ring job first -- that is not the one with the extra short job
-    auto reduce_records = [&](int gr, int nl) {
+    // best reference per offset of the pass that started at (i0r, s0r) (ascending reference, ">=": later wins), scaled by
+    // 1/sigma; by wave 2: an old wave -- it gets through its ring job first -- that is not the one with the extra short job
+    auto reduce_records = [&](int i0r, int s0r, int nl) {
         constexpr int W = sizeof(CandT) / 4;
         if (wave == 2 && lane < nl * W) {
             const int o = lane / W, wd = lane - o * W;
@@ -486,46 +499,77 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
             int word = reinterpret_cast<const int *>(pc + o * nref + br)[wd];
             if (wd == 1 && sv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(word, pc[o * nref + sr]);      // float tie between references
             if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
-            reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
+            int io = i0r, so = s0r + o;
+            if (so >= SPP) { so -= SPP; io++; }
+            reinterpret_cast<int *>(cand + (size_t)particle_of(io) * g.nshift_pad + so)[wd] = word;
         }
     };
-    for (int grp = 0; grp < ngroup; grp++) {
-        const bool tl = p == (int)blockIdx.x && blockIdx.x == 0;      // timeline: first particle of workgroup 0
+    int i0 = 0, s0 = 0, img_i = -1;             // first slot of the current pass: particle index in the stream, offset; resident image
+    int i0p = 0, s0p = 0, nlp = 4;              // ... and live slots of the previous pass (its records are reduced inside this one)
+#pragma unroll 1
+    for (int grp = 0; grp < npass; grp++) {
+        const bool tl = blockIdx.x == 0 && grp < 64;      // timeline: first passes of workgroup 0
         RA_STAMP(g, tl, grp, wave, 0);
+        // live slots of the pass (leading), slots of the first particle, and whether a second particle starts inside it
+        const int nlive = PACK ? min(4, nslots - 4 * grp) : min(4, g.nshift - s0);
+        const int a = min(4, SPP - s0);
+        const bool split = PACK && a < nlive;
+        const float *Bf = cls ? Bf0 + (size_t)cls[particle_of(i0)] * f.b_floats : Bf0;
+        if (img_i != i0) {
+            // a new particle starts with this pass: every wave is through with the sampling of the previous pass (barrier 1 of
+            // that pass), so the image may go; the centres of a stream's first pass are written here
+            load_image(i0);
+            img_i = i0;
+            if (grp == 0 && tid < 4) write_centre(0, 0, (int)tid);
+            RF_LDS_BARRIER();
+        }
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel).
         // The spectra of the previous pass occupy the ring buffers until its inverse FFTs are done; the wait for that
         // (PassSync: an arrival counter) sits INSIDE this pass's first ring job, after the sampling (which touches only the
         // image and the tables): a wave that is through with its inverse FFTs -- or had none -- samples while the others
         // still transform.
-        const int nlive = min(4, g.nshift - 4 * grp);      // the last pass may carry padding offsets: no work for them
         const bool pend = defer && grp > 0;
         if (!RA_DBG(g, 16)) {
+            // one copy of the job code (the instruction cache holds 64 KB for two CUs): a pass that holds the offsets of two
+            // particles runs it twice, over slots [0, a) of the resident image and -- behind the exchange of the image between
+            // two barriers -- over [a, nlive)
 #pragma unroll 1
-            for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
-                // jobs sorted longest first, dealt round robin: the SIMDs issue oldest-wave-first, so the first waves finish
-                // their long jobs earliest (wave timeline, scripts/fused_timeline.sh) and take the short jobs of round 1
-                const int job = jr * RF_WAVES + wave;
-                if (job >= g.n_job) continue;
-                const int4 jd = jr == 0 ? jd0 : jobs_s[job];
-#ifdef RALIGN_PROFILE_SWITCHES
-                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl && grp < 64 ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
-#else
-                const PassSync ps = {pend && jr == 0, ifft_done, done_target};
-#endif
-                switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-                default: break;      // the fused job table holds codes 1, 6, 7 and 9 only (make_jobs with 4 offset slots)
+            for (int ph = 0; ph < (split ? 2 : 1); ph++) {
+                if (ph) {
+                    RF_LDS_BARRIER();
+                    load_image(i0 + 1);
+                    img_i = i0 + 1;
+                    RF_LDS_BARRIER();
                 }
+                const int slo = ph ? a : 0, shi = (split && !ph) ? a : nlive;
+                const bool wait = pend && !ph;
+#pragma unroll 1
+                for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
+                    // jobs sorted longest first, dealt round robin: the SIMDs issue oldest-wave-first, so the first waves finish
+                    // their long jobs earliest (wave timeline, scripts/fused_timeline.sh) and take the short jobs of round 1
+                    const int job = jr * RF_WAVES + wave;
+                    if (job >= g.n_job) continue;
+                    const int4 jd = jr == 0 ? jd0 : jobs_s[job];
+#ifdef RALIGN_PROFILE_SWITCHES
+                    const PassSync ps = {wait && jr == 0, ifft_done, done_target, g.timeline && tl && grp < 64 ? g.timeline + (grp * 16 + wave) * 16 : nullptr};
+#else
+                    const PassSync ps = {wait && jr == 0, ifft_done, done_target};
+#endif
+                    switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+                    case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                    case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                    case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                    case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                    default: break;      // the fused job table holds codes 1, 6, 7 and 9 only (make_jobs with 4 offset slots)
+                    }
+                }
+                if (wait && wave >= g.n_job) { const PassSync ps = {true, ifft_done, done_target}; ps(); }      // a wave without a job in round 0
             }
-            if (pend && wave >= g.n_job) { const PassSync ps = {true, ifft_done, done_target}; ps(); }      // a wave without a job in round 0
         } else if (pend) {
             const PassSync ps = {true, ifft_done, done_target};
             ps();
         }
-        if (pend) reduce_records(grp - 1, 4);                  // only the last pass can carry padding offsets
+        if (pend) reduce_records(i0p, s0p, nlp);
         RA_STAMP(g, tl, grp, wave, 1);
         // lane roles of the contraction (see above), and its first B quad: requested here, it travels while the last ring
         // jobs finish and the barrier is crossed (the barrier does not drain global requests)
@@ -561,12 +605,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
                 rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
             }
             if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
-        } else if (wave == 4 && lane < 4 && grp + 1 < ngroup) {
+        } else if (wave == 4 && lane < 4 && grp + 1 < npass) {
             // sampling centres of the next pass: this pass's ring jobs are done with the current ones
-            const int si = min((grp + 1) * 4 + (int)lane, g.nshift - 1);
-            red[16 + 2 * lane] = cxf + g.shift_x[si];
-            red[17 + 2 * lane] = cyf + g.shift_y[si];
-            red[7] = 0.f;
+            int in = i0, sn = s0 + 4;
+            if (sn >= SPP) { sn -= SPP; in++; }
+            write_centre(in, sn, (int)lane);
         }
         // ---- contraction: accumulate this wave's units over the rings that have bins of its group
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
@@ -669,7 +712,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
             }
         }
         if (defer) {
-            if (grp + 1 < ngroup) {
+            if (grp + 1 < npass) {
                 // this wave's transforms (if it had any) are over: count it; the next pass's ring jobs wait for all 16 before
                 // they write to the ring buffers (PassSync).  The LDS array serves requests in order, so the reads above
                 // precede the increment and the increment precedes whatever a wave that has seen it writes.
@@ -681,11 +724,13 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
             }
         }
         RA_STAMP(g, tl, grp, wave, 8);
-        if (!defer || grp + 1 == ngroup) reduce_records(grp, nlive);
+        if (!defer || grp + 1 == npass) reduce_records(i0, s0, nlive);
+        i0p = i0; s0p = s0; nlp = nlive;
+        s0 += 4;
+        if (s0 >= SPP) { s0 -= SPP; i0++; }
         // no barrier here: the next pass's ring jobs sample first (image and tables only) and wait for the counter before
         // they touch the ring buffers; the ring partials were read before the contraction barrier, the centres written after
         // the first barrier of this pass; `pc` and red[12..15] are next written two and one barriers into the next pass
-    }
     }
 }
 

@@ -340,7 +340,7 @@ template <int R1, int LR, bool NYQ1 = false, class Sync = NoSync>
 __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                          const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
                                          const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4,
-                                         Sync sync = Sync())
+                                         Sync sync = Sync(), int slot_lo = 0)
 {
     // lane id rebuilt from a per-job runtime zero (jobs[].w): keeps the per-variant lane arithmetic
     // inside the job instead of hoisted out of the pass loop for all six variants (VGPR spills)
@@ -352,7 +352,7 @@ __device__ __forceinline__ void ring_job(const DevGeom &g, const float *imgb, fl
     const int4 in = inst_s[inst0 + subc];
     const int slot = in.x & 255, ring = in.x >> 8;
     // inactive: no instance, or a padding offset of the last pass (the instances of a slot are contiguous: whole jobs drop out)
-    const bool active = sub < count && slot < nlive;
+    const bool active = sub < count && slot < nlive && slot >= slot_lo;      // [slot_lo, nlive): the offset slots of this call
     float *buf = bufs + (__mul24(slot, sbuf) + in.y);
     const float rad = (float)in.w, wt = instw_s[inst0 + subc];
     const float cx = ctr[2 * slot], cy = ctr[2 * slot + 1];
@@ -541,13 +541,13 @@ template <bool NYQ1, class Sync = NoSync>
 __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
                                              const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
                                              const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4,
-                                             Sync sync = Sync())
+                                             Sync sync = Sync(), int slot_lo = 0)
 {
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
     const int lanec = min(lane, count - 1);     // lanes without an instance stay in the control flow (see ring_job's `sync`)
     const int4 in = inst_s[inst0 + lanec];
     const int slot = in.x & 255, ring = (in.x >> 8) & 255, lg = (in.x >> 16) & 15, t = in.x >> 20;
-    const bool active = lane < count && slot < nlive;
+    const bool active = lane < count && slot < nlive && slot >= slot_lo;
     const int lgLR = lg - 3, LR = 1 << lgLR, H = 4 << lgLR, lgLT = lg - 2, LTm = (1 << lgLT) - 1;
     float *buf = bufs + (__mul24(slot, sbuf) + in.y);
     const float rad = (float)in.w, wt = instw_s[inst0 + lanec];
