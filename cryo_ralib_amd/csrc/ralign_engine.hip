@@ -332,6 +332,16 @@ static int build_device_geometry(ra_engine *e)
             }
         };
         if (!e->generic) make_jobs(4, jobs, inst, instw);
+        if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
+            std::vector<int4> perm;
+            for (const char *c = po; *c;) {
+                const int k = atoi(c);
+                if (k >= 0 && k < (int)jobs.size()) perm.push_back(jobs[k]);
+                while (*c && *c != ',') c++;
+                if (*c == ',') c++;
+            }
+            if (perm.size() == jobs.size()) jobs = perm;
+        }
     }
     d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     e->ringw_h = ringw;
@@ -593,7 +603,7 @@ template <typename T> static int grow_upload(ra_engine *e, T **dptr, size_t *cap
 static bool pack_ok(const ra_engine *e)
 {
     if (!e->fused || e->tiled || (getenv("RALIGN_PACK") && atoi(getenv("RALIGN_PACK")) == 0)) return false;
-    if (e->geo.nshift % 4 == 0) return false;
+    if (e->geo.nshift % 4 == 0 || e->geo.nshift < 4) return false;      // (a pass holds the offsets of at most two particles)
     return select_fused(e->geo.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, true) != nullptr;
 }
 

@@ -1608,3 +1608,32 @@ def test_tiled_kernel_in_the_iteration_loop():
                         if live[j] else orc.normalize_mask(op[rng.randint(0, n - 1)], mask, 1) for j in range(nref)])
         np.testing.assert_allclose(al.refs.cpu().numpy(), cur, rtol=0, atol=3e-6 * np.abs(cur).max())
     al.close()
+
+
+@pytest.mark.parametrize("nx,ou,xr,yr,n,nref", [(90, 36, 3, 3, 23, 3), (90, 36, 3, 3, 1, 2), (32, 12, 2, 1, 37, 1), (32, 12, 1, 1, 5, 4),
+                                               (32, 12, 1, 0, 9, 2), (32, 12, 0, 0, 7, 2)])
+def test_dense_offset_stream_is_bitwise_the_padded_one(nx, ou, xr, yr, n, nref):
+    """search_fused_kernel's PACK: the offsets of a workgroup's consecutive particles fill the passes without padding (49
+    offsets: 4 particles = 49 passes), a pass may hold offsets of two particles.  Everything behind the sampling is per offset
+    slot, so the records -- peaks, neighbourhoods, assignments -- equal those of the padded stream (RALIGN_PACK=0) bit for bit;
+    particle counts that leave partial last passes, one particle, and windows of 3 and 1 offsets (no packing: a pass would hold
+    more than two particles) included"""
+    refs = synth.make_references(max(nref, 1), nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, max(yr, 1), 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    mode = api.RA_MODE_MREF if nref > 1 else api.RA_MODE_REFFREE
+    outs = []
+    for pack in ("1", "0"):
+        os.environ["RALIGN_PACK"] = pack
+        try:
+            # few workgroups, so that each walks over several particles
+            os.environ["RALIGN_GRID"] = "3"
+            eng, tp, st, res = run_engine(parts, refs_n[:nref] if nref > 1 else refs_n[:1], ou, xr, yr, 1.0, mode=mode)
+        finally:
+            os.environ.pop("RALIGN_PACK", None); os.environ.pop("RALIGN_GRID", None)
+        assert eng.search_path == 1
+        outs.append((eng.result_to_numpy(res).copy(), st.cpu().numpy().copy()))
+        eng.close()
+    for f in api.RESULT_DTYPE.names:
+        np.testing.assert_array_equal(outs[0][0][f], outs[1][0][f], err_msg=f)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
