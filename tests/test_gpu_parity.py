@@ -655,13 +655,15 @@ def _xs_runs(n, nseg):
     return max(1, min(nrun, n // (8 * nseg)))
 
 
-def test_class_sums_are_bitwise_reproducible():
+@pytest.mark.parametrize("nx,ou,xr", [(90, 36, 3), (33, 12, 2), (64, 24, 3)])
+def test_class_sums_are_bitwise_reproducible(nx, ou, xr):
     """class sums are accumulated in a fixed order -- per batch and (class, parity) the member list is cut into `nrun`
     contiguous runs, each added in particle order (like Util.add_img on the CPU path) by one workgroup of
     transform_sum_kernel, the runs then added to the sums in run order -- so two runs agree bit for bit, and with a float32
     restatement of exactly that association on the aligned images of transform_kernel (the two kernels interpolate bit for
-    bit alike); the path that also returns the aligned images (class_sum_kernel, 16 runs per chunk) is pinned the same way"""
-    nx, ou, nref, xr, n = 90, 36, 4, 3, 300
+    bit alike: even and odd box sizes, mirrored and straight particles); the path that also returns the aligned images
+    (class_sum_kernel, 16 runs per chunk) is pinned the same way"""
+    nref, n = 4, 300
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
     rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
@@ -1637,3 +1639,29 @@ def test_dense_offset_stream_is_bitwise_the_padded_one(nx, ou, xr, yr, n, nref):
     for f in api.RESULT_DTYPE.names:
         np.testing.assert_array_equal(outs[0][0][f], outs[1][0][f], err_msg=f)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_device_fit_tanh_agrees_with_the_host_routine():
+    """fsc_fit_kernel (FSC average over the live classes, fit_tanh with amoeba, ref_ali2d's clamps, all on the device) against the
+    host restatement ra_class_fsc + ra_fit_tanh on the class sums of a searched stack: filter parameters within 2e-5, the curve
+    fit_tanh leaves behind (zeroed behind its first drop below 0.1) and the points per shell identical"""
+    al = _searched_aligner(n=600)
+    eng = al.engine
+    frsc = eng.class_fsc(al.buf.sums, al.buf.counts_i, 4, masked=False)
+    fl, aa = api.fit_tanh(frsc)                                  # edits frsc[1] in place like the original
+    fit = torch.zeros(8, device=eng.dev)
+    curve = torch.zeros(3 * eng.fsc_len, device=eng.dev)
+    eng.class_fsc_fit(al.buf.sums, al.buf.counts_i, fit, curve, 4, masked=False)
+    eng.sync()
+    f = fit.cpu().numpy(); c = curve.cpu().numpy().reshape(3, -1)
+    assert f[4] == 0.0
+    assert abs(f[2] - fl) < 2e-5 and abs(f[3] - aa) < 2e-5, (f[:4], fl, aa)
+    assert f[0] == np.float32(max(min(0.4, f[2]), 0.12)) and f[1] == np.float32(min(f[3], 0.2))
+    np.testing.assert_array_equal(c[0], np.asarray(frsc[0], np.float32))
+    np.testing.assert_allclose(c[1], np.asarray(frsc[1], np.float32), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(c[2], np.asarray(frsc[2], np.float32))
+    # every class below min_count: status 1, nothing fitted
+    eng.class_fsc_fit(al.buf.sums, torch.zeros_like(al.buf.counts_i), fit, curve, 4, masked=False)
+    eng.sync()
+    assert fit.cpu().numpy()[4] == 1.0
+    al.close()
