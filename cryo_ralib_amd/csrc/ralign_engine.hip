@@ -483,7 +483,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
     // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup (x 14 only for the 2 x 7 blocks of RALIGN_GCCF_TM=2)
     const bool wide2 = getenv("RALIGN_GCCF_TM") && atoi(getenv("RALIGN_GCCF_TM")) == 2;
-    w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * g.maxrin : 0;
+    w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * (g.maxrin + 2) : 0;      // + 2: N/2 + 1 bins of two values (split kernels)
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);

@@ -218,7 +218,7 @@ __device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__res
 }
 // LDS slot of output element k of wave_ifft3_argmax<16, 4> (N = 1024); complex slots per pair of its image
 __device__ __forceinline__ int ifft3_slot(int k) { return (k & 15) * 68 + ((k >> 4) & 15) * 4 + (k >> 8); }
-#define RA_IFFT3_PSTRIDE (16 * 68)
+#define RA_IFFT3_PSTRIDE (16 * 68 + 4)       // + 4: the 8 images of a batch start 8 banks apart (the scratch -> LDS writes of gccf_ifft_kernel)
 
 // frequency index held at position p of a wave_fft_dif output of h points, and its inverse
 __device__ __forceinline__ int dif_index_of_pos(int p, int h)
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_GCCF_THREADS / 64;
     constexpr int ZPAIRS = 64 * TM * TR;
-    float2 *zs = zscr + (size_t)blockIdx.x * ZPAIRS * N;
+    float2 *zs = zscr + (size_t)blockIdx.x * ZPAIRS * (SPLIT ? N + 2 : N);      // SPLIT: N/2 + 1 bins of 16 bytes per pair
     float2 *xb = reinterpret_cast<float2 *>(lds);
     const int pstride = N + 1;              // complex slots per pair: one N-point buffer (in-place transform) + 1 (bank skew)
     float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
@@ -547,8 +547,15 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                             const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
                             const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                             const int zp = (TR * ai + bi) * 64 + pair;
-                            zs[(size_t)k * ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
-                            zs[(size_t)((N - k) & (N - 1)) * ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
+                            if (RA_DBG(g, 8) && apd != 1.2345f) continue;                 // profiling: no stores
+                            const int kw = RA_DBG(g, 4) ? (k & 7) : k;                    // profiling: stores to a cache-resident piece
+                            if constexpr (SPLIT) {
+                                // [bin 0 .. N/2][pair]{Z_k, Z_{N-k}}: one 16-byte store per lane, 1 KB per instruction
+                                reinterpret_cast<float4 *>(zs)[(size_t)kw * ZPAIRS + zp] = make_float4(apd + bpc, cmb + amd, apd - bpc, amd - cmb);
+                            } else {
+                                zs[(size_t)kw * ZPAIRS + zp] = make_float2(apd + bpc, cmb + amd);
+                                zs[(size_t)((N - kw) & (N - 1)) * ZPAIRS + zp] = make_float2(apd - bpc, amd - cmb);
+                            }
                         }
                 }
             }
@@ -643,8 +650,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
 }
 
 // Second half of the split contraction (maxrin 1024): inverse FFT + argmax + best reference per particle-offset for the blocks
-// [task0, task0 + ntask) whose CCF spectra gccf's SPLIT instantiation left in zscr[task - task0][N][64 TM TR].  A batch = the 8
-// references of one particle-offset of one 8 x 8 tile (8 consecutive pairs: one 64-byte piece per Fourier bin of the scratch):
+// [task0, task0 + ntask) whose CCF spectra gccf's SPLIT instantiation left in zscr[task - task0][N/2 + 1][64 TM TR]{Z_k, Z_{N-k}}.  A
+// batch = the 8 references of one particle-offset of one 8 x 8 tile (8 consecutive pairs: one 128-byte piece per bin of the scratch):
 // scratch -> LDS (row-padded images of wave_ifft3_argmax), one transform per wave in registers, the batch's best reference
 // (ascending, ">=": later wins) scaled by 1/sigma to `cand`.  Persistent workgroups walk the batches; two per CU.
 template <int TM, int TR>
@@ -667,22 +674,27 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
         const int mtile = TM * mt2 + sub / TR, rtile = TR * rt2 + sub % TR;
         if (mtile >= n_mtile || rtile >= nrtile) continue;          // uniform over the workgroup
         const int ref0 = rtile * g.rpt, nvalid = min(g.rpt, nref - ref0);
-        // scratch [k][pairs] -> LDS [pair][k]: pairs sub * 64 + 8 o .. + 7 are 64 contiguous bytes per bin
-        const float2 *src = zscr + (size_t)tl * ZPAIRS * N + sub * 64 + 8 * o;
+        // scratch [bin 0 .. N/2][pairs]{Z_k, Z_{N-k}} -> LDS [pair][k]: pairs sub * 64 + 8 o .. + 7 are 128 contiguous bytes per bin;
+        // bins 0 and N/2 are their own partners: the second value is the one that counts (the order of the unsplit kernel's stores)
+        const float4 *src = reinterpret_cast<const float4 *>(zscr + (size_t)tl * ZPAIRS * (N + 2)) + sub * 64 + 8 * o;
         __syncthreads();                                   // the previous batch's records and images are consumed
+        {
+            constexpr int NT = 8 * (N / 2) / RA_GCCF_THREADS;
+            float4 t[NT], tn = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u0 = 0; u0 < 8 * N; u0 += 8 * RA_GCCF_THREADS) {
-            float2 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int idx = u0 + u * RA_GCCF_THREADS + tid;
-                t[u] = src[(size_t)(idx >> 3) * ZPAIRS + (idx & 7)];
+            for (int u = 0; u < NT; u++) {
+                const int idx = u * RA_GCCF_THREADS + tid;
+                t[u] = src[(size_t)(RA_DBG(g, 16) ? (idx >> 3) & 7 : idx >> 3) * ZPAIRS + (idx & 7)];      // profiling: cache-resident reads
             }
+            if (tid < 8) tn = src[(size_t)(N / 2) * ZPAIRS + tid];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int idx = u0 + u * RA_GCCF_THREADS + tid, kq = idx >> 3;
-                xb[(size_t)(idx & 7) * PS + (kq >> 6) * 68 + (kq & 63)] = t[u];
+            for (int u = 0; u < NT; u++) {
+                const int idx = u * RA_GCCF_THREADS + tid, kq = idx >> 3, km = (N - kq) & (N - 1);
+                float2 *img = xb + (size_t)(idx & 7) * PS;
+                if (kq) img[(kq >> 6) * 68 + (kq & 63)] = make_float2(t[u].x, t[u].y);
+                img[(km >> 6) * 68 + (km & 63)] = make_float2(t[u].z, t[u].w);
             }
+            if (tid < 8) xb[(size_t)tid * PS + (N / 2 >> 6) * 68] = make_float2(tn.z, tn.w);
         }
         __syncthreads();
         if (wave < nvalid) {
