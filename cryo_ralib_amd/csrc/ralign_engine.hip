@@ -481,8 +481,8 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.refspec_floats = (size_t)cfg.nref * g.lring;
     w.b_floats = (size_t)nrtile * g.LBP * 16;
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
-    // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup (x 14 only for the 2 x 7 blocks of RALIGN_GCCF_TM=2)
-    const bool wide2 = getenv("RALIGN_GCCF_TM") && atoi(getenv("RALIGN_GCCF_TM")) == 2;
+    // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup, x 14 for the 2 x 7 blocks (gccf_tm; 4 x 7: half the workgroups)
+    const bool wide2 = generic && gccf_tm(nrtile, g.maxrin) >= 2;
     w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * (g.maxrin + 2) : 0;      // + 2: N/2 + 1 bins of two values (split kernels)
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
@@ -836,6 +836,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
             const int lds2 = (int)(((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2));
             if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         }
     }
     if (he == hipSuccess && !e->xf_generic) he = hipFuncSetAttribute((const void *)transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_xf);
@@ -1258,32 +1260,34 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
         const int n_mtile = (cn * g.nshift_pad + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
-        // RALIGN_GCCF_TM=2: 2 x 7 blocks (the B stream read once per 16 instead of 8 particle-offsets) -- measured 43.2 against
-        // 43.9 ms per chunk at 256 x 256 / 100 references: the kernel is not bound by the B stream (40 spilled registers)
-        if (e->generic && gccf_wide_blocks(e->nrtile) && getenv("RALIGN_GCCF_TM") && atoi(getenv("RALIGN_GCCF_TM")) == 2)
+        // blocks of TM x 7 tiles when the reference tiles come in sevens (gccf_tm): the B stream is read once per 8 TM particle-offsets
+        const bool split = e->generic && g.maxrin == 1024 && !(getenv("RALIGN_GCCF_SPLIT") && atoi(getenv("RALIGN_GCCF_SPLIT")) == 0);
+        const int tmv = e->generic ? gccf_tm(e->nrtile, g.maxrin) : 1;
+        const bool tm2 = tmv >= 2 && gccf_wide_blocks(e->nrtile);
+        if (tm2 && !split)
             hipLaunchKernelGGL((ccf_generic_kernel<2, 7>), dim3(std::min((n_mtile + 1) / 2, e->g_nblk)), dim3(RA_GCCF_THREADS), e->lds_gccf, sp, e->dg,
                                Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats,
                                (const float *)e->d_gcdc);
-        else if (e->generic && g.maxrin == 1024 && !(getenv("RALIGN_GCCF_SPLIT") && atoi(getenv("RALIGN_GCCF_SPLIT")) == 0)) {
+        else if (split) {
             // maxrin 1024: contraction and inverse transforms as two kernels per slice of g_nblk blocks (the scratch holds one slice)
             const bool wide = gccf_wide_blocks(e->nrtile);
-            const int TMv = wide ? 1 : 2, TRv = wide ? 7 : 2;
+            const int TMv = wide ? tmv : 2, TRv = wide ? 7 : 2;
             const int n_mt2 = (n_mtile + TMv - 1) / TMv, n_rt2 = (e->nrtile + TRv - 1) / TRv, ntask = n_mt2 * n_rt2;
             const size_t lds2 = ((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2);
-            for (int task0 = 0; task0 < ntask; task0 += e->g_nblk) {
-                const int nt = std::min(e->g_nblk, ntask - task0);
+            const int nblk = TMv >= 4 ? e->g_nblk / 2 : e->g_nblk;          // 4 x 7 blocks: one workgroup per CU (256 registers)
+            auto launch = [&](auto ccfk, auto ifftk, int task0, int nt, int grid2) {
+                hipLaunchKernelGGL(ccfk, dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
+                                   e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
+                hipLaunchKernelGGL(ifftk, dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
+                                   (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
+            };
+            for (int task0 = 0; task0 < ntask; task0 += nblk) {
+                const int nt = std::min(nblk, ntask - task0);
                 const int grid2 = std::min(nt * TMv * TRv * 8, 2 * e->n_cu);
-                if (wide) {
-                    hipLaunchKernelGGL((ccf_generic_kernel<1, 7, true>), dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile,
-                                       e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
-                    hipLaunchKernelGGL((gccf_ifft_kernel<1, 7>), dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref,
-                                       Cbuf, (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
-                } else {
-                    hipLaunchKernelGGL((ccf_generic_kernel<2, 2, true>), dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile,
-                                       e->nrtile, e->cfg.nref, Cbuf, e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
-                    hipLaunchKernelGGL((gccf_ifft_kernel<2, 2>), dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref,
-                                       Cbuf, (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
-                }
+                if (wide && TMv == 4) launch(ccf_generic_kernel<4, 7, true>, gccf_ifft_kernel<4, 7>, task0, nt, grid2);
+                else if (wide && TMv == 2) launch(ccf_generic_kernel<2, 7, true>, gccf_ifft_kernel<2, 7>, task0, nt, grid2);
+                else if (wide) launch(ccf_generic_kernel<1, 7, true>, gccf_ifft_kernel<1, 7>, task0, nt, grid2);
+                else launch(ccf_generic_kernel<2, 2, true>, gccf_ifft_kernel<2, 2>, task0, nt, grid2);
                 RA_HIP(hipGetLastError());
             }
         }

@@ -418,11 +418,22 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 // (45.2 -> 44.2 ms per chunk).  The scratch holds the largest shape.
 #define RA_GCCF_ZPAIRS_MAX (64 * 14)
 inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 7 * 7 - nrtile <= 1; }
+// particle-offset tiles per block of the x 7 shape: 4 at maxrin 1024 (split kernels; the contraction waits on its operand stream -- 8
+// requests of 1 KB per 7 matrix instructions at 1 x 7, 11 per 28 at 4 x 7, 214 registers, one workgroup per CU: contraction +
+// transforms 36.3 / 31.9 / 30.2 ms per chunk at TM = 1 / 2 / 4), 1 elsewhere; RALIGN_GCCF_TM = 1 | 2 | 4 overrides (4: split kernels only)
+inline int gccf_tm(int nrtile, int maxrin)
+{
+    if (!gccf_wide_blocks(nrtile)) return 1;
+    const char *ev = getenv("RALIGN_GCCF_TM");
+    const int v = ev ? atoi(ev) : 0;
+    if (v == 1 || v == 2 || (v == 4 && maxrin == 1024)) return v;
+    return maxrin == 1024 ? 4 : 1;
+}
 // SPLIT (maxrin 1024): the kernel only contracts -- block task0 + blockIdx.x of the slice [task0, task0 + ntask) of the
 // (mt2, rt2) blocks, spectra to zscr[blockIdx.x] -- and gccf_ifft_kernel transforms the slice afterwards: two kernels with
 // their own register budgets and occupancies instead of two phases that share 128 registers and a barrier.
 template <int TM, int TR, bool SPLIT = false>
-__global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
+__global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_kernel(DevGeom g, const float *__restrict__ A,
                                                                       const float *__restrict__ B, int n_mtile, int nrtile,
                                                                       int nref, CandT *__restrict__ cand,
                                                                       float2 *__restrict__ zscr, int P,
@@ -455,19 +466,11 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                 const int pair = (2 * (lane >> 4) + odd) * 8 + ((lane & 15) >> 1);      // offset-in-tile * 8 + reference slot
                 const int la = kk * 8 + (r16 & 7), lb = kk * 16 + r16;
                 const float *Ab[TM], *Bb[TR];
-                float dcw[TM][TR];
 #pragma unroll
                 for (int ai = 0; ai < TM; ai++)          // a tile past the end repeats the last one: its spectra are never transformed
                     Ab[ai] = A + (size_t)(2 * min(TM * mt2 + ai, n_mtile - 1) + (r16 >> 3)) * g.a_blk;
 #pragma unroll
                 for (int bi = 0; bi < TR; bi++) Bb[bi] = B + (size_t)min(TR * rt2 + bi, nrtile - 1) * g.LBP * 16;
-                // Normalize_ring mean of this lane's particle-offset times the DC weight of its reference (bin 0 only)
-#pragma unroll
-                for (int ai = 0; ai < TM; ai++)
-#pragma unroll
-                    for (int bi = 0; bi < TR; bi++)
-                        dcw[ai][bi] = stats[(size_t)min(TM * mt2 + ai, n_mtile - 1) * 8 + (pair >> 3)].x *
-                                      cdc[min(min(TR * rt2 + bi, nrtile - 1) * g.rpt + (pair & 7), nref - 1)];
                 for (int k = wave; k < g.nbins; k += NW) {
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
                     const float *pa[TM], *pb[TR];
@@ -543,7 +546,12 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void ccf_generic_kernel(DevGeom
                             const f32x4 c4 = acc[ai][bi];
                             const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
                             const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
-                            const float ca = (odd ? r0 : c4[0]) - (k == 0 ? dcw[ai][bi] : 0.f), cb = odd ? r1 : c4[1];
+                            // bin 0 only: Normalize_ring mean of this lane's particle-offset times the DC weight of its reference
+                            float dcw = 0.f;
+                            if (k == 0)
+                                dcw = stats[(size_t)min(TM * mt2 + ai, n_mtile - 1) * 8 + (pair >> 3)].x *
+                                      cdc[min(min(TR * rt2 + bi, nrtile - 1) * g.rpt + (pair & 7), nref - 1)];
+                            const float ca = (odd ? r0 : c4[0]) - dcw, cb = odd ? r1 : c4[1];
                             const float cc = odd ? c4[2] : r0, cd = odd ? c4[3] : r1;
                             const float apd = ca + cd, amd = ca - cd, bpc = cb + cc, cmb = cc - cb;
                             const int zp = (TR * ai + bi) * 64 + pair;
