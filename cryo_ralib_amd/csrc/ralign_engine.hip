@@ -1283,7 +1283,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             };
             for (int task0 = 0; task0 < ntask; task0 += nblk) {
                 const int nt = std::min(nblk, ntask - task0);
-                const int grid2 = std::min(nt * TMv * TRv * 8, 2 * e->n_cu);
+                const int grid2 = std::min(nt * TMv * TRv * 8, (getenv("RALIGN_IFFT_WGS") ? atoi(getenv("RALIGN_IFFT_WGS")) : 2) * e->n_cu);
                 if (wide && TMv == 4) launch(ccf_generic_kernel<4, 7, true>, gccf_ifft_kernel<4, 7>, task0, nt, grid2);
                 else if (wide && TMv == 2) launch(ccf_generic_kernel<2, 7, true>, gccf_ifft_kernel<2, 7>, task0, nt, grid2);
                 else if (wide) launch(ccf_generic_kernel<1, 7, true>, gccf_ifft_kernel<1, 7>, task0, nt, grid2);

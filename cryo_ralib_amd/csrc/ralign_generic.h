@@ -692,9 +692,11 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
 #pragma unroll
             for (int u = 0; u < NT; u++) {
                 const int idx = u * RA_GCCF_THREADS + tid;
+                if (RA_DBG(g, 32)) t[u] = make_float4((float)idx, 1.f, 0.f, (float)u);      // profiling: no reads at all
+                else
                 t[u] = src[(size_t)(RA_DBG(g, 16) ? (idx >> 3) & 7 : idx >> 3) * ZPAIRS + (idx & 7)];      // profiling: cache-resident reads
             }
-            if (tid < 8) tn = src[(size_t)(N / 2) * ZPAIRS + tid];
+            if (tid < 8 && !RA_DBG(g, 32)) tn = src[(size_t)(N / 2) * ZPAIRS + tid];
 #pragma unroll
             for (int u = 0; u < NT; u++) {
                 const int idx = u * RA_GCCF_THREADS + tid, kq = idx >> 3, km = (N - kq) & (N - 1);

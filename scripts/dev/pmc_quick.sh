@@ -20,7 +20,7 @@ for f in glob.glob(sys.argv[1] + "/pmcq_" + sys.argv[2] + "_*/**/*counter_collec
     per = {}
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "search_" not in k and "generic" not in k: continue
+        if "search_" not in k and "generic" not in k and "gccf" not in k: continue
         per.setdefault((k, row["Counter_Name"]), {}).setdefault(row["Dispatch_Id"], 0.0)
         per[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for (k, c), d in per.items():
