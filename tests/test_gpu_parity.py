@@ -1665,3 +1665,35 @@ def test_device_fit_tanh_agrees_with_the_host_routine():
     eng.sync()
     assert fit.cpu().numpy()[4] == 1.0
     al.close()
+
+
+@pytest.mark.timeout(900)
+def test_large_box_block_shapes_are_bitwise_alike(monkeypatch):
+    """the large-box contraction in every shape it has -- blocks of 1 x 7, 2 x 7 and 4 x 7 tiles with the transforms in a second
+    kernel (half-spectrum scratch) -- is the same arithmetic per (particle-offset, reference) pair: peaks, neighbourhoods and
+    assignments agree bit for bit; the one-kernel path of round 3 (another inverse FFT) agrees in every assignment and to
+    1e-6 in the peaks; 3 particles x 124 offset slots = 47 tiles of 8, so every shape ends in a partial block"""
+    nx, ou, nref, xr, n = 256, 120, 100, 5, 3
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    outs = {}
+    for name, env in (("4x7", {"RALIGN_GCCF_TM": "4"}), ("2x7", {"RALIGN_GCCF_TM": "2"}), ("1x7", {"RALIGN_GCCF_TM": "1"}),
+                      ("one kernel", {"RALIGN_GCCF_TM": "1", "RALIGN_GCCF_SPLIT": "0"})):
+        for k in ("RALIGN_GCCF_TM", "RALIGN_GCCF_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+        outs[name] = (api.Engine.result_to_numpy(res).copy(), st.cpu().numpy().copy())
+        eng.close()
+    r0, s0 = outs["4x7"]
+    for name, (r, s) in outs.items():
+        if name == "one kernel":        # another inverse FFT (five radix-4 stages through the LDS): peaks to the last bits only
+            for f in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+                np.testing.assert_array_equal(r[f], r0[f], err_msg="%s: %s" % (name, f))
+            np.testing.assert_allclose(r["peak"], r0["peak"], rtol=1e-6)
+            continue
+        for f in r0.dtype.names:
+            np.testing.assert_array_equal(r[f], r0[f], err_msg="%s: %s" % (name, f))
+        np.testing.assert_array_equal(s, s0, err_msg=name)
