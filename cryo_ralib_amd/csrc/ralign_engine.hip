@@ -833,7 +833,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (g.maxrin == 1024) {
-            const int lds2 = (int)(((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2));
+            const int lds2 = (int)(((size_t)8 * RA_IFFT3_PSTRIDE + 16 * 16 + 16 * 64) * sizeof(float2));
             if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gccf_ifft_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -1273,7 +1273,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             const bool wide = gccf_wide_blocks(e->nrtile);
             const int TMv = wide ? tmv : 2, TRv = wide ? 7 : 2;
             const int n_mt2 = (n_mtile + TMv - 1) / TMv, n_rt2 = (e->nrtile + TRv - 1) / TRv, ntask = n_mt2 * n_rt2;
-            const size_t lds2 = ((size_t)8 * RA_IFFT3_PSTRIDE + g.maxrin) * sizeof(float2);
+            const size_t lds2 = ((size_t)8 * RA_IFFT3_PSTRIDE + 16 * 16 + 16 * 64) * sizeof(float2);
             const int nblk = TMv >= 4 ? e->g_nblk / 2 : e->g_nblk;          // 4 x 7 blocks: one workgroup per CU (256 registers)
             auto launch = [&](auto ccfk, auto ifftk, int task0, int nt, int grid2) {
                 hipLaunchKernelGGL(ccfk, dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,

@@ -148,8 +148,26 @@ __device__ __forceinline__ void wave_fft_dif(float2 *x, int h, const float2 *__r
 // the banks); the transform ends in the same image, element k in slot ifft3_slot(k) (the 7-point neighbourhood of the peak is
 // read from it).  tw[m] = e^{-2 pi i m / N} (conjugated here: inverse, unscaled).  Running maxima of Re (q) and Im (t) with the
 // largest index winning ties, as ccf_generic_kernel's scan.
+// twa [R12][R12] = conj W_N^{R3 n2 k1} at [k1 * R12 + n2], twb [R12][64] = conj W_N^{n3 (k1 + R12 k2)} at [k2 * 64 + lane]
+// (ifft3_twiddles): consecutive lanes read consecutive entries -- out of the plain table W_N^m the stage-A reads of k1 = 8 hit one
+// bank 16 times.
 template <int R12, int R3>
-__device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__restrict__ tw, int lane, float &bq, int &iq, float &bt, int &it)
+__device__ __forceinline__ void ifft3_twiddles(const float2 *__restrict__ tw, float2 *twa, float2 *twb, int tid, int nthreads)
+{
+    constexpr int N = R12 * R12 * R3, LG3 = R3 == 4 ? 2 : 3;
+    for (int i = tid; i < R12 * R12; i += nthreads) {
+        const float2 w = tw[(R3 * (i % R12) * (i / R12)) & (N - 1)];
+        twa[i] = make_float2(w.x, -w.y);
+    }
+    for (int i = tid; i < R12 * 64; i += nthreads) {
+        const int k2 = i >> 6, ln = i & 63, k1 = ln >> LG3, n3 = ln & (R3 - 1);
+        const float2 w = tw[(n3 * (k1 + R12 * k2)) & (N - 1)];
+        twb[i] = make_float2(w.x, -w.y);
+    }
+}
+template <int R12, int R3>
+__device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__restrict__ twa, const float2 *__restrict__ twb, int lane,
+                                                  float &bq, int &iq, float &bt, int &it)
 {
     constexpr int N = R12 * R12 * R3, RS = 64 + R3, LG3 = R3 == 4 ? 2 : 3;
     static_assert(R12 * R3 == 64, "one wave: R12 * R3 lanes per stage");
@@ -159,12 +177,9 @@ __device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__res
     for (int n1 = 0; n1 < R12; n1++) v[n1] = x[n1 * RS + lane];
     Dft<1, R12>::run(v);
     {
-        const int m1 = lane & ~(R3 - 1);            // R3 n2
+        const int n2 = lane >> LG3;
 #pragma unroll
-        for (int k1 = 1; k1 < R12; k1++) {
-            const float2 w = tw[(m1 * k1) & (N - 1)];
-            v[k1] = cmul(v[k1], make_float2(w.x, -w.y));
-        }
+        for (int k1 = 1; k1 < R12; k1++) v[k1] = cmul(v[k1], twa[k1 * R12 + n2]);
     }
     wave_lds_sync();
 #pragma unroll
@@ -176,12 +191,8 @@ __device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__res
 #pragma unroll
         for (int n2 = 0; n2 < R12; n2++) v[n2] = x[k1 * RS + n2 * R3 + n3];
         Dft<1, R12>::run(v);
-        const int b0 = n3 * k1, st = n3 * R12;
 #pragma unroll
-        for (int k2 = 0; k2 < R12; k2++) {
-            const float2 w = tw[(b0 + st * k2) & (N - 1)];
-            v[k2] = cmul(v[k2], make_float2(w.x, -w.y));       // n3 = 0: w = 1
-        }
+        for (int k2 = 0; k2 < R12; k2++) v[k2] = cmul(v[k2], twb[k2 * 64 + lane]);       // n3 = 0: w = 1
         wave_lds_sync();
 #pragma unroll
         for (int k2 = 0; k2 < R12; k2++) x[k1 * RS + k2 * R3 + n3] = v[k2];
@@ -672,8 +683,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
     constexpr int N = 1024, ZPAIRS = 64 * TM * TR, NW = RA_GCCF_THREADS / 64, PS = RA_IFFT3_PSTRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2 *xb = reinterpret_cast<float2 *>(lds);             // [8 pairs][PS]
-    float2 *tw_s = xb + (size_t)NW * PS;
-    for (int i = tid; i < N; i += RA_GCCF_THREADS) tw_s[i] = g.tw[i];
+    float2 *twa_s = xb + (size_t)NW * PS, *twb_s = twa_s + 16 * 16;
+    ifft3_twiddles<16, 4>(g.tw, twa_s, twb_s, tid, RA_GCCF_THREADS);
     const int n_rt2 = (nrtile + TR - 1) / TR;
     const int nbatch = ntask * TM * TR * 8;
     for (int bt_ = blockIdx.x; bt_ < nbatch; bt_ += gridDim.x) {
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
         if (wave < nvalid) {
             float2 *x = xb + (size_t)wave * PS;
             float bq, bt; int iq, it;
-            wave_ifft3_argmax<16, 4>(x, tw_s, lane, bq, iq, bt, it);
+            wave_ifft3_argmax<16, 4>(x, twa_s, twb_s, lane, bq, iq, bt, it);
             const bool mir = !g.nomirror && !(bq >= bt);        // qn >= qm keeps the straight match; nomirror: straight only
             const int jt = mir ? it : iq;
             CandT *dst = pc + wave;              // lanes 0..6 store the 7-point neighbourhood, lane 0 the rest
