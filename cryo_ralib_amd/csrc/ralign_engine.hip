@@ -820,7 +820,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->g_P = 64;
     while (e->g_P > 1 && (size_t)e->g_P * (g.maxrin + 1) * sizeof(float2) > 66 * 1024) e->g_P >>= 1;      // two workgroups per CU
     e->lds_gccf = ((size_t)e->g_P * (g.maxrin + 1) + g.maxrin) * sizeof(float2);      // pair buffers (in-place transforms) + twiddle table
-    e->lds_gpolar = (size_t)(RA_GEN_THREADS / 64 + 1) * g.maxrin * sizeof(float2);      // per-wave ring buffers + twiddle table
+    e->lds_gpolar = ((size_t)(RA_GEN_THREADS / 64 + 1) * g.maxrin + e->dg.n_qtab) * sizeof(float2);      // per-wave ring buffers + twiddle table + (sinf, cosf) tables
     hipError_t he = hipSuccess;
     if (!e->generic) {
         he = hipFuncSetAttribute((const void *)polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_polar);

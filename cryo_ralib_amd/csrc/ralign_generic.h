@@ -258,6 +258,18 @@ __device__ __forceinline__ float2 split_bin(const float2 *Z, int k, int h, float
     return make_float2(er + tr, ei + ti);
 }
 
+// sample j of a ring of 4 lt = 4 << lgl positions and radius fr, relative to the centre: alrl_ms's table position from the first-quadrant
+// (sinf, cosf) table of the ring length in LDS (qt), mirrored into the quadrant of j -- the floats of samp_dx / samp_dy
+// (ralign_geom.h: sinf(fi) * inr, quadrants by sign and swap) without a trip to memory in front of the taps
+__device__ __forceinline__ float2 ring_pos(const float2 *qt, int lt, int lgl, float fr, int j)
+{
+    const int q = j >> lgl;
+    const float2 sc = qt[j & (lt - 1)];
+    const float x = __fmul_rn(sc.x, fr), y = __fmul_rn(sc.y, fr);
+    const float a = (q & 1) ? y : x, b = (q & 1) ? x : y;
+    return make_float2((q & 2) ? -a : a, ((q + 1) & 2) ? -b : b);
+}
+
 // Polar2Dm (bilinear) [+ Normalize_ring] + Frngs for images of any size.
 //   REFS = false: particles; workgroup = (particle, group of 4 search offsets), wave = offset slot;
 //                 output = the A block of that group (layout of ralign_geom.h: ent_apos).
@@ -268,7 +280,7 @@ __device__ __forceinline__ float2 split_bin(const float2 *Z, int k, int h, float
 // transform itself: the particle spectra are written RAW, the statistics {avg, 1/sigma} of every (particle, offset) go to
 // `stats`, and the contraction applies them (DC bin: a -= avg * sum_r n_r C_r(0); peak records: * 1/sigma).
 template <bool REFS>
-__global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g, const float *__restrict__ images,
+__global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeom g, const float *__restrict__ images,
                                                                       const float *__restrict__ state, int n,
                                                                       float *__restrict__ out, float2 *__restrict__ stats)
 {
@@ -277,7 +289,9 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     float2 *bx = reinterpret_cast<float2 *>(lds) + (size_t)wave * g.maxrin;     // two buffers of maxrin/2 complex
     float2 *by = bx + g.maxrin / 2;
     float2 *tw_s = reinterpret_cast<float2 *>(lds) + (size_t)(RA_GEN_THREADS / 64) * g.maxrin;      // twiddle table in LDS
+    float2 *qt_s = tw_s + g.maxrin;                                                                  // (sinf, cosf) tables of the ring lengths
     for (int i = tid; i < g.maxrin; i += RA_GEN_THREADS) tw_s[i] = g.tw[i];
+    for (int i = tid; i < g.n_qtab; i += RA_GEN_THREADS) qt_s[i] = g.qtab[i];
     __syncthreads();
     const int npix = g.nx * g.nx;
 
@@ -288,9 +302,13 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
         const float c = (float)g.cnx;
         for (int i = wave; i < g.nring; i += RA_GEN_THREADS / 64) {
             const int4 ri = g.ringinfo[i];
-            const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
+            const int nlen = ri.z, h = nlen >> 1, lt = nlen >> 2, lgl = 31 - __clz(lt);
+            const float fr = (float)ri.y;
             float *xr = reinterpret_cast<float *>(bx);
-            for (int j = lane; j < nlen; j += 64) xr[j] = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + c, g.samp_dy[kc + j] + c);
+            for (int j = lane; j < nlen; j += 64) {
+                const float2 d = ring_pos(qt_s + ri.w, lt, lgl, fr, j);
+                xr[j] = bilinear_1b(img, g.nx, d.x + c, d.y + c);
+            }
             wave_lds_sync();
             const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
             float *dst = out + (size_t)r * g.lring + ri.x;
@@ -337,8 +355,9 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
                 const int i = c4 + r;
                 if (i < g.nring) {        // uniform
                     const int4 ri = g.ringinfo[i];
-                    const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
-                    const float wt = g.ringw[i];
+                    const int nlen = ri.z, h = nlen >> 1, lt = nlen >> 2, lgl = 31 - __clz(lt);
+                    const float wt = g.ringw[i], fr = (float)ri.y;
+                    const float2 *qt = qt_s + ri.w;
                     float *xr = reinterpret_cast<float *>(bx);
                     float a = 0.f, q = 0.f;
                     // four samples per trip: their 16 image taps (L2) are in flight together; the Normalize_ring partial
@@ -348,7 +367,8 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const int j = min(j0 + 64 * u, nlen - 1);
-                            sv[u] = RA_DBG(g, 512) ? (float)j : bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+                            const float2 d = ring_pos(qt, lt, lgl, fr, j);
+                            sv[u] = RA_DBG(g, 512) ? (float)j : bilinear_1b(img, g.nx, d.x + cx, d.y + cy);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++)
@@ -386,12 +406,13 @@ __global__ __launch_bounds__(RA_GEN_THREADS) void polar_generic_kernel(DevGeom g
     } else
     for (int i = 0; i < g.nring; i++) {
         const int4 ri = g.ringinfo[i];
-        const int nlen = ri.z, h = nlen >> 1, kc = ri.x - kRingPad * i;
-        const float wt = g.ringw[i];
+        const int nlen = ri.z, h = nlen >> 1, lt = nlen >> 2, lgl = 31 - __clz(lt);
+        const float wt = g.ringw[i], fr = (float)ri.y;
         float *xr = reinterpret_cast<float *>(bx);
         float a = 0.f, q = 0.f;
         for (int j = lane; j < nlen; j += 64) {
-            const float sv = bilinear_1b(img, g.nx, g.samp_dx[kc + j] + cx, g.samp_dy[kc + j] + cy);
+            const float2 d = ring_pos(qt_s + ri.w, lt, lgl, fr, j);
+            const float sv = bilinear_1b(img, g.nx, d.x + cx, d.y + cy);
             xr[j] = sv;
             a += sv * wt; q += sv * sv * wt;
         }

@@ -139,7 +139,11 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
     const int y0 = min(max(iy, 1), nx) - 1, y1 = min(y0 + 1, nx - 1);
     // (the two taps of a row as one 4-byte-aligned 8-byte load: measured SLOWER, 15.7 -> 18.9 ms per chunk of the generic polar
     // stage, whose time is 57 % sampling)
-    float f00 = img[y0 * nx + x0], f10 = img[y0 * nx + x1], f01 = img[y1 * nx + x0], f11 = img[y1 * nx + x1];
+    // (unsigned offsets: a wave-uniform image pointer then stays in scalar registers and every tap is one 32-bit lane offset)
+    const unsigned r0 = (unsigned)(y0 * nx), r1 = (unsigned)(y1 * nx);
+    const char *ib = reinterpret_cast<const char *>(img);
+    auto tap = [&](unsigned idx) { return *reinterpret_cast<const float *>(ib + 4u * idx); };      // 32-bit byte offset (images < 4 GB)
+    float f00 = tap(r0 + (unsigned)x0), f10 = tap(r0 + (unsigned)x1), f01 = tap(r1 + (unsigned)x0), f11 = tap(r1 + (unsigned)x1);
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
 }
 
