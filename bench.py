@@ -37,7 +37,7 @@ WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
     "mref": ("configs[1]", 90, 36, 3.0, 10, 50000, 6, 1),
     "reffree": ("configs[2]", 90, 36, 3.0, 1, 50000, 10, 1),
-    "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 4096, 2, 1),
+    "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 8192, 2, 1),
     "mref50": ("configs[3], one GPU's share", 90, 36, 3.0, 50, 125000, 3, 1),
 }
 

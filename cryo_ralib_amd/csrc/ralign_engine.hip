@@ -475,6 +475,22 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
         const size_t cap = std::max<size_t>(2, ((size_t)12 << 30) / per_particle);
         if ((size_t)chunk > cap) chunk = (int)(cap & ~(size_t)1);
     }
+    if (generic && g.maxrin == 1024 && !(getenv("RALIGN_GCCF_SPLIT") && atoi(getenv("RALIGN_GCCF_SPLIT")) == 0) && cfg.chunk <= 0) {
+        // split contraction: a chunk is walked in slices of nblk blocks, one block per workgroup, and a slice takes its time
+        // whether it is full or not (341 particles = 2580 blocks of 4 x 7 tiles = 10 slices of 256 + one of 20): take the chunk
+        // size, up to 64 particles below the cap, with the most particles per slice
+        const bool wide = gccf_wide_blocks(nrtile);
+        const int tm = wide ? gccf_tm(nrtile, g.maxrin) : 2, tr = wide ? 7 : 2, nblk = tm >= 4 ? 256 : 512;
+        int best = chunk;
+        double best_pps = 0.0;
+        for (int cn = chunk; cn >= std::max(2, chunk - 64); cn -= 2) {
+            const long long n_mtile = ((long long)cn * g.nshift_pad + 7) / 8;
+            const long long ntask = ((n_mtile + tm - 1) / tm) * ((nrtile + tr - 1) / tr), slices = (ntask + nblk - 1) / nblk;
+            const double pps = (double)cn / (double)slices;
+            if (pps > best_pps) { best_pps = pps; best = cn; }
+        }
+        chunk = best;
+    }
     w.chunk = chunk;
     w.a_floats = ((size_t)chunk * ngroup + 2) * a_blk;
     w.cand_recs = ((size_t)chunk * g.nshift_pad + 8) * nrtile;
