@@ -480,7 +480,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
         // whether it is full or not (341 particles = 2580 blocks of 4 x 7 tiles = 10 slices of 256 + one of 20): take the chunk
         // size, up to 64 particles below the cap, with the most particles per slice
         const bool wide = gccf_wide_blocks(nrtile);
-        const int tm = wide ? gccf_tm(nrtile, g.maxrin) : 2, tr = wide ? 7 : 2, nblk = tm >= 4 ? 256 : 512;
+        const int tm = wide ? gccf_tm(nrtile, g.maxrin) : 2, tr = wide ? 7 : 2, nblk = (tm >= 4 ? 256 : 512) * gccf_blocks_per_wg();
         int best = chunk;
         double best_pps = 0.0;
         for (int cn = chunk; cn >= std::max(2, chunk - 64); cn -= 2) {
@@ -500,6 +500,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup, x 14 for the 2 x 7 blocks (gccf_tm; 4 x 7: half the workgroups)
     const bool wide2 = generic && gccf_tm(nrtile, g.maxrin) >= 2;
     w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * (g.maxrin + 2) : 0;      // + 2: N/2 + 1 bins of two values (split kernels)
+    if (generic && g.maxrin == 1024) w.zscr_recs *= gccf_blocks_per_wg();
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
     const size_t tables = ((size_t)g.LBP * (8 + 16 + 2) + (size_t)g.lcirc * 4 + (size_t)g.nx * g.nx + (size_t)g.maxrin * 8 + (1 << 16)) * sizeof(float);
@@ -1290,9 +1291,10 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             const int TMv = wide ? tmv : 2, TRv = wide ? 7 : 2;
             const int n_mt2 = (n_mtile + TMv - 1) / TMv, n_rt2 = (e->nrtile + TRv - 1) / TRv, ntask = n_mt2 * n_rt2;
             const size_t lds2 = ((size_t)8 * RA_IFFT3_PSTRIDE + 16 * 16 + 16 * 64) * sizeof(float2);
-            const int nblk = TMv >= 4 ? e->g_nblk / 2 : e->g_nblk;          // 4 x 7 blocks: one workgroup per CU (256 registers)
+            const int nwg = TMv >= 4 ? e->g_nblk / 2 : e->g_nblk;           // 4 x 7 blocks: one workgroup per CU (256 registers)
+            const int nblk = nwg * gccf_blocks_per_wg();                    // blocks per slice (the scratch holds them)
             auto launch = [&](auto ccfk, auto ifftk, int task0, int nt, int grid2) {
-                hipLaunchKernelGGL(ccfk, dim3(nt), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
+                hipLaunchKernelGGL(ccfk, dim3(std::min(nt, nwg)), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
                                    e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
                 hipLaunchKernelGGL(ifftk, dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
                                    (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);

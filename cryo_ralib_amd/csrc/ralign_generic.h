@@ -453,6 +453,14 @@ inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 
 // particle-offset tiles per block of the x 7 shape: 4 at maxrin 1024 (split kernels; the contraction waits on its operand stream -- 8
 // requests of 1 KB per 7 matrix instructions at 1 x 7, 11 per 28 at 4 x 7, 214 registers, one workgroup per CU: contraction +
 // transforms 36.3 / 31.9 / 30.2 ms per chunk at TM = 1 / 2 / 4), 1 elsewhere; RALIGN_GCCF_TM = 1 | 2 | 4 overrides (4: split kernels only)
+// blocks a contraction workgroup walks per slice of the split kernels: 2 (the scratch holds a slice: 7.5 GB at configs[4];
+// fewer launches and tails: 27.9 / 27.6 / 27.1 ms per chunk at 1 / 2 / 5 blocks); RALIGN_GCCF_BPW = 1 .. 8 overrides
+inline int gccf_blocks_per_wg()
+{
+    const char *ev = getenv("RALIGN_GCCF_BPW");
+    const int v = ev ? atoi(ev) : 0;
+    return v >= 1 && v <= 8 ? v : 2;
+}
 inline int gccf_tm(int nrtile, int maxrin)
 {
     if (!gccf_wide_blocks(nrtile)) return 1;
@@ -478,7 +486,6 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = RA_GCCF_THREADS / 64;
     constexpr int ZPAIRS = 64 * TM * TR;
-    float2 *zs = zscr + (size_t)blockIdx.x * ZPAIRS * (SPLIT ? N + 2 : N);      // SPLIT: N/2 + 1 bins of 16 bytes per pair
     float2 *xb = reinterpret_cast<float2 *>(lds);
     const int pstride = N + 1;              // complex slots per pair: one N-point buffer (in-place transform) + 1 (bank skew)
     float2 *tw_s = xb + (size_t)P * pstride;          // twiddles of the inverse transforms, in LDS
@@ -488,8 +495,11 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
     }
 
     const int n_mt2 = (n_mtile + TM - 1) / TM, n_rt2 = (nrtile + TR - 1) / TR;
-    const int task = task0 + (int)blockIdx.x;          // SPLIT: one block per workgroup
-    if (SPLIT && (int)blockIdx.x >= ntask) return;
+    // SPLIT: the workgroup takes blocks task0 + blockIdx.x, + gridDim.x, .. of the slice; block tl leaves its spectra in zscr[tl]
+    // (N/2 + 1 bins of 16 bytes per pair)
+    for (int tl = SPLIT ? (int)blockIdx.x : 0; tl < (SPLIT ? ntask : 1); tl += SPLIT ? (int)gridDim.x : 1) {
+    const int task = task0 + tl;
+    float2 *zs = zscr + (size_t)(SPLIT ? tl : (int)blockIdx.x) * ZPAIRS * (SPLIT ? N + 2 : N);
     for (int mt2 = SPLIT ? task / n_rt2 : (int)blockIdx.x; mt2 < n_mt2; mt2 += SPLIT ? n_mt2 : (int)gridDim.x) {
         for (int rt2 = SPLIT ? task % n_rt2 : 0; rt2 < n_rt2; rt2 += SPLIT ? n_rt2 : 1) {
             // ---- phase 1: contraction per Fourier bin (operand layout of ccf_kernel), TM x TR tiles per operand fetch
@@ -686,6 +696,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
                 __syncthreads();
             }
         }
+    }
     }
 }
 
