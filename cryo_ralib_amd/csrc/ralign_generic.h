@@ -138,12 +138,12 @@ __device__ __forceinline__ void wave_fft_dif(float2 *x, int h, const float2 *__r
         wave_lds_sync();
     }
 }
-// Inverse FFT of N = R12 * R12 * R3 complex points (1024 = 16 x 16 x 4) by one wave, three register stages with two LDS
-// transposes in between (wave_fft_dif runs five radix-4 stages through the LDS, each with a wave hand-off):
+// Inverse FFT of N = R12 * R12 * R3 complex points (1024 = 16 x 16 x 4) by one wave, three register stages with one LDS
+// transpose and one quad exchange in between (wave_fft_dif runs five radix-4 stages through the LDS, each with a wave hand-off):
 //   n = R12 R3 n1 + R3 n2 + n3,  k = k1 + R12 k2 + R12^2 k3
 //   A [k1; n2 n3] = sum_n1 x W_R12^{n1 k1},           lane = (n2, n3):   x[64 n1 + lane], then * W_{R12^2}^{n2 k1}
 //   B [k1 k2; n3] = sum_n2 A W_R12^{n2 k2},           lane = (k1, n3):   then * W_N^{n3 (k1 + R12 k2)}
-//   X [k]         = sum_n3 B W_R3^{n3 k3},            lane takes R12^2 / 64 pairs (k1, k2), in place
+//   X [k]         = sum_n3 B W_R3^{n3 k3},            across the R3 = 4 lanes (k1, 0..3) of a quad (DPP), stored once
 // x: the pair's LDS image, rows of 64 complex padded by R3 (row stride 64 + R3: the stride-R3 reads of stage B spread over
 // the banks); the transform ends in the same image, element k in slot ifft3_slot(k) (the 7-point neighbourhood of the peak is
 // read from it).  tw[m] = e^{-2 pi i m / N} (conjugated here: inverse, unscaled).  Running maxima of Re (q) and Im (t) with the
@@ -193,29 +193,30 @@ __device__ __forceinline__ void wave_ifft3_argmax(float2 *x, const float2 *__res
         Dft<1, R12>::run(v);
 #pragma unroll
         for (int k2 = 0; k2 < R12; k2++) v[k2] = cmul(v[k2], twb[k2 * 64 + lane]);       // n3 = 0: w = 1
+        // ---- stage C: DFT-4 over n3 = the four lanes of a quad, through DPP instead of a third pass over the image: the
+        // butterflies of vdft4 (a0 +- a2, a1 +- a3, the odd difference turned by +i, then sums and differences of neighbours),
+        // the same additions in the same pairs, so the values are those of Dft<1, 4> bit for bit; lane n3 ends with
+        // X[k1 + R12 k2 + R12^2 s(n3)], s = 0 2 1 3, and stores it in the slot of B[k1 k2; s(n3)] (ifft3_slot)
+        static_assert(R3 == 4, "stage C is written for quads");
+        const float sg2 = (lane & 2) ? -1.0f : 1.0f, sg1 = (lane & 1) ? -1.0f : 1.0f;
+        const bool l3 = n3 == 3;
+        const int s3 = ((n3 & 1) << 1) | (n3 >> 1);
+        bq = -1.0e20f; bt = -1.0e20f; iq = -1; it = -1;
         wave_lds_sync();
 #pragma unroll
-        for (int k2 = 0; k2 < R12; k2++) x[k1 * RS + k2 * R3 + n3] = v[k2];
-    }
-    wave_lds_sync();
-    // ---- stage C: pair (k1, k2) = (c * 64 + lane) / R12, % R12: DFT-R3 over n3 in place -- X[k1 + R12 k2 + R12^2 k3] takes the
-    // slot of B[k1 k2; n3 = k3] (ifft3_slot) -- and running maxima
-    bq = -1.0e20f; bt = -1.0e20f; iq = -1; it = -1;
-    constexpr int NC = R12 * R12 / 64;
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int pr = c * 64 + lane, k1 = pr / R12, k2 = pr % R12;
-        float2 xo[R3];
-#pragma unroll
-        for (int n3 = 0; n3 < R3; n3++) xo[n3] = x[k1 * RS + k2 * R3 + n3];
-        Dft<1, R3>::run(xo);
-#pragma unroll
-        for (int k3 = 0; k3 < R3; k3++) {
-            const int k = k1 + R12 * k2 + R12 * R12 * k3;
-            const float2 z = xo[k3];
+        for (int k2 = 0; k2 < R12; k2++) {
+            const float2 a = v[k2];
+            const float tx = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0x4E, 0xF, 0xF, true));      // lane ^ 2
+            const float ty = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0x4E, 0xF, 0xF, true));
+            const float bx = __builtin_fmaf(sg2, a.x, tx), by = __builtin_fmaf(sg2, a.y, ty);         // a + t | t - a (exact products)
+            const float cx = l3 ? -by : bx, cy = l3 ? bx : by;                                         // lane 3: (a1 - a3) * i
+            const float ux = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cx), 0xB1, 0xF, 0xF, true));       // lane ^ 1
+            const float uy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cy), 0xB1, 0xF, 0xF, true));
+            const float2 z = make_float2(__builtin_fmaf(sg1, cx, ux), __builtin_fmaf(sg1, cy, uy));
+            const int k = k1 + R12 * k2 + R12 * R12 * s3;
             if (z.x > bq || (z.x == bq && k > iq)) { bq = z.x; iq = k; }
             if (z.y > bt || (z.y == bt && k > it)) { bt = z.y; it = k; }
-            x[k1 * RS + k2 * R3 + k3] = z;
+            x[k1 * RS + k2 * R3 + s3] = z;
         }
     }
 #pragma unroll
