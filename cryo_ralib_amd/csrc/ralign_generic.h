@@ -729,7 +729,8 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
         // scratch [bin 0 .. N/2][pairs]{Z_k, Z_{N-k}} -> LDS [pair][k]: pairs sub * 64 + 8 o .. + 7 are 128 contiguous bytes per bin;
         // bins 0 and N/2 are their own partners: the second value is the one that counts (the order of the unsplit kernel's stores)
         const float4 *src = reinterpret_cast<const float4 *>(zscr + (size_t)tl * ZPAIRS * (N + 2)) + sub * 64 + 8 * o;
-        __syncthreads();                                   // the previous batch's records and images are consumed
+        // (no barrier here: behind the one in front of the record reduction nobody reads the images any more, and the records are
+        // written again only behind the next one)
         {
             constexpr int NT = 8 * (N / 2) / RA_GCCF_THREADS;
             float4 t[NT], tn = make_float4(0.f, 0.f, 0.f, 0.f);
