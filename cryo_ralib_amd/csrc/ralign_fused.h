@@ -426,6 +426,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         tws[i] = make_float2(t.x, -t.y);
     }
     for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;      // slack between rings must hold finite values
+    for (int i = tid; i < g.pst * g.pst; i += RF_THREADS) img[i] = 0.f;    // zero border of the padded image (load_image writes the pixels only)
     for (int i = tid; i < RF_MAXREF; i += RF_THREADS) cdc_s[i] = i < nref ? f.cdc_w[i] : 0.f;
     for (int i = tid; i < f.ng * f.gstr; i += RF_THREADS) {
         const int m = i / f.gstr, j = i - m * f.gstr;
@@ -457,8 +458,28 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
     const int npw = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nslots = npw * SPP, npass = (nslots + 3) >> 2;
     auto particle_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    // the particle's pixels into the padded LDS image (its zero border is written once, above).  Boxes up to 128 x 128: a wave
+    // per row, every request of the wave (<= 8 rows x 2 pieces of 64 pixels) in flight at once -- as a loop over rows with the zero
+    // padding inside, each wave made its ~14 round trips to HBM one after the other.
     auto load_image = [&](int i) {
         const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
+        if (g.nx <= 128) {
+            // global -> LDS without a stop in registers (global_load_lds_dword: lane l of a request writes LDS dword base + l,
+            // i.e. a piece of 64 pixels of one image row)
+            // (a rolled loop: the requests carry no registers, so nothing in it waits, and the kernel's code stays small -- unrolled
+            // over 8 rows at both call sites it grew by 3.9 KB and every pass slowed down by 4 %)
+#pragma unroll 1
+            for (int y = wave; y < g.nx; y += RF_WAVES) {
+                const float *row = src + y * g.nx;
+                float *dst = img + (y + g.bd) * g.pst + g.bd;
+                if (lane < g.nx)
+                    __builtin_amdgcn_global_load_lds(row + lane, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+                if (lane + 64 < g.nx)
+                    __builtin_amdgcn_global_load_lds(row + 64 + lane, (__attribute__((address_space(3))) void *)(dst + 64), 4, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
             const int y = row - g.bd;
             const bool yin = y >= 0 && y < g.nx;
