@@ -164,6 +164,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
         tws[i] = make_float2(t.x, -t.y);
     }
     for (int i = tid; i < 4 * g.sbuf; i += RF_THREADS) bufs[i] = 0.f;
+    for (int i = tid; i < npad; i += RF_THREADS) img[i] = 0.f;            // zero border of the padded image
     for (int i = tid; i < nref; i += RF_THREADS) cdc_s[i] = f.cdc_w[i];
     for (int i = tid; i < f.ng * f.gstr; i += RF_THREADS) {
         const int m = i / f.gstr, j = i - m * f.gstr;
@@ -183,6 +184,20 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
     RF_LDS_BARRIER();
     const float *src = particles + (size_t)p * g.nx * g.nx;
+    if (g.nx <= 128) {
+        // pixels only (the zero border is written once, above), global -> LDS without a stop in registers, every request of the
+        // wave in flight at once (search_fused_kernel: load_image)
+#pragma unroll 1
+        for (int y = wave; y < g.nx; y += RF_WAVES) {
+            const float *row = src + y * g.nx;
+            float *dst = img + (y + g.bd) * g.pst + g.bd;
+            if (lane < g.nx)
+                __builtin_amdgcn_global_load_lds(row + lane, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+            if (lane + 64 < g.nx)
+                __builtin_amdgcn_global_load_lds(row + 64 + lane, (__attribute__((address_space(3))) void *)(dst + 64), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
     for (int row = wave; row < g.pst; row += RF_WAVES) {
         const int y = row - g.bd;
         const bool yin = y >= 0 && y < g.nx;
