@@ -57,6 +57,7 @@ struct FusedGeom {
     const float *cdc_w;            // [nref] DC weights of the references: sum over rings of n_r * B_r(bin 0) (ref_dc_weights_kernel)
     int wmap[16];                  // contraction role of wave w: bin group | share of the reference pairs << 8 (balance_waves)
     int stat_wave[4];              // the wave that reduces the Normalize_ring partials of offset slot s
+    int ctr_wave;                  // the wave that writes the next pass's sampling centres (slack behind its contraction, no statistics)
     int ntile, nh;                 // search_tiled_kernel (ralign_tiled.h): reference tiles per pass, reference pairs per tile
     int ifft_full;                 // inverse-FFT slots 32 .. go to waves 8, 9, .. in FULL calls (4 transforms each) instead of half-filled ones
 };
@@ -160,6 +161,12 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
             light[c] = w;            // items arrive heaviest first: the last one of a class is its lightest
         }
         for (int q = 0; q < 4; q++) f.stat_wave[q] = light[q];
+        // the next pass's sampling centres (two dependent global reads in front of the wave's contraction): the third wave of SIMD 0
+        // (wave 8: 3.8 k cycles of slack at the barrier behind the contraction in the headline geometry; wave 4, which ended that
+        // phase, did it until round 4: 29.6 -> 29.35 ms per 50 k), or the next wave that reduces no statistics
+        f.ctr_wave = 8;
+        for (int w : {8, 9, 10, 11, 4, 5, 6, 7})
+            if (w != light[0] && w != light[1] && w != light[2] && w != light[3]) { f.ctr_wave = w; break; }
     }
     out.cdc_w.assign(g.nring, 0.f);
     if (g.nring > 64) return false;
@@ -626,8 +633,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
                 rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
             }
             if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
-        } else if (wave == 4 && lane < 4 && grp + 1 < npass) {
-            // sampling centres of the next pass: this pass's ring jobs are done with the current ones
+        } else if (wave == f.ctr_wave && lane < 4 && grp + 1 < npass) {
+            // sampling centres of the next pass: this pass's ring jobs are done with the current ones (rf_plan: ctr_wave)
             int in = i0, sn = s0 + 4;
             if (sn >= SPP) { sn -= SPP; in++; }
             write_centre(in, sn, (int)lane);
