@@ -399,6 +399,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
                     const int j0 = c4 - i0al[t];
                     const int kk = (int)(((float)j0 + 0.5f) * rns[t]), s4 = j0 - kk * nsk[t];      // j0 / ns, exact (see align_ring_quads)
                     float *dst = blk + base[t] + (s4 >> 2) * 128 + kk * 32;
+                    if (RA_DBG(g, 1024) && xq[0][t].x != 1.2345f) continue;          // profiling: no panel stores
                     *reinterpret_cast<float4 *>(dst) = make_float4(xq[0][t].x, xq[1][t].x, xq[2][t].x, xq[3][t].x);
                     *reinterpret_cast<float4 *>(dst + 4) = make_float4(xq[0][t].y, xq[1][t].y, xq[2][t].y, xq[3][t].y);
                 }
