@@ -465,36 +465,24 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
     const int npw = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nslots = npw * SPP, npass = (nslots + 3) >> 2;
     auto particle_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
-    // the particle's pixels into the padded LDS image (its zero border is written once, above).  Boxes up to 128 x 128: a wave
-    // per row, every request of the wave (<= 8 rows x 2 pieces of 64 pixels) in flight at once -- as a loop over rows with the zero
-    // padding inside, each wave made its ~14 round trips to HBM one after the other.
+    // the particle's pixels into the padded LDS image (its zero border is written once, above): a wave per row, every request of
+    // the wave in flight at once -- as a loop over rows with the zero padding inside, each wave made its ~14 round trips to HBM one
+    // after the other.
     auto load_image = [&](int i) {
         const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
-        if (g.nx <= 128) {
-            // global -> LDS without a stop in registers (global_load_lds_dword: lane l of a request writes LDS dword base + l,
-            // i.e. a piece of 64 pixels of one image row)
-            // (a rolled loop: the requests carry no registers, so nothing in it waits, and the kernel's code stays small -- unrolled
-            // over 8 rows at both call sites it grew by 3.9 KB and every pass slowed down by 4 %)
+        // global -> LDS without a stop in registers (global_load_lds_dword: lane l of a request writes LDS dword base + l, i.e. a
+        // piece of 64 pixels of one image row).  A rolled loop: the requests carry no registers, so nothing in it waits, and the
+        // kernel's code stays small -- unrolled over 8 rows at both call sites it grew by 3.9 KB and every pass slowed down by 4 %.
 #pragma unroll 1
-            for (int y = wave; y < g.nx; y += RF_WAVES) {
-                const float *row = src + y * g.nx;
-                float *dst = img + (y + g.bd) * g.pst + g.bd;
-                if (lane < g.nx)
-                    __builtin_amdgcn_global_load_lds(row + lane, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-                if (lane + 64 < g.nx)
-                    __builtin_amdgcn_global_load_lds(row + 64 + lane, (__attribute__((address_space(3))) void *)(dst + 64), 4, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
+        for (int y = wave; y < g.nx; y += RF_WAVES) {
+            const float *row = src + y * g.nx;
+            float *dst = img + (y + g.bd) * g.pst + g.bd;
+#pragma unroll 1
+            for (int c0 = 0; c0 < g.nx; c0 += 64)
+                if (c0 + lane < g.nx)
+                    __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
         }
-        for (int row = wave; row < g.pst; row += RF_WAVES) {        // a wave per padded row: no per-pixel division
-            const int y = row - g.bd;
-            const bool yin = y >= 0 && y < g.nx;
-            for (int c = lane; c < g.pst; c += 64) {
-                const int x = c - g.bd;
-                img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // sampling centre of slot k of the pass that starts at (particle i0, offset s0): lanes 0 .. 3 of one wave
     auto write_centre = [&](int i0, int s0, int k) {

@@ -184,27 +184,19 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
     RF_LDS_BARRIER();
     const float *src = particles + (size_t)p * g.nx * g.nx;
-    if (g.nx <= 128) {
+    {
         // pixels only (the zero border is written once, above), global -> LDS without a stop in registers, every request of the
         // wave in flight at once (search_fused_kernel: load_image)
 #pragma unroll 1
         for (int y = wave; y < g.nx; y += RF_WAVES) {
             const float *row = src + y * g.nx;
             float *dst = img + (y + g.bd) * g.pst + g.bd;
-            if (lane < g.nx)
-                __builtin_amdgcn_global_load_lds(row + lane, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-            if (lane + 64 < g.nx)
-                __builtin_amdgcn_global_load_lds(row + 64 + lane, (__attribute__((address_space(3))) void *)(dst + 64), 4, 0, 0);
+#pragma unroll 1
+            for (int c0 = 0; c0 < g.nx; c0 += 64)
+                if (c0 + lane < g.nx)
+                    __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else
-    for (int row = wave; row < g.pst; row += RF_WAVES) {
-        const int y = row - g.bd;
-        const bool yin = y >= 0 && y < g.nx;
-        for (int c = lane; c < g.pst; c += 64) {
-            const int x = c - g.bd;
-            img[row * g.pst + c] = (yin && x >= 0 && x < g.nx) ? src[y * g.nx + x] : 0.f;
-        }
     }
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
     const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
