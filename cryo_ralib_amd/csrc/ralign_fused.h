@@ -497,6 +497,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         red[7] = 0.f;
     };
     // this wave's job of round 0 is the same in every pass
+    if (tid < 4 && npw > 0) write_centre(0, 0, (int)tid);          // sampling centres of the stream's first pass
     RF_LDS_BARRIER();
     const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     constexpr bool defer = ONE;         // one store / inverse-FFT round per pass: its end is the arrival counter, not a barrier
@@ -533,10 +534,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         const float *Bf = cls ? Bf0 + (size_t)cls[particle_of(i0)] * f.b_floats : Bf0;
         if (img_i != i0) {
             // a new particle starts with this pass: every wave is through with the sampling of the previous pass (barrier 1 of
-            // that pass), so the image may go; the centres of a stream's first pass are written here
+            // that pass), so the image may go
             load_image(i0);
             img_i = i0;
-            if (grp == 0 && tid < 4) write_centre(0, 0, (int)tid);
             RF_LDS_BARRIER();
         }
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel).
