@@ -532,13 +532,6 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         const int a = min(4, SPP - s0);
         const bool split = PACK && a < nlive;
         const float *Bf = cls ? Bf0 + (size_t)cls[particle_of(i0)] * f.b_floats : Bf0;
-        if (img_i != i0) {
-            // a new particle starts with this pass: every wave is through with the sampling of the previous pass (barrier 1 of
-            // that pass), so the image may go
-            load_image(i0);
-            img_i = i0;
-            RF_LDS_BARRIER();
-        }
         // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFT of the 4 offsets (as polar_fft_kernel).
         // The spectra of the previous pass occupy the ring buffers until its inverse FFTs are done; the wait for that
         // (PassSync: an arrival counter) sits INSIDE this pass's first ring job, after the sampling (which touches only the
@@ -551,10 +544,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
             // two barriers -- over [a, nlive)
 #pragma unroll 1
             for (int ph = 0; ph < (split ? 2 : 1); ph++) {
-                if (ph) {
-                    RF_LDS_BARRIER();
-                    load_image(i0 + 1);
-                    img_i = i0 + 1;
+                if (img_i != i0 + ph) {
+                    // the next particle's image (one copy of the load): at the top of a pass every wave is through with the sampling
+                    // of the previous pass (barrier 1 of that pass), so the image may go; inside a pass the first job round has to end
+                    if (ph) RF_LDS_BARRIER();
+                    load_image(i0 + ph);
+                    img_i = i0 + ph;
                     RF_LDS_BARRIER();
                 }
                 const int slo = ph ? a : 0, shi = (split && !ph) ? a : nlive;
