@@ -728,7 +728,7 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
 // One launch of a particle-resident kernel takes up to RA_RESIDENT_BATCH particles (cfg.chunk > 0: that many): every launch
 // ends with a tail in which the CUs run dry one by one, ~1 % of a 7 000-particle launch (measured: 7 launches 30.9 ms, 5 launches
 // 30.6 ms per 50 000 particles); its candidate records (2 KB per particle at 49 offsets) and the refine list grow on demand.
-#define RA_RESIDENT_BATCH 65536
+#define RA_RESIDENT_BATCH 131072
 static int resident_batch(const ra_engine *e, int n)
 {
     return std::max(1, std::min(n, e->cfg.chunk > 0 ? e->chunk : RA_RESIDENT_BATCH));
