@@ -17,6 +17,7 @@
 #include "ralign_generic.h"
 #include "ralign_fused.h"
 #include "ralign_tiled.h"
+#include "ralign_solo.h"
 #include "ralign_exact.h"
 #include "ralign_refine.h"
 
@@ -102,6 +103,7 @@ struct ra_engine {
     std::vector<float> ringw_h;
     bool fused = false;                 // plan valid and not disabled (RALIGN_FUSED=0)
     bool tiled = false;                 // the plan is search_tiled_kernel's (ralign_tiled.h: reference tiles, more than RF_MAXREF references)
+    bool solo = false;                  // search_solo_kernel (ralign_solo.h: maxrin 512, one offset resident per pass) on top of the generic tables
     float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
     size_t f_cap_b = 0;
@@ -150,6 +152,14 @@ static bool tiled_wanted(const ra_engine *e)
     if (getenv("RALIGN_TILED") && !force) return false;
     // (from 15 references on: search_fused_kernel needs two spectra rounds per pass from 12 on and is 4 % slower at 15 and 16)
     return (e->cfg.nref >= RT_MINREF || force) && e->geo.maxrin == 256 && e->geo.nring <= 4 * RT_NQ && e->cfg.nref <= 127;
+}
+
+// search_solo_kernel is planned for this engine: a geometry of the size-generic class whose rings end at 512 samples
+// (RALIGN_SOLO=0: the generic kernels)
+static bool solo_wanted(const ra_engine *e)
+{
+    if (!e->generic || e->geo.maxrin != 512 || e->geo.nring > 4 * RS_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
+    return !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
 }
 
 static bool fused_wanted(const ra_engine *e)
@@ -277,21 +287,24 @@ static int build_device_geometry(ra_engine *e)
             ringinfo[i] = make_int4(g.ring_off[i], g.numr[3 * i], n, qoff[lg]);
             ringw[i] = (float)(g.numr[3 * i] * 2 * M_PI / (float)n);
         }
-        auto code_of = [](int n) { switch (n) { case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
+        auto code_of = [](int n) { switch (n) { case 512: return 10; case 256: return 0; case 128: return 1; case 64: return 2; case 32: return 3; case 16: return 4; case 8: return 5; default: return -1; } };
         for (int i = 0; i < g.nring && !e->generic; i++)
-            if (code_of(g.numr[3 * i + 2]) < 0) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
+            if (code_of(g.numr[3 * i + 2]) < 0 || g.numr[3 * i + 2] > 256) { g_last_error = "ring length not supported by the polar kernel (8..256)"; return RA_ERR_ARG; }
         // job code 6: 256-sample rings with 8 lanes per ring (16 sample pairs per lane, two 8-point rows per lane in
         // the second FFT pass) instead of 16 lanes with half of them idle there; code 7 does the same for 64-sample rings
         // (4 lanes x 8 pairs).  Measured: polar stage 5.64 -> 5.2 ms per 7143 particles.
+        // nslot = 4: the four offset slots of a pass of the LDS-resident kernels; nslot = 1: search_solo_kernel (rings up to 512
+        // samples, code 10: 16 lanes per ring)
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
-            const int lanes_of[8] = {16, 8, 8, 4, 4, 4, 8, 4};
+            const int lanes_of[11] = {16, 8, 8, 4, 4, 4, 8, 4, 0, 0, 16};
+            const bool solo = nslot == 1;
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
-            const bool mixed = nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0));
-            for (int lg = 8; lg >= (mixed ? 6 : 3); lg--) {
+            const bool mixed = solo || (nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
+            for (int lg = solo ? 9 : 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
-                const int code = (n == 256 && nslot == 4) ? 6 : ((n == 64 && nslot == 4) ? 7 : code_of(n));
+                const int code = (n == 256 && (nslot == 4 || solo)) ? 6 : ((n == 64 && (nslot == 4 || solo)) ? 7 : code_of(n));
                 std::vector<int4> cls;
                 std::vector<float> clsw;
                 for (int sft = 0; sft < nslot; sft++)
@@ -332,6 +345,7 @@ static int build_device_geometry(ra_engine *e)
             }
         };
         if (!e->generic) make_jobs(4, jobs, inst, instw);
+        else if (solo_wanted(e)) make_jobs(1, jobs, inst, instw);
         if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
             std::vector<int4> perm;
             for (const char *c = po; *c;) {
@@ -656,6 +670,45 @@ static int setup_fused(ra_engine *e)
     return RA_OK;
 }
 
+typedef void (*solo_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, float *);
+static solo_fn select_solo(int maxrin, int nh)
+{
+    if (maxrin != 512) return nullptr;
+    switch (nh) {
+    case 1: return search_solo_kernel<512, 1>;
+    case 2: return search_solo_kernel<512, 2>;
+    case 3: return search_solo_kernel<512, 3>;
+    case 4: return search_solo_kernel<512, 4>;
+    case 5: return search_solo_kernel<512, 5>;
+    default: return nullptr;
+    }
+}
+
+// plan of search_solo_kernel (ralign_solo.h) for an engine of the size-generic class whose rings end at 512 samples; the generic
+// kernels stay available underneath (reference preparation, RALIGN_SOLO=0, geometries whose image and one ring buffer exceed
+// the LDS)
+static int setup_solo(ra_engine *e)
+{
+    e->solo = false;
+    if (!solo_wanted(e)) return RA_OK;
+    const Geometry &g = e->geo;
+    FusedPlanHost &fp = e->fplan;
+    if (!build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
+    const solo_fn fk = select_solo(g.maxrin, fp.f.nh);
+    if (!fk) { fp.f.on = 0; return RA_OK; }
+    int rc;
+    if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
+    if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
+    if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
+    fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
+    hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(solo): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: solo plan: %zu bytes of LDS, image %d x %d, ring buffer %d floats, %d jobs, %d tiles of %d reference pairs\n",
+                                       fp.lds_bytes, fp.f.s_rows, fp.f.s_pst, fp.f.s_sbuf, e->dg.n_job, fp.f.ntile, fp.f.nh);
+    e->solo = true;
+    return RA_OK;
+}
+
 // tables and buffers of the sub-bin angle refinement (ralign_exact.h): twiddles (float) of the double-precision cos / sin for
 // every power-of-two length, as fftr_q's tables; exact reference spectra; the list of flagged particles of a chunk
 static int setup_refine(ra_engine *e)
@@ -880,6 +933,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
             (rc = dev_alloc(e, &e->d_gcdc, (size_t)cfg->nref, true))) { ra_destroy(e); return rc; }
     }
     if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
+    if ((rc = setup_solo(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_refine(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
@@ -948,7 +1002,7 @@ extern "C" int ra_last_refine_count(ra_engine *e)
     return h;
 }
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
-extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->generic ? 2 : e->fused ? 1 : 0; }
+extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->generic ? 2 : e->fused ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
 extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }
@@ -1227,6 +1281,29 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         RA_HIP(hipGetLastError());
     }
     hipStream_t sp = e->stream;
+    if (e->solo) {
+        // particle-resident search, one offset resident per pass (ralign_solo.h): one persistent workgroup per CU
+        const FusedGeom f = e->fplan.f;
+        const solo_fn fk = select_solo(g.maxrin, f.nh);
+        const int rch = resident_batch(e, n);
+        {
+            int rcw = ensure_resident_ws(e, rch);
+            if (rcw) return rcw;
+        }
+        for (int start = 0; start < n; start += rch) {
+            const int cn = std::min(rch, n - start);
+            float *st = d_state + (size_t)start * 2;
+            std::pair<hipEvent_t, hipEvent_t> *evc = e->timing ? next_events(e->ev_ccf, e->ev_used_ccf) : nullptr;
+            if (evc) RA_HIP(hipEventRecord(evc->first, sp));
+            hipLaunchKernelGGL(fk, dim3(std::min(cn, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, sp, e->dg, f, d_particles + (size_t)start * npix,
+                               (const float *)st, cn, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, (float *)nullptr);
+            RA_HIP(hipGetLastError());
+            if (evc) RA_HIP(hipEventRecord(evc->second, sp));
+            int rcf = finalize_and_refine(e, e->d_fcand, 1, cn, st, d_result + start, d_particles + (size_t)start * npix, e->d_refx, nullptr);
+            if (rcf) return rcf;
+        }
+        return RA_OK;
+    }
     if (e->fused) {
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
@@ -1333,6 +1410,28 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
 {
     if (!e || !d_particles || !d_state || !h_out || n < 1 || n > e->chunk) { g_last_error = "bad argument"; return RA_ERR_ARG; }
     const Geometry &g = e->geo;
+    if (e->solo) {
+        // the polar stage of search_solo_kernel: ring buffer and statistics of every in-window (particle, offset)
+        const size_t rawcnt = (size_t)n * g.nshift * (g.lring + 2), cnt = (size_t)n * g.nshift * g.lcirc;
+        float *d_raw = nullptr, *d_out = nullptr;
+        RA_HIP(hipMalloc((void **)&d_raw, rawcnt * sizeof(float)));
+        hipError_t he = hipMalloc((void **)&d_out, cnt * sizeof(float));
+        if (he == hipSuccess) he = hipMemsetAsync(d_raw, 0, rawcnt * sizeof(float), e->stream);
+        if (he == hipSuccess) {
+            const FusedGeom f = e->fplan.f;
+            hipLaunchKernelGGL(select_solo(g.maxrin, f.nh), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
+                               d_state, n, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, d_raw);
+            hipLaunchKernelGGL(unpack_solo_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, (const float *)d_raw, n,
+                               (const int *)e->d_numr, (const int *)e->d_ring_off, d_out);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he == hipSuccess) he = hipMemcpy(h_out, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(d_raw);
+        if (d_out) (void)hipFree(d_out);
+        RA_HIP(he);
+        return RA_OK;
+    }
     {
         int rcw = ensure_unfused_ws(e);
         if (rcw) return rcw;

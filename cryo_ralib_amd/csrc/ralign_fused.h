@@ -48,9 +48,9 @@ struct FusedGeom {
     int nrpw;                      // reference pairs per wave = ceil(nrp / wpg): template parameter of the kernel
     int rz, nzr, rz_inv;           // references per inverse-FFT round, rounds, ceil(2^16 / rz) (division by multiply-shift)
     int b_floats;
-    int grp_ring0[8];              // first ring that has bins of group m (rings are sorted by length)
-    int grp_boff[8];               // float offset of group m's B block: [pair][ring quad][lane][4 rings]
-    int grp_nq[8];                 // ring quads of group m
+    int grp_ring0[16];             // first ring that has bins of group m (rings are sorted by length)
+    int grp_boff[16];              // float offset of group m's B block: [pair][ring quad][lane][4 rings]
+    int grp_nq[16];                // ring quads of group m
     const int *bsrc;               // [b_floats] (entry << 5 | reference << 1 | imaginary part), -1 = 0
     int roff[68];                  // ring offsets in a ring buffer (padded with the last ring's)
     int gstr;                      // ints per group in the LDS table of ring offsets (quads of 4, padded by one quad)
@@ -60,6 +60,12 @@ struct FusedGeom {
     int ctr_wave;                  // the wave that writes the next pass's sampling centres (slack behind its contraction, no statistics)
     int ntile, nh;                 // search_tiled_kernel (ralign_tiled.h): reference tiles per pass, reference pairs per tile
     int ifft_full;                 // inverse-FFT slots 32 .. go to waves 8, 9, .. in FULL calls (4 transforms each) instead of half-filled ones
+    // search_solo_kernel (ralign_solo.h): one search offset resident per pass (maxrin 512)
+    int s_pst, s_rows;             // row stride and rows of the LDS image (no search-range border: out-of-window offsets are skipped)
+    int s_sbuf;                    // floats of the ring buffer | CCF spectra of a reference tile
+    int s_rank[16];                // wave w runs ring jobs s_rank[w], s_rank[w] + 16, ..; the highest ranks have none
+    int s_call[16];                // inverse-FFT call of wave w in every tile (4 transforms each), -1: none
+    int s_stat, s_ctr, s_rec;      // waves that reduce the Normalize_ring partials, write the next centre, merge the records
 };
 
 struct FusedPlanHost {

@@ -878,6 +878,7 @@ __device__ __forceinline__ float prb1d7(const float *t)
 }
 
 template <int N> struct IfftPlan;
+template <> struct IfftPlan<512> { static constexpr int R1 = 16, R2 = 32; };      // ifft32_argmax: two columns, then one 32-point row per lane
 template <> struct IfftPlan<256> { static constexpr int R1 = 16, R2 = 16; };
 template <> struct IfftPlan<128> { static constexpr int R1 = 16, R2 = 8; };
 template <> struct IfftPlan<64>  { static constexpr int R1 = 8,  R2 = 8; };
@@ -1053,6 +1054,73 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
             dst->jtot = jt + 1;
             dst->refmir = ((mir ? 1 : 0) << 16) | (ref0 + (pr[q] & REFMASK));
         }
+    }
+}
+
+// The same for N = 16 x 32 points (maxrin 512, search_solo_kernel): 16 lanes per transform; in the first pass a lane transforms
+// columns j and j + 16 (two 16-point DFTs over k1), in the second one row of 32 points (Dft<1, 32>), so that lane j again
+// holds the outputs with index = j mod 16 and the argmax / neighbourhood code is the one above.  One spectrum slot per call
+// and lane group; twl = the [n0][column] twiddle table + j.
+template <int N>
+__device__ __forceinline__ void ifft32_argmax(float *Z, CandT *dst, const float2 *twl, int pair, int j, int refid, bool nomirror)
+{
+    typedef ZLayout<N> ZL;
+    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
+    static_assert(R1 == 16 && R2 == 32, "ifft32_argmax: N = 16 x 32");
+    // (the two columns one after the other: 32 registers of data at a time; a column's outputs overwrite its own inputs, which
+    // no other lane of the group reads in this pass)
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        float2 v[16];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, R2 * k1 + j + 16 * cc));
+        Dft<1, R1>::run(v);
+#pragma unroll
+        for (int n0 = 1; n0 < R1; n0++) v[n0] = cmul(v[n0], twl[n0 * R2 + 16 * cc]);
+#pragma unroll
+        for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pair, n0 * R2 + j + 16 * cc)) = v[n0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float2 w[R2];
+#pragma unroll
+    for (int k0 = 0; k0 < R2; k0++) w[k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, j * R2 + k0));
+    Dft<1, R2>::run(w);
+    // maximum first, index second (see ifft_argmax): ">=" scan semantics, straight beats mirrored on equality
+    float bq = -1.0e20f, bt = -1.0e20f;
+#pragma unroll
+    for (int n1 = 0; n1 < R2; n1++) { bq = __builtin_fmaxf(bq, w[n1].x); bt = __builtin_fmaxf(bt, w[n1].y); }
+#define RA_DPP_FMAX(X, CTRL) X = __builtin_fmaxf(X, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xF, 0xF, true)))
+    RA_DPP_FMAX(bq, 0x140); RA_DPP_FMAX(bt, 0x140); RA_DPP_FMAX(bq, 0x141); RA_DPP_FMAX(bt, 0x141);
+    RA_DPP_FMAX(bq, 0x4E); RA_DPP_FMAX(bt, 0x4E); RA_DPP_FMAX(bq, 0xB1); RA_DPP_FMAX(bt, 0xB1);
+#undef RA_DPP_FMAX
+    const bool mir = !nomirror && !(bq >= bt);
+    const float best = mir ? bt : bq;
+    float c[R2];
+    int nb = -1;
+#pragma unroll
+    for (int n1 = 0; n1 < R2; n1++) {
+        c[n1] = mir ? w[n1].y : w[n1].x;
+        nb = c[n1] == best ? n1 : nb;
+    }
+    int jt = nb >= 0 ? R1 * nb + j : -1;
+#define RA_DPP_IMAX(CTRL) jt = max(jt, __builtin_amdgcn_update_dpp(0, jt, CTRL, 0xF, 0xF, true))
+    RA_DPP_IMAX(0x140); RA_DPP_IMAX(0x141); RA_DPP_IMAX(0x4E); RA_DPP_IMAX(0xB1);
+#undef RA_DPP_IMAX
+    // neighbour jt + k (k = -3..3) lives in lane (jt + k) mod R1 at register (jt + k) / R1
+    const int d = (j - jt) & (R1 - 1);
+    const int k = d <= 3 ? d : d - R1;
+    if (k >= -3) {
+        const int n1 = ((jt + k + N) & (N - 1)) / R1;
+        float val = 0.f;
+#pragma unroll
+        for (int r = 0; r < R2; r++) val = (r == n1) ? c[r] : val;
+        dst->t7[k + 3] = val;
+    }
+    if (j == 0) {
+        dst->val = best;
+        dst->jtot = jt + 1;
+        dst->refmir = ((mir ? 1 : 0) << 16) | refid;
     }
 }
 
