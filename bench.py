@@ -33,12 +33,18 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
+SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo (one offset resident per pass)"}
+
 WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
     "mref": ("configs[1]", 90, 36, 3.0, 10, 50000, 6, 1),
     "reffree": ("configs[2]", 90, 36, 3.0, 1, 50000, 10, 1),
     "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 8192, 2, 1),
     "mref50": ("configs[3], one GPU's share", 90, 36, 3.0, 50, 125000, 3, 1),
+    # rings of 512 samples (search_solo_kernel): the reference's own documented run (notebook/00_Multireference_Alignment.ipynb
+    # cell 3: 5000 x 130 x 130, nref = 50, ou = 52) and a 128 x 128 box at the largest radius
+    "nb00": ("reference notebook/00 cell 3 geometry", 130, 52, 3.0, 50, 5000, 3, 1),
+    "box128": ("128 x 128 box, ou = 60 (maxrin 512)", 128, 60, 3.0, 10, 16384, 3, 1),
 }
 
 
@@ -187,8 +193,10 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=4096):
     import torch
     from cryo_ralib_amd import api
     from oracle import oracle as orc
-    if nx > 128:
+    if nx > 130:
         n = 8
+    elif nx > 90:
+        n = 512           # maxrin 512: ~1 k particles/s on 16 threads at nref = 10
     elif nref > 16:
         n = 1024          # the oracle's share of the run grows with the reference count
     rg = orc.rings(1, ou, 1)
@@ -228,7 +236,7 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=4096):
                     "tie_flips": int((~same).sum()),
                     "max_rel_peak_gap_of_flips": float(rel[~same].max()) if (~same).any() else 0.0,
                     "alpha_outliers_gt_2e-3_deg": int((da > 2e-3).sum()), "max_alpha_diff_deg": float(da.max()) if da.size else 0.0}
-        out["search_path"] = {0: "kernel pair", 1: "fused", 2: "generic"}[path]
+        out["search_path"] = SEARCH_PATHS[path]
     return out
 
 
@@ -315,7 +323,12 @@ def run_workload(args, rank, local, world, dev):
         polar_f, ccf_f, S, L, M = algorithmic_flops(nx, ou, xr, xr, 1.0, nref)
         per_launch = n * args.steps / max(n_a, 1)
         kernels = {}
-        if path == 1:
+        if path == 3:
+            kernels["search_solo_kernel<%d>" % M] = {
+                "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + 512-point inverse FFT + argmax, "
+                        "particle-resident, one search offset per pass, reference tiles of <= 10 with the A operand in registers",
+                "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
+        elif path == 1:
             kernels[("search_tiled_kernel<%d>" if tiled else "search_fused_kernel<%d>") % M] = {
                 "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + inverse FFT + argmax, "
                         "particle-resident" + (", reference tiles of <= 10 with the A operand in registers" if tiled else ""), "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
@@ -349,7 +362,7 @@ def run_workload(args, rank, local, world, dev):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "particles_per_gpu": n, "nref": nref, "shifts": S, "parallelism": "dp%d" % world,
-                       "search_path": {0: "kernel pair", 1: "fused", 2: "generic"}[path]},
+                       "search_path": SEARCH_PATHS[path]},
             "roofline": {"bound": "hbm" if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else "mfma",
                          "achieved": hbm_gbps if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else kernels[dom]["achieved_tflops"],
                          "peak": PEAK_HBM_GBPS if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else PEAK_F32_TFLOPS,
@@ -382,7 +395,7 @@ def run_workload(args, rank, local, world, dev):
 
 
 # what the default run adds to the headline line: the other BASELINE configs at one GPU's share, a few steps each
-OTHER_WORKLOADS = ("reffree", "mref50", "largebox")
+OTHER_WORKLOADS = ("reffree", "mref50", "largebox", "nb00", "box128")
 
 
 def main():

@@ -671,15 +671,17 @@ static int setup_fused(ra_engine *e)
 }
 
 typedef void (*solo_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, float *);
-static solo_fn select_solo(int maxrin, int nh)
+static solo_fn select_solo(int maxrin, int nh, int ntile)
 {
     if (maxrin != 512) return nullptr;
+    if (ntile > 1)       // 3 .. 5 pairs per tile (build_solo_plan)
+        return nh == 3 ? search_solo_kernel<512, 3, false> : nh == 4 ? search_solo_kernel<512, 4, false> : nh == 5 ? search_solo_kernel<512, 5, false> : nullptr;
     switch (nh) {
-    case 1: return search_solo_kernel<512, 1>;
-    case 2: return search_solo_kernel<512, 2>;
-    case 3: return search_solo_kernel<512, 3>;
-    case 4: return search_solo_kernel<512, 4>;
-    case 5: return search_solo_kernel<512, 5>;
+    case 1: return search_solo_kernel<512, 1, true>;
+    case 2: return search_solo_kernel<512, 2, true>;
+    case 3: return search_solo_kernel<512, 3, true>;
+    case 4: return search_solo_kernel<512, 4, true>;
+    case 5: return search_solo_kernel<512, 5, true>;
     default: return nullptr;
     }
 }
@@ -694,7 +696,7 @@ static int setup_solo(ra_engine *e)
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
     if (!build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
-    const solo_fn fk = select_solo(g.maxrin, fp.f.nh);
+    const solo_fn fk = select_solo(g.maxrin, fp.f.nh, fp.f.ntile);
     if (!fk) { fp.f.on = 0; return RA_OK; }
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
@@ -1284,7 +1286,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
     if (e->solo) {
         // particle-resident search, one offset resident per pass (ralign_solo.h): one persistent workgroup per CU
         const FusedGeom f = e->fplan.f;
-        const solo_fn fk = select_solo(g.maxrin, f.nh);
+        const solo_fn fk = select_solo(g.maxrin, f.nh, f.ntile);
         const int rch = resident_batch(e, n);
         {
             int rcw = ensure_resident_ws(e, rch);
@@ -1419,7 +1421,7 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
         if (he == hipSuccess) he = hipMemsetAsync(d_raw, 0, rawcnt * sizeof(float), e->stream);
         if (he == hipSuccess) {
             const FusedGeom f = e->fplan.f;
-            hipLaunchKernelGGL(select_solo(g.maxrin, f.nh), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
+            hipLaunchKernelGGL(select_solo(g.maxrin, f.nh, f.ntile), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
                                d_state, n, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, d_raw);
             hipLaunchKernelGGL(unpack_solo_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, (const float *)d_raw, n,
                                (const int *)e->d_numr, (const int *)e->d_ring_off, d_out);

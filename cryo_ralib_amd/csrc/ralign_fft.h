@@ -6,8 +6,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 namespace ralign {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -165,29 +163,6 @@ template <int SIGN> struct Dft<SIGN, 16> {
             vdft4<SIGN>(t0, t1, t2, t3);
             v[c] = to_f2(t0); v[c + 4] = to_f2(t1); v[c + 8] = to_f2(t2); v[c + 12] = to_f2(t3);
         }
-    }
-};
-
-template <int SIGN> struct Dft<SIGN, 32> {
-    static __device__ __forceinline__ void run(float2 *v)
-    {
-        // radix-2 DIT over two 16-point transforms: X[k] = E[k] + W32^k O[k], X[k + 16] = E[k] - W32^k O[k]
-        float2 e[16], o[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
-        Dft<SIGN, 16>::run(e);
-        Dft<SIGN, 16>::run(o);
-        auto fin = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const v2f t = vtw<SIGN, k, 32>(to_v(o[k])), a = to_v(e[k]);
-            v[k] = to_f2(a + t); v[k + 16] = to_f2(a - t);
-        };
-        fin(std::integral_constant<int, 0>{}); fin(std::integral_constant<int, 1>{}); fin(std::integral_constant<int, 2>{});
-        fin(std::integral_constant<int, 3>{}); fin(std::integral_constant<int, 4>{}); fin(std::integral_constant<int, 5>{});
-        fin(std::integral_constant<int, 6>{}); fin(std::integral_constant<int, 7>{}); fin(std::integral_constant<int, 8>{});
-        fin(std::integral_constant<int, 9>{}); fin(std::integral_constant<int, 10>{}); fin(std::integral_constant<int, 11>{});
-        fin(std::integral_constant<int, 12>{}); fin(std::integral_constant<int, 13>{}); fin(std::integral_constant<int, 14>{});
-        fin(std::integral_constant<int, 15>{});
     }
 };
 

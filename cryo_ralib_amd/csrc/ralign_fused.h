@@ -64,7 +64,7 @@ struct FusedGeom {
     int s_pst, s_rows;             // row stride and rows of the LDS image (no search-range border: out-of-window offsets are skipped)
     int s_sbuf;                    // floats of the ring buffer | CCF spectra of a reference tile
     int s_rank[16];                // wave w runs ring jobs s_rank[w], s_rank[w] + 16, ..; the highest ranks have none
-    int s_call[16];                // inverse-FFT call of wave w in every tile (4 transforms each), -1: none
+    int s_call[16];                // the transform (reference of the tile) wave w carries in every tile, -1: none
     int s_stat, s_ctr, s_rec;      // waves that reduce the Normalize_ring partials, write the next centre, merge the records
 };
 

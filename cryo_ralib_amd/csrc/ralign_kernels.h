@@ -878,7 +878,6 @@ __device__ __forceinline__ float prb1d7(const float *t)
 }
 
 template <int N> struct IfftPlan;
-template <> struct IfftPlan<512> { static constexpr int R1 = 16, R2 = 32; };      // ifft32_argmax: two columns, then one 32-point row per lane
 template <> struct IfftPlan<256> { static constexpr int R1 = 16, R2 = 16; };
 template <> struct IfftPlan<128> { static constexpr int R1 = 16, R2 = 8; };
 template <> struct IfftPlan<64>  { static constexpr int R1 = 8,  R2 = 8; };
@@ -1057,67 +1056,106 @@ __device__ __forceinline__ void ifft_argmax(float *Z, CandT *pc, const float2 *t
     }
 }
 
-// The same for N = 16 x 32 points (maxrin 512, search_solo_kernel): 16 lanes per transform; in the first pass a lane transforms
-// columns j and j + 16 (two 16-point DFTs over k1), in the second one row of 32 points (Dft<1, 32>), so that lane j again
-// holds the outputs with index = j mod 16 and the argmax / neighbourhood code is the one above.  One spectrum slot per call
-// and lane group; twl = the [n0][column] twiddle table + j.
-template <int N>
-__device__ __forceinline__ void ifft32_argmax(float *Z, CandT *dst, const float2 *twl, int pair, int j, int refid, bool nomirror)
+// One 512-point inverse transform per WAVE (search_solo_kernel): 512 = 8 x 8 x 8, three 8-point DFTs per lane with two transposes
+// through the transform's own LDS image in between -- 16 registers of data, so it runs next to a full A slice, and a quarter of the
+// dependent chain of the 16-lane form (16 lanes per transform, two 16-point columns and a 32-point row per lane: 13 k cycles per call on the wave timeline, the critical path of a pass).
+//   k = 64 k2 + 8 k1 + k0,  n = n0 + 8 n1 + 64 n2,  W = e^{2 pi i / 512}
+//   A [n0; k1 k0] = sum_k2 Z[64 k2 + 8 k1 + k0] W8^{k2 n0},   lane = 8 k1 + k0;   then * W^{(8 k1 + k0) n0}      (twa[n0][lane])
+//   B [n0 n1; k0] = sum_k1 A W8^{k1 n1},                      lane = 8 n0 + k0;   then * W^{8 k0 n1}             (twb[n1][k0])
+//   x [n]         = sum_k0 B W8^{k0 n2},                      lane = 8 n0 + n1:   outputs n = n0 + 8 n1 + 64 n2 in registers
+// Argmax with the CPU scan's ">=" semantics (the LAST maximum; straight beats mirrored on equality) and the 7-point neighbourhood
+// of the maximum picked out of the registers, as in ifft_argmax.  twa: [8][64], twb: [8][8] (ifft512_twiddles).
+__device__ __forceinline__ void ifft512_twiddles(const float2 *__restrict__ tw512, float2 *twa, float2 *twb, int tid, int nthreads)
 {
-    typedef ZLayout<N> ZL;
-    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
-    static_assert(R1 == 16 && R2 == 32, "ifft32_argmax: N = 16 x 32");
-    // (the two columns one after the other: 32 registers of data at a time; a column's outputs overwrite its own inputs, which
-    // no other lane of the group reads in this pass)
+    for (int i = tid; i < 8 * 64; i += nthreads) {
+        const float2 w = tw512[((i >> 6) * (i & 63)) & 511];
+        twa[i] = make_float2(w.x, -w.y);
+    }
+    for (int i = tid; i < 64; i += nthreads) {
+        const float2 w = tw512[(8 * (i >> 3) * (i & 7)) & 511];
+        twb[i] = make_float2(w.x, -w.y);
+    }
+}
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+#define RA_DPP_FMAX(X, CTRL) X = __builtin_fmaxf(X, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xF, 0xF, true)))
+    RA_DPP_FMAX(v, 0x140); RA_DPP_FMAX(v, 0x141); RA_DPP_FMAX(v, 0x4E); RA_DPP_FMAX(v, 0xB1);
+#undef RA_DPP_FMAX
+    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return __builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3));
+}
+__device__ __forceinline__ int wave_imax_dpp(int v)
+{
+#define RA_DPP_IMAX(CTRL) v = max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true))
+    RA_DPP_IMAX(0x140); RA_DPP_IMAX(0x141); RA_DPP_IMAX(0x4E); RA_DPP_IMAX(0xB1);
+#undef RA_DPP_IMAX
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ void ifft512_wave_argmax(float *Z, CandT *dst, const float2 *twa, const float2 *twb, int pair, int lane, int refid,
+                                                    bool nomirror)
+{
+    typedef ZLayout<512> ZL;
+    float2 v[8];
+    float *zp = Z + pair * ZL::kPairStride;
+    auto slot = [&](int sl) { return reinterpret_cast<float2 *>(zp + 2 * (sl + (sl >> 4))); };
+    // ---- stage 1: DFT-8 over k2
 #pragma unroll
-    for (int cc = 0; cc < 2; cc++) {
-        float2 v[16];
+    for (int k2 = 0; k2 < 8; k2++) v[k2] = *slot(64 * k2 + lane);
+    Dft<1, 8>::run(v);
 #pragma unroll
-        for (int k1 = 0; k1 < R1; k1++) v[k1] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, R2 * k1 + j + 16 * cc));
-        Dft<1, R1>::run(v);
+    for (int n0 = 1; n0 < 8; n0++) v[n0] = cmul(v[n0], twa[n0 * 64 + lane]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-        for (int n0 = 1; n0 < R1; n0++) v[n0] = cmul(v[n0], twl[n0 * R2 + 16 * cc]);
+    for (int n0 = 0; n0 < 8; n0++) *slot(64 * n0 + lane) = v[n0];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- stage 2: lane = 8 n0 + k0: DFT-8 over k1
+    {
+        const int n0 = lane >> 3, k0 = lane & 7;
 #pragma unroll
-        for (int n0 = 0; n0 < R1; n0++) *reinterpret_cast<float2 *>(Z + ZL::addr(pair, n0 * R2 + j + 16 * cc)) = v[n0];
+        for (int k1 = 0; k1 < 8; k1++) v[k1] = *slot(64 * n0 + 8 * k1 + k0);
+        Dft<1, 8>::run(v);
+#pragma unroll
+        for (int n1 = 1; n1 < 8; n1++) v[n1] = cmul(v[n1], twb[n1 * 8 + k0]);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) *slot(64 * n0 + 8 * n1 + k0) = v[n1];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float2 w[R2];
+    // ---- stage 3: lane = 8 n0 + n1: DFT-8 over k0 (8 consecutive slots); outputs n = m + 64 n2, m = n0 + 8 n1
 #pragma unroll
-    for (int k0 = 0; k0 < R2; k0++) w[k0] = *reinterpret_cast<const float2 *>(Z + ZL::addr(pair, j * R2 + k0));
-    Dft<1, R2>::run(w);
-    // maximum first, index second (see ifft_argmax): ">=" scan semantics, straight beats mirrored on equality
+    for (int k0 = 0; k0 < 8; k0++) v[k0] = *slot(8 * lane + k0);
+    Dft<1, 8>::run(v);
+    const int m = (lane >> 3) + 8 * (lane & 7);
     float bq = -1.0e20f, bt = -1.0e20f;
 #pragma unroll
-    for (int n1 = 0; n1 < R2; n1++) { bq = __builtin_fmaxf(bq, w[n1].x); bt = __builtin_fmaxf(bt, w[n1].y); }
-#define RA_DPP_FMAX(X, CTRL) X = __builtin_fmaxf(X, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xF, 0xF, true)))
-    RA_DPP_FMAX(bq, 0x140); RA_DPP_FMAX(bt, 0x140); RA_DPP_FMAX(bq, 0x141); RA_DPP_FMAX(bt, 0x141);
-    RA_DPP_FMAX(bq, 0x4E); RA_DPP_FMAX(bt, 0x4E); RA_DPP_FMAX(bq, 0xB1); RA_DPP_FMAX(bt, 0xB1);
-#undef RA_DPP_FMAX
+    for (int r = 0; r < 8; r++) { bq = __builtin_fmaxf(bq, v[r].x); bt = __builtin_fmaxf(bt, v[r].y); }
+    bq = wave_max_dpp(bq); bt = wave_max_dpp(bt);
     const bool mir = !nomirror && !(bq >= bt);
     const float best = mir ? bt : bq;
-    float c[R2];
+    float c[8];
     int nb = -1;
 #pragma unroll
-    for (int n1 = 0; n1 < R2; n1++) {
-        c[n1] = mir ? w[n1].y : w[n1].x;
-        nb = c[n1] == best ? n1 : nb;
+    for (int r = 0; r < 8; r++) {
+        c[r] = mir ? v[r].y : v[r].x;
+        nb = c[r] == best ? r : nb;
     }
-    int jt = nb >= 0 ? R1 * nb + j : -1;
-#define RA_DPP_IMAX(CTRL) jt = max(jt, __builtin_amdgcn_update_dpp(0, jt, CTRL, 0xF, 0xF, true))
-    RA_DPP_IMAX(0x140); RA_DPP_IMAX(0x141); RA_DPP_IMAX(0x4E); RA_DPP_IMAX(0xB1);
-#undef RA_DPP_IMAX
-    // neighbour jt + k (k = -3..3) lives in lane (jt + k) mod R1 at register (jt + k) / R1
-    const int d = (j - jt) & (R1 - 1);
-    const int k = d <= 3 ? d : d - R1;
+    const int jt = wave_imax_dpp(nb >= 0 ? 64 * nb + m : -1);
+    // neighbour jt + k (k = -3 .. 3) lives in the lane whose m = (jt + k) mod 64, at register (jt + k) / 64
+    const int d = (m - jt) & 63;
+    const int k = d <= 3 ? d : d - 64;
     if (k >= -3) {
-        const int n1 = ((jt + k + N) & (N - 1)) / R1;
+        const int r7 = ((jt + k + 512) & 511) >> 6;
         float val = 0.f;
 #pragma unroll
-        for (int r = 0; r < R2; r++) val = (r == n1) ? c[r] : val;
+        for (int r = 0; r < 8; r++) val = (r == r7) ? c[r] : val;
         dst->t7[k + 3] = val;
     }
-    if (j == 0) {
+    if (lane == 0) {
         dst->val = best;
         dst->jtot = jt + 1;
         dst->refmir = ((mir ? 1 : 0) << 16) | refid;

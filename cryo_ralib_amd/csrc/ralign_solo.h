@@ -12,26 +12,28 @@
 //   contraction   v_mfma_f32_4x4x1_16b_f32 in one straight line per wave (A in registers, B = the prepared references streamed from
 //                 L2 with scalar row offsets), tiles of 2 NH <= 10 references; rows 2 and 3 of the 4 x 4 blocks (the second offset
 //                 of the four-offset kernels) idle: with one resident offset there is nothing to put there.
-//   spectra       Z_k = Q_k + i T_k and Z_{N-k} to LDS, one 512-point complex inverse FFT per reference (16 lanes: two 16-point
-//                 columns, then a 32-point row per lane; ifft32_argmax), argmax with the CPU scan's ">=" rules, best reference per
-//                 offset with the runner-up inside AND across tiles for the float-tie re-evaluation (ralign_exact.h).
+//   spectra       Z_k = Q_k + i T_k and Z_{N-k} to LDS, one 512-point complex inverse FFT per reference and WAVE (8 x 8 x 8 in
+//                 registers with two transposes through the transform's own LDS image; ifft512_wave_argmax), argmax with the CPU
+//                 scan's ">=" rules, best reference per offset with the runner-up inside AND across tiles for the float-tie
+//                 re-evaluation (ralign_exact.h).
 // Search offsets outside a particle's window (search_range; finalize_kernel ignores them) are skipped altogether, so no tap ever
 // leaves the image and the LDS copy needs no search-range border: rows and columns 1 .. nx + 1 (the last one zero: the zero-weight
 // tap of a sample that lands exactly on the last row or column).
 // The end of a pass's inverse FFTs is an arrival counter (PassSync): the next pass's ring jobs sample first and wait for it before
-// they write to the ring buffer; the waves without a ring job carry the inverse-FFT calls.
+// they write to the ring buffer; the waves with the lightest ring jobs (or none) carry the transforms.
 //
 // Reference call sites restated: Util.multiref_polar_ali_2d / ormq (test_mref_gpu_align.py:1043-1044, test_reffree_gpu_align.py:
 // 844-847); replaces cu_resample_to_polar + cuFFT + cu_ccf_mult_m + CcfResultTable + cu_max_idx_batch
 // (cuda/gpu_aln_noref.cu:818-879, 1009-1143, 2095-2206, 1289-1346) for this geometry class.
 #pragma once
 
+#include <type_traits>
+
 #include "ralign_tiled.h"
 
 namespace ralign {
 
 constexpr int RS_NQ = 16;          // ring quads of a wave's A slice (<= 64 rings)
-constexpr int RS_LIGHT_NQ = 6;     // "light" waves: bin groups with at most this many ring quads; they carry the inverse-FFT calls
 constexpr int RS_MAXNH = 5;        // reference pairs per tile
 constexpr int RS_GSTR = 4 * RS_NQ; // ints per group in the LDS table of ring offsets
 
@@ -52,7 +54,7 @@ inline SoloLds solo_lds_plan(int N, int rows, int pst, int sbuf, int n_qtab, int
     L.jobs = o; o += 4 * n_job;
     L.instw = o; o += rs_up4(n_inst);
     L.red = o; o += rs_up4(24 + 2 * nring);
-    L.tws = o; o += 2 * N;
+    L.tws = o; o += 2 * N + 2 * 64;                                            // ifft512_twiddles: [8][64] + [8][8]
     L.pc = o; o += rs_up4((2 * RS_MAXNH + 4) * (int)(sizeof(CandT) / 4));      // [2 RS_MAXNH] records of a tile, [2] best / runner-up over the tiles
     L.goff = o; o += 16 * RS_GSTR;
     L.cdc = o; o += rs_up4(nref);
@@ -83,21 +85,17 @@ inline bool build_solo_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
     f.s_sbuf = std::max((g.lring + 31) / 32 * 32 + 16, f.rz * zstride);
     // ring jobs: longest first, wave w runs jobs rank[w], rank[w] + 16, ..; the waves with the highest ranks have no job in a
-    // geometry with fewer than 16 jobs and carry the inverse-FFT calls (4 transforms each) instead.  RALIGN_SOLO_ORDER=1 gives
-    // the jobs to the youngest waves and the calls to the oldest (the SIMDs issue oldest-first).
+    // geometry with fewer than 16 jobs; the transforms of a tile (one per wave) go to the highest ranks.  RALIGN_SOLO_ORDER=1 gives
+    // the jobs to the youngest waves and the transforms to the oldest (the SIMDs issue oldest-first).
     const bool rev = getenv("RALIGN_SOLO_ORDER") && atoi(getenv("RALIGN_SOLO_ORDER")) == 1;
-    const int ncall = (f.rz + 3) / 4;
     for (int w = 0; w < 16; w++) {
         f.s_rank[w] = rev ? 15 - w : w;
         const int c = 15 - f.s_rank[w];
-        f.s_call[w] = c < ncall ? c : -1;
+        f.s_call[w] = c < f.rz ? c : -1;          // one 512-point transform per wave and tile (ifft512_wave_argmax)
     }
-    // wave of rank r takes bin group r: the groups of the high bins (only the longest rings reach them: few ring quads, a small
-    // slice) go to the waves that carry the inverse-FFT calls, whose transforms need the registers a large slice would occupy
-    for (int w = 0; w < 16; w++) {
-        f.wmap[w] = f.s_rank[w];
-        if (f.s_call[w] >= 0 && f.grp_nq[f.wmap[w]] > RS_LIGHT_NQ) return false;
-    }
+    // wave of rank r takes bin group r: the groups of the high bins (only the longest rings reach them: few ring quads) go to
+    // the waves that carry the transforms
+    for (int w = 0; w < 16; w++) f.wmap[w] = f.s_rank[w];
     auto wave_of_rank = [&](int r) { for (int w = 0; w < 16; w++) if (f.s_rank[w] == r) return w; return 0; };
     f.s_rec = wave_of_rank(15);       // merges the records behind the counter wait: a wave without a ring job
     f.s_stat = wave_of_rank(14);
@@ -111,16 +109,17 @@ inline bool build_solo_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     return f.on != 0;
 }
 
-// contraction of one tile for one wave (see rt_contract, ralign_tiled.h): NH reference pairs of the wave's bin group against the
-// A slice in registers, NS ring-quad slots in one straight line; the slice is right-aligned in a[]
+// contraction of one chunk of a tile for one wave (see rt_contract, ralign_tiled.h): NH reference pairs of the wave's bin group
+// against the A slice in registers, NS ring-quad slots in one straight line; the slice is right-aligned in a[]
 template <int NH, int NS, int NQT>
 __device__ __forceinline__ void rs_contract(const float (&a)[4 * NQT], __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
-                                            const unsigned (&row)[NH], f32x4 (&acc)[NH])
+                                            const unsigned (&row)[NH], unsigned pad0, f32x4 (&acc)[NH])
 {
     constexpr int A0 = 4 * (NQT - NS);
     float4 bc[NH];
+    // pad0 != 0: slot 0 is padding (zero A); its B requests are sent out of the buffer's range and return zeros without a fetch
 #pragma unroll
-    for (int h = 0; h < NH; h++) bc[h] = rt_load_b(rsrc, voff, row[h]);
+    for (int h = 0; h < NH; h++) bc[h] = rt_load_b(rsrc, voff, row[h] | pad0);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sl = 0; sl < NS; sl++) {
@@ -143,7 +142,8 @@ __device__ __forceinline__ void rs_contract(const float (&a)[4 * NQT], __amdgpu_
 
 // dbg_spec != null (tests: the polar stage bin for bin): the ring buffer after the ring jobs and {avg, 1 / sigma} of every
 // (particle, in-window offset) go to dbg_spec[(p nshift + s) (lring + 2)]; nothing else runs
-template <int N, int NH>
+// ONE: a single reference tile (nref <= 2 NH): the slice is dead before the inverse FFTs
+template <int N, int NH, bool ONE>
 __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, FusedGeom f, const float *__restrict__ particles,
                                                                  const float *__restrict__ state, int n,
                                                                  const float *__restrict__ Bf, int nref,
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     DevGeom g = g_in;
     g.maxrin = N; g.lg_maxrin = __builtin_ctz(N);
     g.sbuf = f.s_sbuf; g.pst = f.s_pst;
-    constexpr int R1 = IfftPlan<N>::R1, R2 = IfftPlan<N>::R2;
     constexpr int RZ = 2 * NH;                                         // references per tile
     extern __shared__ __align__(16) float lds[];
     const int o_bufs = (f.s_rows * f.s_pst + 3) & ~3;
@@ -164,8 +163,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     int4 *jobs_s = inst_s + g.n_inst;
     float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);
     float *red = instw_s + ((g.n_inst + 3) & ~3);      // [6] counter, [7] zero, [8] avg, [12] 1 / sigma, [16] centre, [24 ..] ring partials
-    float2 *tws = reinterpret_cast<float2 *>(red + ((24 + 2 * g.nring + 3) & ~3));      // [R1 * R2] inverse-FFT twiddles
-    CandT *pc = reinterpret_cast<CandT *>(tws + R1 * R2);              // [RZ] records of the tile
+    float2 *tws = reinterpret_cast<float2 *>(red + ((24 + 2 * g.nring + 3) & ~3));      // inverse-FFT twiddles: [8][64], then [8][8]
+    CandT *pc = reinterpret_cast<CandT *>(tws + N + 64);               // [RZ] records of the tile
     CandT *pbest = pc + 2 * RS_MAXNH;                                  // [2] best record and runner-up over the tiles so far
     int *goff_s = reinterpret_cast<int *>(reinterpret_cast<float *>(pc) + (((2 * RS_MAXNH + 4) * (int)(sizeof(CandT) / 4) + 3) & ~3));
     float *cdc_s = reinterpret_cast<float *>(goff_s + 16 * RS_GSTR);   // [nref] DC weights of the references
@@ -175,10 +174,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
     for (int i = tid; i < g.n_inst; i += RF_THREADS) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
     for (int i = tid; i < g.n_job; i += RF_THREADS) jobs_s[i] = g.jobs[i];
-    for (int i = tid; i < R1 * R2; i += RF_THREADS) {
-        const float2 t = g.tw[((i / R2) * (i % R2)) & (N - 1)];
-        tws[i] = make_float2(t.x, -t.y);
-    }
+    static_assert(N == 512, "ifft512_wave_argmax");
+    ifft512_twiddles(g.tw, tws, tws + N, tid, RF_THREADS);
     for (int i = tid; i < f.s_sbuf; i += RF_THREADS) bufs[i] = 0.f;       // slack between rings must hold finite values
     for (int i = tid; i < o_bufs; i += RF_THREADS) img[i] = 0.f;          // row and column nx + 1 stay zero
     for (int i = tid; i < nref; i += RF_THREADS) cdc_s[i] = f.cdc_w[i];
@@ -201,6 +198,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
 
     bool pend = false;                     // a pass whose last inverse FFTs and records are outstanding
     int p_prev = 0, s_prev = 0;
+    int ipass = 0;                         // passes of this workgroup so far (profiling builds: the wave timeline covers the first 64)
     // records of tile t (ascending reference, ">=": later wins) against the best of the earlier tiles (a later tile wins ties, as a
     // later reference does).  The runner-up -- the largest peak among the references that lost, inside this tile or in an earlier
     // one -- travels along; the last tile of a pass scales by 1 / sigma and writes the record out, with the runner-up in spare bits
@@ -241,13 +239,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     };
 
     // One pass behind the ring jobs: this wave's slice of the spectra -- bins 16 xm .. 16 xm + 15, every ring that has them, right-
-    // aligned in a[4 NQT] -- and the tiles of RZ references (contraction, spectra store, inverse FFTs).  NQT = RS_NQ: the waves of
-    // the low bins (up to 64 registers of slice, no inverse-FFT call); NQT = RS_LIGHT_NQ: the waves of the high bins, which carry
-    // the inverse-FFT calls (a 512-point transform holds 64 registers of data: next to a 64-register slice it would spill).
-    // Both instantiations cross the same workgroup barriers.
-    auto tile_loop = [&](auto nqt_c, int ln, int p, int s) {
-        constexpr int NQT = decltype(nqt_c)::value;
-        constexpr bool LIGHT = NQT == RS_LIGHT_NQ;
+    // aligned in a[4 RS_NQ] -- and the tiles of RZ references (contraction, spectra store, inverse FFTs)
+    auto tile_loop = [&](int ln, int p, int s, bool tl) {
+        constexpr int NQT = RS_NQ;
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
         float a[4 * NQT];
         {
@@ -264,56 +258,62 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 }
             }
         }
+        RA_STAMP(g, tl, ipass, wave, 3);
 #pragma unroll 1
-        for (int t = 0; t < ntile; t++) {
+        for (int t = 0; t < (ONE ? 1 : ntile); t++) {
             const int ref_lo = t * RZ, nrz = min(RZ, nref - ref_lo);
-            f32x4 acc[NH];
-            {
-                // row offsets (bytes) of the tile's reference pairs in the wave's group block, moved back by the slots the wave
-                // pads; a pair past the last one (final tile) re-reads the last pair's rows and is never stored
-                unsigned row[NH];
-                const int ns = LIGHT ? (nq <= 2 ? 2 : nq <= 4 ? 4 : 6) : ((nq + 1) & ~1);
+            // the tile's reference pairs in chunks of at most three: the slice, 12 accumulator and 12 operand registers fit a
+            // wave's 128 next to the addresses, five pairs at once (104 + addresses) spilled 43 registers into the contraction
+            constexpr int NC = NH > 3 ? 2 : 1, NH0 = NH > 3 ? (NH + 1) / 2 : NH, NH1 = NH - NH0;
+            const int ns = (nq + 1) & ~1;          // straight-line instantiations for even slot counts; an odd group pads its first slot
+            const unsigned voff = (unsigned)ln * 16u;
+            auto chunk = [&](auto nhc_c, int h0) {
+                constexpr int NHC = decltype(nhc_c)::value;
+                f32x4 acc[NHC];
+                {
+                    // row offsets (bytes) of the reference pairs in the wave's group block, moved back by the slot the wave pads (its
+                    // requests go out of the buffer's range: zeros, no memory traffic); a pair past the last one (final tile)
+                    // re-reads the last pair's rows and is never stored
+                    unsigned row[NHC];
+                    const unsigned pad = ns > nq ? 0x80000000u : 0u;
 #pragma unroll
-                for (int h = 0; h < NH; h++)
-                    row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)((ns - nq) * 1024);
-                const unsigned voff = (unsigned)ln * 16u;
-                if constexpr (LIGHT) {
+                    for (int h = 0; h < NHC; h++)
+                        row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h0 + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)((ns - nq) * 1024);
                     switch (ns) {
-                    case 2: rs_contract<NH, 2, NQT>(a, brsrc, voff, row, acc); break;
-                    case 4: rs_contract<NH, 4, NQT>(a, brsrc, voff, row, acc); break;
-                    default: rs_contract<NH, 6, NQT>(a, brsrc, voff, row, acc); break;
-                    }
-                } else {
-                    switch (ns) {
-                    case 8: rs_contract<NH, 8, NQT>(a, brsrc, voff, row, acc); break;
-                    case 10: rs_contract<NH, 10, NQT>(a, brsrc, voff, row, acc); break;
-                    case 12: rs_contract<NH, 12, NQT>(a, brsrc, voff, row, acc); break;
-                    case 14: rs_contract<NH, 14, NQT>(a, brsrc, voff, row, acc); break;
-                    default: rs_contract<NH, 16, NQT>(a, brsrc, voff, row, acc); break;
+                    case 2: rs_contract<NHC, 2, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 4: rs_contract<NHC, 4, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 6: rs_contract<NHC, 6, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 8: rs_contract<NHC, 8, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 10: rs_contract<NHC, 10, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 12: rs_contract<NHC, 12, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    case 14: rs_contract<NHC, 14, NQT>(a, brsrc, voff, row, pad, acc); break;
+                    default: rs_contract<NHC, 16, NQT>(a, brsrc, voff, row, pad, acc); break;
                     }
                 }
-            }
-            RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
-            if (t > 0) merge_records(t - 1, false, p, s);
-            {
+                if (h0 == 0) {
+                    RA_STAMP(g, tl && t == 0, ipass, wave, 4);
+                    RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
+                    RA_STAMP(g, tl && t == 0, ipass, wave, 5);
+                    if (t > 0) merge_records(t - 1, false, p, s);
+                }
                 // Z_k = Q_k + i T_k (even lane) and Z_{N-k} = conj Q_k + i conj T_k (odd lane) of this lane pair's bin for every
-                // reference pair of the tile, from the four products a = c1 d1, b = c1 d2 (even lane: the reference's real part
+                // reference pair of the chunk, from the four products a = c1 d1, b = c1 d2 (even lane: the reference's real part
                 // times the image's (Re, Im)), c = c2 d1, d = c2 d2 (odd lane) summed over the rings (Util::Crosrng_ms:
                 // Q = (a + d) + i (c - b), T = (a - d) - i (b + c)); bin 0 carries the DC term in a and the Nyquist term of the
                 // full-length rings in d
                 typedef ZLayout<N> ZL;
                 const int k = 16 * xm + xb, km = k ? N - k : N / 2;
                 const int ks = odd ? km : k;
-                const int ref_b = ref_lo + (xj >> 1);
-                float *zk = bufs + (xj >> 1) * ZL::kPairStride + 2 * (ks + (ks >> 4));
-                float dcv[NH];
+                const int ref_b = ref_lo + 2 * h0 + (xj >> 1);
+                float *zk = bufs + (2 * h0 + (xj >> 1)) * ZL::kPairStride + 2 * (ks + (ks >> 4));
+                float dcv[NHC];
                 if (xm == 0) {
                     const float av = red[8];
 #pragma unroll
-                    for (int h = 0; h < NH; h++) dcv[h] = av * cdc_s[min(ref_b + 2 * h, nref - 1)];
+                    for (int h = 0; h < NHC; h++) dcv[h] = av * cdc_s[min(ref_b + 2 * h, nref - 1)];
                 }
 #pragma unroll
-                for (int h = 0; h < NH; h++) {
+                for (int h = 0; h < NHC; h++) {
                     const int ref = ref_b + 2 * h;
                     const f32x4 c4 = acc[h];
                     const float x0 = swap_lane_pair(c4[0]), x1 = swap_lane_pair(c4[1]);
@@ -331,14 +331,14 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                     }
                     if (ref < nref) *reinterpret_cast<float2 *>(zk + 2 * h * ZL::kPairStride) = v;
                 }
-            }
+            };
+            chunk(std::integral_constant<int, NH0>{}, 0);
+            if constexpr (NC > 1) chunk(std::integral_constant<int, NH1>{}, NH0);
+            RA_STAMP(g, tl && t == 0, ipass, wave, 6);
             RF_LDS_BARRIER();         // the spectra of the tile are complete
-            if constexpr (LIGHT) {
-                if (call >= 0) {
-                    const int j = ln & 15, zs = 4 * call + (ln >> 4);
-                    if (zs < nrz) ifft32_argmax<N>(bufs, pc + zs, tws + j, zs, j, ref_lo + zs, g.nomirror != 0);
-                }
-            }
+            RA_STAMP(g, tl && t == 0, ipass, wave, 7);
+            if (call >= 0 && call < nrz) ifft512_wave_argmax(bufs, pc + call, tws, tws + N, call, ln, ref_lo + call, g.nomirror != 0);
+            RA_STAMP(g, tl && t == 0, ipass, wave, 8);
         }
     };
 
@@ -377,6 +377,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
 #pragma unroll 1
         for (; s < g.nshift; ) {
             const int sn = next_live(s + 1);
+            // profiling builds: wave timeline of workgroup 0 (stamps: 0 pass start, 13 / 14 around the counter wait inside the ring
+            // job, 1 ring jobs done, 2 behind their barrier, 3 slice in registers, 4 contraction of tile 0 done, 5 behind barrier A,
+            // 6 spectra stored, 7 behind barrier B, 8 transforms of tile 0 done, 9 end of the pass)
+            const bool tl = blockIdx.x == 0 && ipass < 64;
+            RA_STAMP(g, tl, ipass, wave, 0);
             // ---- ring jobs: sampling + Normalize_ring partial sums + ring FFTs of this offset.  The previous pass's last inverse
             // FFTs are awaited inside the job, between its sampling and its first write to the ring buffer
 #pragma unroll 1
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 if (job >= g.n_job) continue;
                 const int4 jd = jr == 0 ? jd0 : jobs_s[job];
 #ifdef RALIGN_PROFILE_SWITCHES
-                const PassSync ps = {pend && jr == 0, ifft_done, done_target, nullptr};
+                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl ? g.timeline + (ipass * 16 + wave) * 16 : nullptr};
 #else
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target};
 #endif
@@ -407,8 +412,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 ps();
             }
             if (pend) merge_records(ntile - 1, true, p_prev, s_prev);
+            RA_STAMP(g, tl, ipass, wave, 1);
             const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
             RF_LDS_BARRIER();
+            RA_STAMP(g, tl, ipass, wave, 2);
             // Normalize_ring statistics of the offset (fixed order: reproducible) and the next pass's sampling centre
             if (wave == f.s_stat) {
                 float a = 0.f, q = 0.f;
@@ -434,9 +441,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 s = sn;
                 continue;
             }
-            // ---- this wave's slice of the spectra and the reference tiles: two instantiations, by the size of the slice
-            if (nq <= RS_LIGHT_NQ) tile_loop(std::integral_constant<int, RS_LIGHT_NQ>{}, ln, p, s);
-            else tile_loop(std::integral_constant<int, RS_NQ>{}, ln, p, s);
+            // ---- this wave's slice of the spectra and the reference tiles
+            tile_loop(ln, p, s, tl);
+            RA_STAMP(g, tl, ipass, wave, 9);
+            ipass++;
             // this wave's transforms (if it had any) are over: count it; the next pass's ring jobs wait for all 16 before they write
             // to the ring buffer (PassSync)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
