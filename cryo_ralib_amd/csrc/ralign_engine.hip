@@ -455,7 +455,28 @@ template <typename T> static int dev_grow(ra_engine *e, T **p, size_t count, boo
 // the two-kernel path, which are then never allocated (ensure_unfused_ws is lazy).
 static bool resident_expected(const Geometry &g, const ra_config &cfg, bool generic, size_t *b_floats)
 {
-    if (generic || (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0)) return false;
+    if (generic) {
+        // search_solo_kernel (setup_solo): rings of 512 samples, image and one ring buffer in the LDS
+        if (g.maxrin != 512 || g.nring > 4 * RS_NQ || g.numr[2] < 8 || cfg.nref > 127 || (getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0)) return false;
+        int pst = g.nx + 1;
+        while (!((pst & 1) && ((pst - 1) & 7) && ((pst + 1) & 7))) pst++;
+        const int nrp = (cfg.nref + 1) / 2, ntile = (nrp + RS_MAXNH - 1) / RS_MAXNH, nh = (nrp + ntile - 1) / ntile;
+        const int sbuf = std::max((g.lring + 31) / 32 * 32 + 16, 2 * nh * (2 * (g.maxrin + g.maxrin / 16) + 2));
+        if ((size_t)((g.nx + 1) * pst + sbuf + 4600 + 2 * g.nring + 5 * (g.nring + 16)) * sizeof(float) > 160 * 1024) return false;
+        size_t quads = 0;
+        for (int m = 0; m < g.maxrin / 32; m++) {
+            int r0 = 0;
+            while (r0 < g.nring) {
+                const int n = g.numr[3 * r0 + 2], nbin = (n == g.maxrin) ? n / 2 : n / 2 + 1;
+                if (16 * m < nbin) break;
+                r0++;
+            }
+            quads += (g.nring - r0 + 3) / 4;
+        }
+        if (b_floats) *b_floats = (size_t)nrp * quads * 256 + 256;
+        return true;
+    }
+    if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
     const bool tiled = cfg.nref >= RT_MINREF && g.maxrin == 256 && g.nring <= 4 * RT_NQ && cfg.nref <= 127 &&
                        !(getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) == 0);
     if (!tiled && (cfg.nref > RF_MAXREF || !(g.maxrin == 256 || g.maxrin == 128))) return false;
@@ -513,7 +534,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     w.alscratch_floats = (size_t)chunk * g.nx * g.nx;
     // CCF-spectra scratch of ccf_generic_kernel: 64 pairs x 7 tiles per workgroup, x 14 for the 2 x 7 blocks (gccf_tm; 4 x 7: half the workgroups)
     const bool wide2 = generic && gccf_tm(nrtile, g.maxrin) >= 2;
-    w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * (g.maxrin + 2) : 0;      // + 2: N/2 + 1 bins of two values (split kernels)
+    w.zscr_recs = generic ? (size_t)512 * (wide2 ? RA_GCCF_ZPAIRS_MAX : RA_GCCF_ZPAIRS_MAX / 2) * (g.maxrin + 2) : 0;      // + 2: N/2 + 1 bins of two values (split kernels); allocated on first use of the generic search
     if (generic && g.maxrin == 1024) w.zscr_recs *= gccf_blocks_per_wg();
     const size_t nxh = g.nx / 2 + 1, rf_cap = 2 * (size_t)cfg.nref;
     const size_t refine = 2 * rf_cap * g.nx * nxh * sizeof(double2) + rf_cap * (nxh + 3) * sizeof(float) + (size_t)g.nx * sizeof(double2);
@@ -536,7 +557,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     const size_t exact_ws = (size_t)cfg.nref * g.lcirc * sizeof(float) + (size_t)chunk * sizeof(RefineRec) +
                             (lds_ref > 160 * 1024 - 256 ? (size_t)std::max(256, cfg.nref) * 2 * g.lcirc * sizeof(float) : 0);
     w.bytes = (w.refspec_floats + w.b_floats + 2) * sizeof(float) + search_ws + sums_ws + exact_ws +
-              w.zscr_recs * sizeof(float2) + refine + tables;
+              (resident ? 0 : w.zscr_recs * sizeof(float2)) + refine + tables;
     // every hipMalloc is rounded up to the allocator's granule; ~40 small tables and buffers
     w.bytes += (size_t)48 * (2 << 20);
     return w;

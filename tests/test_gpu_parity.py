@@ -3,9 +3,9 @@ seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's 
 through size-independent properties.
 
 Bars (BASELINE.json north_star): CCF peaks within 1e-4 relative; identical integer
-(ref, mirror, angle-bin, shift) assignments.  Float near-ties (|dpeak|/peak < 3e-6, i.e. below
-what f32 accumulation can resolve against the oracle's f64) are audited, not hidden: they are
-counted and must stay under 1 % of the particles.
+(ref, mirror, angle-bin, shift) assignments -- literally: every oracle comparison asserts zero
+disagreements (float near-ties, |dpeak|/peak < 3e-6, are decided by the engine in the CPU path's
+arithmetic; the count of every comparison is logged in gpurun_out/parity_audit.json).
 """
 import ctypes
 import os
@@ -70,7 +70,10 @@ def assert_alpha_equal_to_the_ulp(got, want):
     assert (got == want).mean() >= 0.97, (got == want).mean()
 
 
-def compare_search(r, st, params, infos, d, max_tie_frac=0.01, alpha_outlier_frac=0.0):
+def compare_search(r, st, params, infos, d, max_tie_frac=0.0, alpha_outlier_frac=0.0):
+    """the bar of BASELINE.json's north_star, literally: identical integer (ref, mirror, angle bin, shift) assignments -- no
+    allowance for float ties since round 5: the engine decides them in the CPU path's arithmetic (refine_winner_kernel), so a
+    disagreement is a finding to fix there, not to admit here -- and CCF peaks within 1e-4"""
     n = len(r)
     jt = np.array([infos[i].jtot for i in range(n)])
     same = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & \
@@ -245,7 +248,7 @@ def test_ragged_sizes_and_reference_tiles(n, nref):
     d = np.zeros((n, 2), np.float32)
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
-    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d, max_tie_frac=0.05)
+    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     eng.close()
 
 
@@ -272,7 +275,7 @@ def test_edge_limited_windows_and_reset_rule():
     d = d0.copy()
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=d0)
-    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d, max_tie_frac=0.05)
+    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     assert np.abs(d).max() <= 8 + 3
     eng.close()
 
@@ -287,7 +290,7 @@ def test_anisotropic_and_fractional_windows(xr, yr, step):
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, step, d)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, yr, step)
     assert eng.num_shifts == (2 * int(xr / step) + 1) * (2 * int(yr / step) + 1)
-    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d, max_tie_frac=0.1)
+    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     eng.close()
 
 
@@ -316,7 +319,7 @@ def test_reset_shifts_shrinks_window():
     eng.align(tp, st, res); eng.sync()
     d = np.zeros((n, 2), np.float32)
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, 1, 1, 1.0, d)
-    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d, max_tie_frac=0.1)
+    compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     with pytest.raises(api.EngineError):
         eng.reset_shifts(3, 3, 1.0)      # more offsets than the engine was sized for
     eng.close()
@@ -442,7 +445,7 @@ def test_iteration_loop_matches_oracle_loop(roundtrip):
         params, infos, sums, counts, d = _oracle_mref_loop_step(op, cur, rg, mask, xr, prev, d, roundtrip)
         got_counts = al.iterate()
         r = al.params()
-        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.03)
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d)
         _log_flips("mref loop %s it=%d" % ("round trip" if roundtrip else "exact carry", it), n, flips)
         if flips:
             # re-seed: continue from the device's parameters, state and references
@@ -771,7 +774,7 @@ def test_large_box_search_transform_and_sums(nx, ou, xr, nref, n):
     got = eng.prepared_references()
     assert np.abs(got - cref).max() < 1e-6 * np.abs(cref).max()
     r = api.Engine.result_to_numpy(res)
-    compare_search(r, st.cpu().numpy(), params, infos, d, max_tie_frac=0.0)
+    compare_search(r, st.cpu().numpy(), params, infos, d)
     gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
     gc = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
     eng.transform_accumulate(tp, res, 0, None, gs, gc)
@@ -1019,7 +1022,7 @@ def test_reffree_loop_matches_oracle_loop_at_headline_geometry(center, user_func
         osums = np.zeros((1, 2, nx, nx), np.float32)
         params, infos, osums, oss = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, al.cs, d, params, sums=osums, nthreads=16)
         r = al.params()
-        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02)
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d)
         _log_flips("reffree loop center=%d func=%s it=%d" % (center, user_func, it), n, flips)
         # the next iteration starts from the device's sums and parameter sums
         sums = al.buf.sums.cpu().numpy().copy()
@@ -1137,7 +1140,7 @@ def test_large_box_hundred_references_config4():
     params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
     r = api.Engine.result_to_numpy(res)
-    flips = compare_search(r, st.cpu().numpy(), params, infos, d, max_tie_frac=0.0)
+    flips = compare_search(r, st.cpu().numpy(), params, infos, d)
     _log_flips("256^2 nref=100", n, flips)
     assert (r["ref_id"] == truth["cls"]).all()
     gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
@@ -1182,7 +1185,7 @@ def test_large_box_is_refined_to_the_ulp():
     eng.align(tp, st, res)
     eng.sync()
     r = api.Engine.result_to_numpy(res)
-    flips = compare_search(r, st.cpu().numpy(), params, infos, d, max_tie_frac=0.0)
+    flips = compare_search(r, st.cpu().numpy(), params, infos, d)
     _log_flips("256^2 refined nref=12 sigma=1", n, flips)
     assert_alpha_equal_to_the_ulp(r["alpha"], params[:, 0])
     np.testing.assert_allclose(r["sx"], params[:, 1], rtol=0, atol=5e-7)
@@ -1466,7 +1469,7 @@ def test_multi_stage_schedule_against_oracle():
             params = np.zeros((n, 6), np.float32)
             params[:, 0] = prev["alpha"]; params[:, 1] = prev["sx"]; params[:, 2] = prev["sy"]; params[:, 3] = prev["mirror"]
             params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, x, y, t, (0, 0), d, params, nthreads=16)
-            flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02)
+            flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d)
             _log_flips("stage %d it %d" % (stage, it), n, flips)
     al.close()
     # the driver walks the stages itself when asked to (SPHIRE's schedule) ...
@@ -1592,7 +1595,7 @@ def test_tiled_kernel_in_the_iteration_loop():
         params, infos, sums, counts, d = _oracle_mref_loop_step(op, cur, rg, mask, xr, prev, d, True)
         got_counts = al.iterate()
         r = al.params()
-        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d, max_tie_frac=0.02)
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d)
         _log_flips("tiled loop nref=24 it=%d" % it, n, flips)
         if flips:
             prev = np.zeros((n, 6), np.float32)

@@ -1,0 +1,172 @@
+"""GPU parity tests of the particle-resident search for rings of 512 samples (search_solo_kernel, ralign_solo.h): ou = 41 .. ~62,
+the geometry class of the reference's own documented run (notebook/00_Multireference_Alignment.ipynb cell 3: 130 x 130, ou = 52,
+nref = 50).  Same bars as tests/test_gpu_parity.py: identical integer assignments (no tie allowance), CCF peaks within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from cryo_ralib_amd import api, synth
+from cryo_ralib_amd.mref import MrefAligner
+from oracle import oracle as orc
+
+from test_gpu_parity import (_log_flips, assert_images_close, compare_search, oracle_setup, polar_stage_check, run_engine)
+
+pytestmark = pytest.mark.gpu
+
+SOLO = 3        # ra_search_path: particle-resident, one offset per pass
+
+
+@pytest.mark.parametrize("nx,ou,xr,mode", [(130, 52, 3, api.RA_MODE_MREF), (128, 60, 3, api.RA_MODE_MREF),
+                                           (128, 60, 3, api.RA_MODE_REFFREE), (101, 44, 2, api.RA_MODE_MREF)])
+def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
+    """Polar2Dm -> (Normalize_ring) -> Frngs of every in-window search offset through the ring jobs of the solo kernel (the
+    512-sample job included), element by element against the oracle in EMAN2's packed ring layout"""
+    eng = api.Engine(nx, ou, xr, xr, 1.0, 2 if mode == api.RA_MODE_MREF else 1, mode)
+    assert eng.search_path == SOLO and eng.maxrin == 512
+    eng.close()
+    polar_stage_check(nx, ou, xr, mode)
+
+
+def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
+    """the size-generic polar kernel at a geometry the solo kernel took over (RALIGN_SOLO=0)"""
+    monkeypatch.setenv("RALIGN_SOLO", "0")
+    eng = api.Engine(128, 50, 2, 2, 1.0, 2)
+    assert eng.search_path == 2
+    eng.close()
+    polar_stage_check(128, 50, 2, api.RA_MODE_MREF, n=2, rtol=2e-5)
+
+
+@pytest.mark.parametrize("nx,ou,nref,n,sigma", [(130, 52, 50, 160, 0.25), (130, 52, 50, 160, 1.0),       # the reference notebook's geometry
+                                                (128, 60, 10, 384, 0.25), (128, 60, 10, 384, 1.0),
+                                                (128, 60, 7, 96, 1.0),                                   # odd reference count: a half-filled pair
+                                                (130, 52, 12, 96, 1.0),                                  # two tiles of three pairs
+                                                (131, 58, 3, 64, 0.5)])                                  # odd box
+def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
+    xr = 3
+    refs = synth.make_references(nref, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == SOLO
+    r = eng.result_to_numpy(res)
+    flips = compare_search(r, st.cpu().numpy(), params, infos, d)
+    _log_flips("solo %d/%d nref=%d sigma=%g" % (nx, ou, nref, sigma), n, flips)
+    assert flips == 0
+    if sigma == 0.25:
+        assert (r["ref_id"] == truth["cls"]).all() and (r["mirror"] == truth["mir"]).all()
+    gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
+    gc = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
+    eng.transform_accumulate(tp, res, 0, None, gs, gc)
+    eng.sync()
+    np.testing.assert_array_equal(gc.cpu().numpy(), counts)
+    if sigma <= 0.5:      # (at sigma = 1 a 1e-5 degree difference of the sub-bin angle moves single pixels of a 7-image sum by O(sigma):
+        assert_images_close(gs.cpu().numpy(), sums, mask, 2e-5 * np.abs(sums).max() + 1e-4)      # quadri's cell borders, see assert_images_close)
+    eng.close()
+
+
+def test_solo_search_equals_generic_search(monkeypatch):
+    """same inputs through the solo kernel and through the size-generic kernels it replaces: identical integer assignments"""
+    nx, ou, nref, xr, n = 128, 60, 10, 3, 96
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    st0 = np.zeros((n, 2), np.float32)
+    st0[::3] = (2, -1); st0[1::5] = (-3, 3)          # edge-limited windows: the solo kernel skips their out-of-window offsets
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=st0)
+    assert eng.search_path == SOLO
+    solo = api.Engine.result_to_numpy(res).copy()
+    st_solo = st.cpu().numpy().copy()
+    eng.close()
+    monkeypatch.setenv("RALIGN_SOLO", "0")
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=st0)
+    assert eng.search_path == 2
+    gen = api.Engine.result_to_numpy(res).copy()
+    for f in ("ref_id", "mirror", "angle_bin", "shift_idx"):
+        assert (solo[f] == gen[f]).all(), f
+    assert (np.abs(solo["peak"] - gen["peak"]) / np.abs(solo["peak"])).max() < 1e-5
+    np.testing.assert_array_equal(st_solo, st.cpu().numpy())
+    eng.close()
+
+
+def test_solo_edge_limited_windows_and_reset_rule():
+    """accumulated shifts at and beyond the edge of the box: search_range cuts the window, |shift| > mashi resets it
+    (test_mref_gpu_align.py:1030-1038); the solo kernel never samples an out-of-window offset"""
+    nx, ou, nref, xr, n = 130, 52, 4, 3, 40
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    rng = np.random.default_rng(5)
+    mashi = nx // 2 + 1 - ou - 2
+    d0 = rng.integers(-mashi - 2, mashi + 3, size=(n, 2)).astype(np.float32)
+    d0[:4] = [(mashi, mashi), (-mashi, mashi), (mashi + 1, 0), (0, -mashi - 1)]
+    d = d0.copy()
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=d0)
+    assert eng.search_path == SOLO
+    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    _log_flips("solo edge-limited windows", n, flips)
+    eng.close()
+
+
+def test_solo_reference_free_and_nomirror():
+    """ormq's rules (no Normalize_ring, one reference) and its nomirror form (Crosrng_ns) at maxrin 512"""
+    nx, ou, xr, n = 128, 56, 3, 96
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    refs_n, cref = orc.prepare_refs(refs, None, rg)
+    for nomirror in (False, True):
+        orc.set_nomirror(nomirror)
+        try:
+            d = np.zeros((n, 2), np.float32)
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=8)
+        finally:
+            orc.set_nomirror(False)
+        eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE)
+        assert eng.search_path == SOLO
+        eng.set_nomirror(nomirror)
+        eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+        st, res = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+        eng.sync()
+        r = eng.result_to_numpy(res)
+        if nomirror:
+            assert (r["mirror"] == 0).all()
+        flips = compare_search(r, st.cpu().numpy(), params, infos, d)
+        _log_flips("solo reffree nomirror=%d" % nomirror, n, flips)
+        eng.close()
+
+
+def test_solo_in_the_iteration_loop():
+    """three mref_ali2d iterations of the host driver at the notebook's geometry (search, rot_shift2D + class sums, reference
+    update, state round trip through the header values) against the same loop built from oracle calls"""
+    from test_gpu_parity import _oracle_mref_loop_step, assert_alpha_equal_to_the_ulp
+    nx, ou, nref, xr, n = 130, 52, 4, 3, 96
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    al = MrefAligner(parts, refs, ou, xr, xr, 1.0, preprocess=True, refine=-1)
+    assert al.engine.search_path == SOLO
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    cur = np.stack([orc.normalize_mask(r, mask, 1) for r in refs])
+    op = np.stack([orc.normalize_mask(p, mask, 0) for p in parts])
+    d = np.zeros((n, 2), np.float32)
+    prev = None
+    for it in range(3):
+        params, infos, sums, counts, d = _oracle_mref_loop_step(op, cur, rg, mask, xr, prev, d, True)
+        got_counts = al.iterate()
+        r = al.params()
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d)
+        _log_flips("solo mref loop it=%d" % it, n, flips)
+        prev = params
+        np.testing.assert_array_equal(got_counts, counts)
+        assert_alpha_equal_to_the_ulp(r["alpha"], params[:, 0])
+        cur = np.stack([orc.normalize_mask((sums[j, 0] + sums[j, 1]) * np.float32(1.0 / float(counts[j])), mask, 1)
+                        for j in range(nref)])
+        # (sx / sy agree to one float32 ulp -- the device's double sin / cos against libm's --, which moves a pixel at one of quadri's
+        # cell borders now and then: a handful of the 67 600 pixels may differ by more than the rounding of the sums)
+        diff = np.abs(al.refs.cpu().numpy() - cur)
+        assert (diff > 2e-6 * np.abs(cur).max()).sum() <= 4 and diff.max() < 1e-3 * np.abs(cur).max(), (diff.max(), (diff > 2e-6 * np.abs(cur).max()).sum())
+    al.close()
