@@ -553,7 +553,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     const size_t sums_ws = xs ? nseg * chunk * sizeof(int) + std::min<size_t>(512, (1024 + nseg - 1) / nseg) * nseg * npix * sizeof(float) + (size_t)chunk * sizeof(float2)
                               : w.alscratch_floats * sizeof(float) + nseg * chunk * sizeof(int) + 16 * nseg * npix * sizeof(float);
     // sub-bin refinement (ralign_exact.h): exact reference spectra, the list of flagged particles, global ring buffers of large boxes
-    const size_t lds_ref = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float);
+    const size_t lds_ref = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float) + RA_EXACT_TABLE_BYTES(g.maxrin);
     const size_t exact_ws = (size_t)cfg.nref * g.lcirc * sizeof(float) + (size_t)chunk * sizeof(RefineRec) +
                             (lds_ref > 160 * 1024 - 256 ? (size_t)std::max(256, cfg.nref) * 2 * g.lcirc * sizeof(float) : 0);
     w.bytes = (w.refspec_floats + w.b_floats + 2) * sizeof(float) + search_ws + sums_ws + exact_ws +
@@ -739,12 +739,14 @@ static int setup_refine(ra_engine *e)
     const Geometry &g = e->geo;
     e->refine_ok = false;
     if (getenv("RALIGN_REFINE")) e->refine_thr = (float)atof(getenv("RALIGN_REFINE"));
-    e->lds_refine = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float);
+    // ring buffers (2 lcirc floats) + the twiddles and samples of the f64 CCF (RA_EXACT_TABLE_BYTES)
+    e->lds_refine = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float) + RA_EXACT_TABLE_BYTES(g.maxrin);
     if (g.lcirc & 1) return RA_OK;
-    // large boxes: one offset's rings exceed the LDS (271 KB at 256 x 256 / ou = 120) -- the same kernels on global scratch
+    // large boxes: one offset's rings exceed the LDS (271 KB at 256 x 256 / ou = 120) -- the same kernels with the ring buffers
+    // in global scratch
     e->refine_gm = e->lds_refine > 160 * 1024 - 256;
     e->refine_grid = e->refine_gm ? 256 : 2048;
-    if (e->refine_gm) e->lds_refine = 0;
+    if (e->refine_gm) e->lds_refine = RA_EXACT_TABLE_BYTES(g.maxrin);
     std::vector<float> tw;
     std::vector<int> off(32, 0);
     for (int l = 1; (1 << l) <= g.maxrin; l++) {
@@ -789,7 +791,7 @@ static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int 
     if (refine) {
         const int grid = std::min(cn, e->refine_grid);
         if (e->refine_gm)
-            hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(RA_EXACT_THREADS), 0, e->stream, e->dg, (const int *)e->d_numr,
+            hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_twx, (const int *)e->d_twxoff, part, refx, (const RefineRec *)e->d_rlist, (const int *)e->d_rcount,
                                res, cls, st, e->d_rscratch);
         else

@@ -16,8 +16,9 @@
 //   Frngs      the radix-2 real FFT of fftr_q in f32, table twiddles, no contraction: bit-identical spectra
 //   Crosrng_ms f32 products, f64 accumulation over the rings in ring order, against reference spectra prepared with the
 //              same three routines + Applyws (refspec_exact_kernel)
-//   inverse    the 7 samples q(jtot - 3 .. jtot + 3) by direct f64 summation of the inverse real DFT (fftr_d computes all
-//              maxrin of them; the values agree to f64 rounding)
+//   inverse    all maxrin samples of q (or t) by direct f64 summation of the inverse real DFT (fftr_d computes the same values to
+//              f64 rounding), scanned with the CPU path's ">=" for the last maximum: the winner's bin is the f64 CCF's own,
+//              wherever the f32 transform put it
 // One wave per particle (the butterflies of a radix-2 stage are independent, so they are dealt to the lanes without
 // changing an operation); the kernel runs for the particles finalize_kernel flags as ill-conditioned
 // (|c3| < refine_thr x max |b|), or for all of them when the threshold is negative.
@@ -39,6 +40,7 @@ namespace ralign {
 // GM: the ring buffers live in global memory (boxes whose rings exceed the LDS: 271 KB per offset at 256 x 256 / ou = 120); the
 // workgroup's threads then hand data to each other through the CU's vector cache.
 #define RA_EXACT_THREADS 256
+#define RA_EXACT_TABLE_BYTES(maxrin) ((size_t)24 * (maxrin))      // refine_winner_kernel: [maxrin] double2 twiddles + [maxrin] double samples
 template <bool GM = false> __device__ __forceinline__ void exact_lds_sync()
 {
     if constexpr (GM) __threadfence_block();
@@ -54,6 +56,25 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// maximum over the workgroup with the CPU scan's ">=" rule: of equal values the LARGEST index wins (the scan runs over ascending
+// bins and keeps the last maximum); red / redi: LDS scratch of 4 doubles / 4 ints
+__device__ __forceinline__ void block_argmax_f64(double &v, int &idx, double *red, int *redi)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi > idx)) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    v = red[0]; idx = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++)
+        if (red[w] > v || (red[w] == v && redi[w] > idx)) { v = red[w]; idx = redi[w]; }
 }
 
 template <bool GM = false>
@@ -161,14 +182,14 @@ __device__ __forceinline__ void finish_params(const DevGeom &g, float sxi, float
 }
 
 // One candidate (search offset bs, reference spectrum c1, orientation mir) of particle image `img`, evaluated as the CPU path
-// evaluates it: samples, Normalize_ring, Frngs, the q or t spectrum, and the 7 CCF samples around bin `jtot` in f64.  The f32
-// search may have stopped one bin beside the f64 maximum of a flat peak: the window is re-centred on its own maximum (">=":
-// the last of equal values, as the CPU scan) until the peak sits in the middle.  Wave-uniform results.
+// evaluates it: samples, Normalize_ring, Frngs, the q or t spectrum, the whole CCF in f64 and its maximum (">=": the last of
+// equal values, as the CPU scan); jtot <- that bin, b <- the 7 samples around it.  Uniform results.
 template <bool GM>
 __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__restrict__ numr, const float *__restrict__ tw,
                                                 const int *__restrict__ twoff, const float *__restrict__ img,
                                                 const float *__restrict__ c1, int bs, float sxi, float syi, bool mir, int &jtot,
-                                                double (&b)[7], float *circ, float *work, int lane, double *red)
+                                                double (&b)[7], float *circ, float *work, int lane, double *red, int *redi,
+                                                const double2 *twd, double *xs)
 {
 #pragma clang fp contract(off)
     const float cx = ((float)g.cnx + sxi) + g.shift_x[bs], cy = ((float)g.cnx + syi) + g.shift_y[bs];
@@ -240,41 +261,32 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
         spec[j] = s0; spec[j + 1] = s1;
     }
     exact_lds_sync<GM>();
-    // 7 samples of the inverse real transform around the peak: x[m] = (X0 + (-1)^m X_{N/2} + 2 sum_k Re(X_k e^{+2 pi i k m / N})) / N
-    for (int trip = 0; trip < 4; trip++) {
-#pragma unroll
-        for (int t = 0; t < 7; t++) b[t] = 0.0;
-        const int m0 = jtot - 1;
-        for (int k = 1 + lane; k < N / 2; k += T) {
-            const double xr = spec[2 * k], xi = spec[2 * k + 1];
-#pragma unroll
-            for (int t = 0; t < 7; t++) {
-                const int m = (m0 + t - 3 + N) & (N - 1);
-                const int km = (int)(((long long)k * m) & (N - 1));
-                double sn, cs;
-                sincospi(2.0 * (double)km / (double)N, &sn, &cs);
-                b[t] += xr * cs - xi * sn;
-            }
+    // the whole inverse real transform in f64, x[m] = (X0 + (-1)^m X_{N/2} + 2 sum_k Re(X_k e^{+2 pi i k m / N})) / N by direct
+    // summation (twd[j] = (cos, sin)(2 pi j / N)), thread m -> samples m, m + T, ..: fftr_d computes the same N values (they agree
+    // to f64 rounding), and Crosrng_ms scans ALL of them.  Until round 5 only the 7 samples around the f32 winner were evaluated
+    // (re-centred on their own maximum): two SEPARATED maxima of one flat CCF within 3e-6 of each other -- the first reference-free
+    // iteration against the blob average of an unaligned stack -- were then decided by the f32 transform (13 of 65 536 particles
+    // disagreed with the CPU path, profiles/r05_parity_audit_large.json).
+    for (int m = lane; m < N; m += T) {
+        double acc = 0.0;
+        for (int k = 1; k < N / 2; k++) {
+            const double2 w = twd[(k * m) & (N - 1)];
+            acc += spec[2 * k] * w.x - spec[2 * k + 1] * w.y;
         }
-        int kb = 3;
-#pragma unroll
-        for (int t = 0; t < 7; t++) {
-            b[t] = block_sum_f64(b[t], red);
-            const int m = (m0 + t - 3 + N) & (N - 1);
-            b[t] = (spec[0] + ((m & 1) ? -spec[1] : spec[1]) + 2.0 * b[t]) / (double)N;
-        }
-        // the CPU scan runs over j = 1 .. N with ">=": of equal values the largest bin wins (the window may wrap around N)
-        double bm = b[0];
-        int jm = ((m0 - 3 + N) & (N - 1)) + 1;
-        kb = 0;
-#pragma unroll
-        for (int t = 1; t < 7; t++) {
-            const int jt = ((m0 + t - 3 + N) & (N - 1)) + 1;
-            if (b[t] > bm || (b[t] == bm && jt > jm)) { bm = b[t]; jm = jt; kb = t; }
-        }
-        if (kb == 3) break;
-        jtot = jm;
+        xs[m] = (spec[0] + ((m & 1) ? -spec[1] : spec[1]) + 2.0 * acc) / (double)N;
     }
+    exact_lds_sync<GM>();
+    // the CPU scan runs over j = 1 .. N with ">=": of equal values the largest bin wins
+    double bm = -1.0e300;
+    int jm = 0;
+    for (int m = lane; m < N; m += T) {
+        const double v = xs[m];
+        if (v >= bm) { bm = v; jm = m + 1; }
+    }
+    block_argmax_f64(bm, jm, red, redi);
+    jtot = jm;
+#pragma unroll
+    for (int t = 0; t < 7; t++) b[t] = xs[(jm - 1 + t - 3 + N) & (N - 1)];
 }
 
 // refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls, state: of the chunk (indexed by rec.p)
@@ -288,12 +300,23 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
                                                            float *__restrict__ gscr)
 {
 #pragma clang fp contract(off)
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     __shared__ double red[4];
+    __shared__ int redi[4];
     const int lane = threadIdx.x;
     float *circ, *work;
     if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
     else { circ = lds; work = lds + g.lcirc; }
+    // behind the ring buffers (GM: at the start of the dynamic LDS): [maxrin] (cos, sin)(2 pi j / maxrin) and the maxrin samples of
+    // a candidate's CCF, both in double (RA_EXACT_TABLE_BYTES)
+    double2 *twd = reinterpret_cast<double2 *>(GM ? lds : lds + 2 * g.lcirc);
+    double *xs = reinterpret_cast<double *>(twd + g.maxrin);
+    for (int j = lane; j < g.maxrin; j += RA_EXACT_THREADS) {
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)g.maxrin, &sn, &cs);
+        twd[j] = make_double2(cs, sn);
+    }
+    __syncthreads();
     for (int item = blockIdx.x; item < *count; item += gridDim.x) {
     const RefineRec rec = list[item];
     const float *img = particles + (size_t)rec.p * g.nx * g.nx;
@@ -301,14 +324,14 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     int ref = rec.ref, mirror = rec.mirror, jtot = rec.jtot, bs = rec.bs;
     double b[7];
     exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
-                        circ, work, lane, red);
+                        circ, work, lane, red, redi, twd, xs);
     if (rec.bs2 >= 0) {
         // a second record within RA_TIE_RTOL of the winner: both peaks in the CPU path's arithmetic, and its order of the scan --
         // offsets, then references, ascending, a later candidate wins with ">="; straight beats mirrored on equality
         int jt2 = rec.jtot2;
         double b2[7];
         exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
-                            rec.mirror2 != 0, jt2, b2, circ, work, lane, red);
+                            rec.mirror2 != 0, jt2, b2, circ, work, lane, red, redi, twd, xs);
         const long long o1 = ((long long)bs << 32) | ((long long)(rec.rt2 & 0xffff) << 16) | (unsigned)ref;
         const long long o2 = ((long long)rec.bs2 << 32) | ((long long)(rec.rt2 >> 16) << 16) | (unsigned)rec.ref2;
         bool second_wins;

@@ -44,6 +44,15 @@ def shard_range(total, world, rank):
 ORDERED_MAX_BYTES = 8 << 20       # gathered size up to which the rank-ordered sum replaces the all-reduce
 
 
+def _collective_needed():
+    """more than one rank -- or RALIGN_FORCE_COLLECTIVE=1 in a process group of ONE rank: the collectives then run as they
+    would on many (RCCL's library load, communicator set-up and kernels execute; the result of a sum / gather / broadcast over
+    one rank is the input), which is how the one-GPU test box exercises the RCCL path (tests/test_multigpu.py)"""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("RALIGN_FORCE_COLLECTIVE") == "1"
+
+
 class ClassSumBuffer:
     """flat fp32 buffer [R][2][nx][nx] sums | [R] counts | [extra] scalars, all-reduced in place.
 
@@ -75,7 +84,7 @@ class ClassSumBuffer:
         the same bits on every rank of a run, but the association of the float additions follows RCCL's algorithm, so
         runs on different rank counts / topologies agree to rounding only.  RALIGN_ORDERED_REDUCE=1 / 0 forces either."""
         self.counts_f.copy_(self.counts_i.to(torch.float32))
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _collective_needed():
             world = dist.get_world_size()
             # gloo rehearsal of several ranks on one GPU (RALIGN_DIST_BACKEND=gloo): the collective runs on a host copy
             staged = self.flat.is_cuda and dist.get_backend() == "gloo"
@@ -100,7 +109,7 @@ class ClassSumBuffer:
 def broadcast(t, src=0):
     """in-place broadcast of tensor `t` from rank `src` (bcast_EMData_to_all, test_mref_gpu_align.py:572-575); under the gloo
     rehearsal of several ranks on one GPU the collective runs on a host copy, like ClassSumBuffer.all_reduce"""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collective_needed():
         return t
     if t.is_cuda and dist.get_backend() == "gloo":
         h = t.cpu()

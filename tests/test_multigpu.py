@@ -192,3 +192,63 @@ def test_reference_free_raw_average_is_the_reduced_one(tmp_path):
     # iteration 0's raw average is the plain mean of the stack
     np.testing.assert_allclose(a["raw"][0], parts.mean(0), rtol=0, atol=1e-5 * np.abs(parts).max())
     al.close()
+
+
+_RCCL_WORLD1 = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r,
+                  HSA_ENABLE_IPC_MODE_LEGACY="0", RALIGN_FORCE_COLLECTIVE="1")
+import numpy as np
+import torch
+import torch.distributed as dist
+from cryo_ralib_amd import dist as rdist, synth
+from cryo_ralib_amd.mref import MrefAligner
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+nx, ou, nref, xr, n = 90, 36, 6, 3, 200
+refs = synth.make_references(nref, nx, ou)
+parts, _ = synth.make_particles(refs, n, xr, xr, 0.5)
+al = MrefAligner(parts, refs, ou, xr, xr, 1.0, device=0, preprocess=True)
+al.search()
+al.engine.sync()
+before = al.buf.sums.clone()
+cnt = al.buf.counts_i.clone()
+for mode in ("1", "0"):                      # rank-ordered all-gather + sum, then the plain all-reduce
+    os.environ["RALIGN_ORDERED_REDUCE"] = mode
+    al.buf.all_reduce()
+    torch.cuda.synchronize()
+    assert torch.equal(al.buf.sums, before), mode
+    assert torch.equal(al.buf.counts_i, cnt) and int(cnt.sum()) == n
+t = al.refs.clone()
+rdist.broadcast(t, src=0)
+torch.cuda.synchronize()
+assert torch.equal(t, al.refs)
+x = torch.arange(1024, dtype=torch.float32, device="cuda")
+dist.all_reduce(x)
+assert float(x[1000]) == 1000.0
+assert rdist.max_over_ranks(3.5, torch.device("cuda", 0)) == 3.5
+rdist.barrier()
+al.close()
+dist.destroy_process_group()
+print("RCCL world-1 ok")
+"""
+
+
+@pytest.mark.timeout(600)
+def test_rccl_executes_in_a_process_group_of_one_rank():
+    """RCCL itself on the one-GPU box: a world-size-1 `nccl` process group in a fresh child process (launcher environment set
+    before any GPU call) runs ClassSumBuffer.all_reduce in both forms -- the rank-ordered all-gather + sum and the plain
+    all-reduce -- dist.broadcast, an all-reduce of a plain tensor, the max-over-ranks of bench.py and a barrier on device
+    tensors, so that a missing or mismatched librccl, a communicator that cannot be built or a failing collective kernel shows
+    here and not first in the driver's 8-GPU run.  (One rank: sums, gathers and broadcasts return their input.)
+    Replaces reduce_EMData_to_root x 2R + mpi_reduce + bcast_EMData_to_all x R (test_mref_gpu_align.py:495-499, 572-575)."""
+    import subprocess
+    port = str(30500 + (os.getpid() % 200))
+    code = _RCCL_WORLD1 % {"root": ROOT, "port": port}
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "RCCL world-1 ok" in out.stdout
