@@ -39,6 +39,8 @@ static thread_local std::string g_last_error;
 
 // device workspace of one engine, shared by ra_create and the size checks of the reference surface
 // (pre_align_size_check / ref_free_alignment_2D_size_check), so that the estimate cannot drift from what is allocated
+#define RA_XS_LDS_MAX ((size_t)80 * 1024)      // padded image copy of transform_sum_kernel: two workgroups of 1024 threads share a CU
+
 struct WorkspacePlan {
     int chunk;
     size_t a_floats, cand_recs, refspec_floats, b_floats, alscratch_floats, zscr_recs;
@@ -549,7 +551,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     // rot_shift2D + class sums: member lists, per-run partial sums and cos / sin of a batch (transform_sum_kernel), or -- images
     // that do not fit the LDS -- the aligned images of a chunk, their member lists and 16 runs of partial sums
     const size_t npix = (size_t)g.nx * g.nx, nseg = 2 * (size_t)cfg.nref;
-    const bool xs = (size_t)(g.nx + 2) * ((g.nx + 2) | 1) * sizeof(float) <= 64 * 1024 && g.nx <= 1024;
+    const bool xs = (size_t)(g.nx + 2) * ((g.nx + 2) | 1) * sizeof(float) <= RA_XS_LDS_MAX && g.nx <= 1024;
     const size_t sums_ws = xs ? nseg * chunk * sizeof(int) + std::min<size_t>(512, (1024 + nseg - 1) / nseg) * nseg * npix * sizeof(float) + (size_t)chunk * sizeof(float2)
                               : w.alscratch_floats * sizeof(float) + nseg * chunk * sizeof(int) + 16 * nseg * npix * sizeof(float);
     // sub-bin refinement (ralign_exact.h): exact reference spectra, the list of flagged particles, global ring buffers of large boxes
@@ -1483,8 +1485,9 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
 // once, every (class, parity) list cut into runs so that ~1000 workgroups share the work
 #define RA_XS_BATCH 65536
 typedef void (*xs_fn)(int, const float *, int, int, const ra_result *, const float2 *, const int *, const int *, int, float *);
-static xs_fn select_xs(int nx)
+static xs_fn select_xs(int nx, int *nband = nullptr)
 {
+    if (nband) *nband = 1;
     if (nx < 8 || nx > RA_XS_THREADS) return nullptr;
     const int ry = RA_XS_THREADS / nx, npt = (nx + ry - 1) / ry;      // sweeps of the workgroup over the image
     if (npt <= 1) return transform_sum_kernel<1>;
@@ -1492,21 +1495,27 @@ static xs_fn select_xs(int nx)
     if (npt <= 4) return transform_sum_kernel<4>;
     if (npt <= 6) return transform_sum_kernel<6>;
     if (npt <= 9) return transform_sum_kernel<9>;
-    if (npt <= 12) return transform_sum_kernel<12>;
-    if (npt <= 16) return transform_sum_kernel<16>;
+    // larger boxes: row bands of at most 8 sweeps per workgroup (9 accumulators and their prefetch registers are what 128 hold)
+    if (npt <= 12) { if (nband) *nband = 2; return transform_sum_kernel<6, 12>; }
+    if (npt <= 16) { if (nband) *nband = 2; return transform_sum_kernel<8, 16>; }
+    if (npt <= 20) { if (nband) *nband = 3; return transform_sum_kernel<7, 20>; }
+    if (npt <= 24) { if (nband) *nband = 3; return transform_sum_kernel<8, 24>; }
     return nullptr;
 }
 static bool xs_usable(const ra_engine *e)
 {
     const int npix = e->geo.nx * e->geo.nx;
     if (e->xf_generic || e->atomic_sums || !select_xs(e->geo.nx)) return false;
-    if ((size_t)(e->geo.nx + 2) * ((e->geo.nx + 2) | 1) * sizeof(float) > 64 * 1024) return false;
+    if ((size_t)(e->geo.nx + 2) * ((e->geo.nx + 2) | 1) * sizeof(float) > RA_XS_LDS_MAX) return false;
     return !(getenv("RALIGN_XSUM") && atoi(getenv("RALIGN_XSUM")) == 0);
 }
 static int transform_sum(ra_engine *e, const float *d_particles, int n, int index0, const ra_result *d_result, float *d_sums, int *d_counts)
 {
     const int nx = e->geo.nx, npix = nx * nx, nseg = 2 * e->cfg.nref;
-    const xs_fn fn = select_xs(nx);
+    int nband = 1;
+    const xs_fn fn = select_xs(nx, &nband);
+    const size_t xs_lds = (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float);
+    if (xs_lds > 64 * 1024) RA_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_lds));
     for (int start = 0; start < n; start += RA_XS_BATCH) {
         const int cn = std::min(RA_XS_BATCH, n - start);
         // runs per segment: ~1024 workgroups, at least ~8 members per run on average
@@ -1534,7 +1543,7 @@ static int transform_sum(ra_engine *e, const float *d_particles, int n, int inde
         hipLaunchKernelGGL(class_members_wide_kernel, dim3(nseg), dim3(1024), 0, e->stream, d_result + start, cn, index0 + start,
                            e->d_xs_members, e->d_xs_mcount, cn, d_counts);
         RA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(fn, dim3(nseg, nrun), dim3(RA_XS_THREADS), (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float), e->stream, nx,
+        hipLaunchKernelGGL(fn, dim3(nseg, nrun, nband), dim3(RA_XS_THREADS), (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float), e->stream, nx,
                            d_particles + (size_t)start * npix, cn, index0 + start, d_result + start, (const float2 *)e->d_xs_trig, (const int *)e->d_xs_members,
                            (const int *)e->d_xs_mcount, cn, e->d_xs_partial);
         RA_HIP(hipGetLastError());

@@ -1599,7 +1599,10 @@ __device__ __forceinline__ float quadri_background_wrap(const float *P, int pst,
 // Thread (tx, ty) = (tid % nx, tid / nx) owns column tx of rows ty, ty + RY, ty + 2 RY, .. (RY = 1024 / nx rows per sweep of
 // the workgroup, NPT sweeps): the column terms of the rotation -- mirror, x, x cos, x sin -- are formed once per member, pixel
 // indices are tid + k RY nx, and nothing per-pixel has to live in registers besides the accumulator and the prefetched value.
-template <int NPT>      // sweeps: NPT * (1024 / nx) >= nx
+// NPF sweeps fill the LDS image (NPF * (1024 / nx) >= nx), NPT sweeps of output rows per workgroup: larger boxes are cut into
+// gridDim.z row bands (NPT * gridDim.z >= NPF) so that a thread keeps at most 9 accumulators -- every band loads the whole image
+// (any pixel may be a tap), but 16 - 20 accumulators per thread next to their prefetch registers spilled 75 - 126 registers.
+template <int NPT, int NPF = NPT>
 __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, const float *__restrict__ particles, int n, int index0,
                                                                       const ra_result *__restrict__ res, const float2 *__restrict__ trig,
                                                                       const int *__restrict__ members,
@@ -1617,7 +1620,8 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
     const int RY = RA_XS_THREADS / nx, S = RY * nx;               // rows, pixels per sweep
     const int ty = (int)__umulhi((unsigned)tid, nx_rcp), tx = tid - ty * nx;
     const bool live = tid < S;
-    float acc[NPT], pre[NPT];
+    const int band = blockIdx.z * NPT;                            // first output sweep of this workgroup's row band
+    float acc[NPT], pre[NPF];
 #pragma unroll
     for (int k = 0; k < NPT; k++) acc[k] = 0.f;
     // wrap-around border of the padded copy: 4 nx + 4 elements, one per thread tid < 4 nx + 4 (padded (row, col) <- pixel)
@@ -1641,7 +1645,7 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
         asm volatile("" : "+v"(t0));
         const float *src = particles + (size_t)mem[j] * npix;
 #pragma unroll
-        for (int k = 0; k < NPT; k++) pre[k] = src[min(t0 + k * S, npix - 1)];
+        for (int k = 0; k < NPF; k++) pre[k] = src[min(t0 + k * S, npix - 1)];
         preb = src[bsrc];
     };
     if (j0 < j1) fetch(j0);
@@ -1652,7 +1656,7 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
         asm volatile("" : "+v"(t1), "+v"(tyv));
         float *fill = img + (tyv + 1) * pst + tx + 1;
 #pragma unroll
-        for (int k = 0; k < NPT; k++)
+        for (int k = 0; k < NPF; k++)
             if (t1 < S && t1 + k * S < npix) fill[k * RY * pst] = pre[k];
         if (bdst >= 0) img[bdst] = preb;
         const ra_result r = res[mem[j]];
@@ -1672,7 +1676,7 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
         const float xcang = x * cang, xsang = x * sang;
 #pragma unroll
         for (int k = 0; k < NPT; k++) {
-            const int iy = min(tyv + k * RY, nx - 1);     // rows past the image (last sweep, idle threads) shadow the last row
+            const int iy = min(tyv + (band + k) * RY, nx - 1);     // rows past the image (last sweep, idle threads) shadow the last row
             const float y = (float)iy - shiftyc;
             const float ycang = y * cang + yc;
             const float ysang = -y * sang + xc;
@@ -1683,7 +1687,7 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
     }
     float *dst = partial + ((size_t)run * gridDim.x + seg) * npix;
 #pragma unroll
-    for (int k = 0; k < NPT; k++) { const int o = tid + k * S; if (live && o < npix) dst[o] = acc[k]; }
+    for (int k = 0; k < NPT; k++) { const int o = tid + (band + k) * S; if (live && o < npix) dst[o] = acc[k]; }
 }
 
 // (float)cos / sin of the angle in double, once per particle, exactly as transform_kernel forms them

@@ -28,7 +28,7 @@ def default_path_only(*switches):
     """tests that assert WHICH kernel path runs (or restate the default path's association of the class sums) are statements
     about the default selection: under a path switch of the whole-suite runs (RALIGN_FUSED=0, RALIGN_XSUM=0, RALIGN_TILED=0 ..)
     they are skipped, not failed, so that the remaining tests of that run are reached"""
-    on = [sw for sw in (switches or ("RALIGN_FUSED", "RALIGN_TILED", "RALIGN_XSUM", "RALIGN_SOLO", "RALIGN_GENERIC")) if os.environ.get(sw) is not None]
+    on = [sw for sw in (switches or ("RALIGN_FUSED", "RALIGN_TILED", "RALIGN_GENERIC")) if os.environ.get(sw) is not None]
     if on:
         pytest.skip("asserts the default kernel path; %s is set" % ", ".join(on))
 
@@ -667,7 +667,7 @@ def _xs_runs(n, nseg):
     return max(1, min(nrun, n // (8 * nseg)))
 
 
-@pytest.mark.parametrize("nx,ou,xr", [(90, 36, 3), (33, 12, 2), (64, 24, 3)])
+@pytest.mark.parametrize("nx,ou,xr", [(90, 36, 3), (33, 12, 2), (64, 24, 3), (130, 52, 3)])
 def test_class_sums_are_bitwise_reproducible(nx, ou, xr):
     """class sums are accumulated in a fixed order -- per batch and (class, parity) the member list is cut into `nrun`
     contiguous runs, each added in particle order (like Util.add_img on the CPU path) by one workgroup of

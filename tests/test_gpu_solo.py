@@ -9,7 +9,8 @@ from cryo_ralib_amd import api, synth
 from cryo_ralib_amd.mref import MrefAligner
 from oracle import oracle as orc
 
-from test_gpu_parity import (_log_flips, assert_images_close, compare_search, oracle_setup, polar_stage_check, run_engine)
+from test_gpu_parity import (_log_flips, assert_images_close, compare_search, default_path_only, oracle_setup, polar_stage_check,
+                             run_engine)
 
 pytestmark = pytest.mark.gpu
 
@@ -21,6 +22,7 @@ SOLO = 3        # ra_search_path: particle-resident, one offset per pass
 def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
     """Polar2Dm -> (Normalize_ring) -> Frngs of every in-window search offset through the ring jobs of the solo kernel (the
     512-sample job included), element by element against the oracle in EMAN2's packed ring layout"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     eng = api.Engine(nx, ou, xr, xr, 1.0, 2 if mode == api.RA_MODE_MREF else 1, mode)
     assert eng.search_path == SOLO and eng.maxrin == 512
     eng.close()
@@ -42,6 +44,7 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
                                                 (130, 52, 12, 96, 1.0),                                  # two tiles of three pairs
                                                 (131, 58, 3, 64, 0.5)])                                  # odd box
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     xr = 3
     refs = synth.make_references(nref, nx, ou)
     parts, truth = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
@@ -68,6 +71,7 @@ def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
 
 def test_solo_search_equals_generic_search(monkeypatch):
     """same inputs through the solo kernel and through the size-generic kernels it replaces: identical integer assignments"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     nx, ou, nref, xr, n = 128, 60, 10, 3, 96
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
@@ -93,6 +97,7 @@ def test_solo_search_equals_generic_search(monkeypatch):
 def test_solo_edge_limited_windows_and_reset_rule():
     """accumulated shifts at and beyond the edge of the box: search_range cuts the window, |shift| > mashi resets it
     (test_mref_gpu_align.py:1030-1038); the solo kernel never samples an out-of-window offset"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     nx, ou, nref, xr, n = 130, 52, 4, 3, 40
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
@@ -112,6 +117,7 @@ def test_solo_edge_limited_windows_and_reset_rule():
 
 def test_solo_reference_free_and_nomirror():
     """ormq's rules (no Normalize_ring, one reference) and its nomirror form (Crosrng_ns) at maxrin 512"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     nx, ou, xr, n = 128, 56, 3, 96
     refs = synth.make_references(1, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
@@ -142,6 +148,7 @@ def test_solo_reference_free_and_nomirror():
 def test_solo_in_the_iteration_loop():
     """three mref_ali2d iterations of the host driver at the notebook's geometry (search, rot_shift2D + class sums, reference
     update, state round trip through the header values) against the same loop built from oracle calls"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
     from test_gpu_parity import _oracle_mref_loop_step, assert_alpha_equal_to_the_ulp
     nx, ou, nref, xr, n = 130, 52, 4, 3, 96
     refs = synth.make_references(nref, nx, ou)
