@@ -370,7 +370,9 @@ class RefFreeAligner:
         # the average as reduced over the ranks, before the user function and the centring: what the reference writes to
         # aqc.hdf at image total_iter - 1 in every iteration, iteration 0 (sum_oe of the raw stack) included (:365-383)
         self.raw_avg = self.tavg[0].clone()
-        pa1 = _Pending((self.tavg[0][self.mask > 0.5] ** 2).sum().reshape(1))
+        # (no boolean-mask indexing here: it reads the number of selected elements back and so synchronises the host with the
+        # stream at the top of every iteration -- the GPU then idles while the host queues the kernels in front of the search)
+        pa1 = _Pending(torch.where(self.mask > 0.5, self.tavg[0], torch.zeros_like(self.tavg[0])).double().square().sum().float().reshape(1))
         self._cs_dev.zero_()
         if center == -1 and self.iteration > 0:
             # average-centre rule cs = (sum +-sx, sum sy) / N (:403-410) in double, rounded to float32 once like the host value
