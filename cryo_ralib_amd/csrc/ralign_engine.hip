@@ -298,15 +298,21 @@ static int build_device_geometry(ra_engine *e)
         // nslot = 4: the four offset slots of a pass of the LDS-resident kernels; nslot = 1: search_solo_kernel (rings up to 512
         // samples, code 10: 16 lanes per ring)
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
-            const int lanes_of[11] = {16, 8, 8, 4, 4, 4, 8, 4, 0, 0, 16};
+            const int lanes_of[12] = {16, 8, 8, 4, 4, 4, 8, 4, 0, 0, 16, 32};
             const bool solo = nslot == 1;
+            // solo: code 10 (512-sample rings, 16 lanes per ring) and code 6 by default; RALIGN_SOLO_JOBS=1: the short, register-light
+            // jobs -- code 11 (32 lanes per ring, 8 x 8 x 4: ring_job512) and code 0 -- which keep all 16 waves busy but measured
+            // SLOWER (295 k against 324 k particles/s at 128 / 60 / nref 10): the ring jobs of a pass are bound by the LDS array
+            // (~10 k cycles of tap reads and transposes per offset), not by the number of waves that issue them
+            const bool lightjobs = solo && getenv("RALIGN_SOLO_JOBS") && atoi(getenv("RALIGN_SOLO_JOBS")) == 1;
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
             const bool mixed = solo || (nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
             for (int lg = solo ? 9 : 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
-                const int code = (n == 256 && (nslot == 4 || solo)) ? 6 : ((n == 64 && (nslot == 4 || solo)) ? 7 : code_of(n));
+                const int code = lightjobs && n == 512 ? 11 : lightjobs && n == 256 ? 0 :
+                                 (n == 256 && (nslot == 4 || solo)) ? 6 : ((n == 64 && (nslot == 4 || solo)) ? 7 : code_of(n));
                 std::vector<int4> cls;
                 std::vector<float> clsw;
                 for (int sft = 0; sft < nslot; sft++)

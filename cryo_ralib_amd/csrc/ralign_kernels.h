@@ -647,6 +647,127 @@ __device__ __forceinline__ void ring_job_mix(const DevGeom &g, const float *imgb
     if (t == 0) { part[2 * (slot * g.nring + ring)] = av; part[2 * (slot * g.nring + ring) + 1] = sq; }
 }
 
+// Rings of 512 samples with 32 lanes per ring and EIGHT sample pairs per lane (code 11, search_solo_kernel): the 256-point complex
+// transform as 8 x 8 x 4 -- DFT-8 over the stride-32 elements a lane sampled, one transpose through the ring's own buffer, DFT-8,
+// and the last DFT-4 across the four lanes of a quad with DPP exchanges -- then the real-FFT split step from the buffer.  Half the
+// registers of ring_job<16, 16> (16 values per lane instead of 32 + 32) and twice as many, half as long jobs: a pass of one offset
+// (36 - 62 rings) then keeps all 16 waves busy, and the job fits next to a live A slice.
+//   m = 32 a + 4 b + c,  k = k1 + 8 k2 + 64 k3,  W = e^{-2 pi i / 256}
+//   A1 [k1; b c] = sum_a z[32 a + t] W8^{a k1},   t = 4 b + c;   * W^{t k1}
+//   A2 [k1 k2; c] = sum_b A1 W8^{b k2},           lane = (k1, c);   * W^{8 c k2}
+//   Z  [k]        = sum_c A2 (-i)^{c k3},         across the quad (k1, 0..3): lane c ends with k3 = (0, 2, 1, 3)[c]
+// Same samples, tables and Normalize_ring partial sums as ring_job.
+template <bool NYQ1, class Sync = NoSync>
+__device__ __forceinline__ void ring_job512(const DevGeom &g, const float *imgb, float *bufs, const float2 *tw_s,
+                                            const float2 *qt_s, const float *ctr, float *part, const int4 *inst_s,
+                                            const float *instw_s, int inst0, int count, int zero, int sbuf, int nlive = 4,
+                                            Sync sync = Sync(), int slot_lo = 0)
+{
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+    constexpr int LR = 32, H = 256;
+    const int sub = lane >> 5, t = lane & 31;
+    const int subc = min(sub, count - 1);
+    const int4 in = inst_s[inst0 + subc];
+    const int slot = in.x & 255, ring = in.x >> 8;
+    const bool active = sub < count && slot < nlive && slot >= slot_lo;
+    float *buf = bufs + (__mul24(slot, sbuf) + in.y);
+    const float rad = (float)in.w, wt = instw_s[inst0 + subc];
+    const v2f ctr2 = {ctr[2 * slot], ctr[2 * slot + 1]};
+    const float2 *qt = qt_s + in.z;
+    v2f av2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+    float2 v[8];
+    // element a of the lane is z[32 a + t] = samples 64 a + 2 t, + 1: quadrant a >> 1, table entries 64 (a & 1) + 2 t + u (of 128):
+    // the four quadrants of a table position share the table read and the radius multiply (alrl_ms mirroring (x, y), (y, -x),
+    // (-x, -y), (-y, x) as an operand modifier of the packed add of the centre)
+    if (active) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            v2f xy[2];
+            {
+#pragma clang fp contract(off)
+                const float2 s0 = qt[64 * b + 2 * t], s1 = qt[64 * b + 2 * t + 1];
+                xy[0] = v2f{s0.x, s0.y} * rad;
+                xy[1] = v2f{s1.x, s1.y} * rad;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v2f val;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const v2f o = q == 0 ? ctr2 + xy[u] : q == 1 ? vadd_rot<-1>(ctr2, xy[u]) : q == 2 ? ctr2 - xy[u] : vadd_rot<1>(ctr2, xy[u]);
+                    const float sv = bilinear_pad(imgb, g.pst, o.x, o.y);
+                    if (u == 0) val.x = sv; else val.y = sv;
+                }
+                av2 += val;
+                sq2 += val * val;
+                v[2 * q + b] = make_float2(val.x, val.y);
+                if (q & 1) __builtin_amdgcn_sched_barrier(0);       // at most 4 samples' taps in flight
+            }
+        }
+    }
+    sync();
+    if (!active) return;
+    float av = (av2.x + av2.y) * wt, sq = (sq2.x + sq2.y) * wt;
+    // ---- stage 1: DFT-8 over a, twiddle W^{t k1} = W512^{2 t k1}; row k1 parked rotated by 4 k1 (conflict-free both ways)
+    Dft<-1, 8>::run(v);
+    const int sh = g.lg_maxrin - 8;                       // W256 in units of the table's W_maxrin
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) {
+        float2 o = v[k1];
+        if (k1 > 0) o = cmul(o, tw_s[__mul24(t, k1) << sh]);
+        *reinterpret_cast<float2 *>(buf + 2 * (32 * k1 + ((t + 4 * k1) & 31))) = o;
+    }
+    RA_WAVE_SYNC();
+    // ---- stage 2: lane = (k1, c): DFT-8 over b, twiddle W^{8 c k2}
+    const int k1 = t >> 2, c = t & 3;
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const float2 *>(buf + 2 * (32 * k1 + ((4 * b + c + 4 * k1) & 31)));
+    Dft<-1, 8>::run(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; k2++) v[k2] = cmul(v[k2], tw_s[(8 * c * k2) << sh]);
+    RA_WAVE_SYNC();                      // every lane of the ring has its row: the buffer may be overwritten
+    // ---- stage 3: DFT-4 over c across the quad (DPP), natural order into the buffer: Z[k1 + 8 k2 + 64 k3]
+    {
+        const float sg2 = (c & 2) ? -1.0f : 1.0f, sg1 = (c & 1) ? -1.0f : 1.0f;
+        const bool l3 = c == 3;
+        const int k3 = ((c & 1) << 1) | (c >> 1);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) {
+            const float2 a = v[k2];
+            const float tx = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0x4E, 0xF, 0xF, true));      // lane ^ 2
+            const float ty = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0x4E, 0xF, 0xF, true));
+            const float bx = __builtin_fmaf(sg2, a.x, tx), by = __builtin_fmaf(sg2, a.y, ty);       // x0 + x2, x1 + x3, x0 - x2, x1 - x3
+            const float cx = l3 ? by : bx, cy = l3 ? -bx : by;                                       // lane 3: (x1 - x3) * (-i)
+            const float ux = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cx), 0xB1, 0xF, 0xF, true));     // lane ^ 1
+            const float uy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cy), 0xB1, 0xF, 0xF, true));
+            *reinterpret_cast<float2 *>(buf + 2 * (k1 + 8 * k2 + 64 * k3)) = make_float2(__builtin_fmaf(sg1, cx, ux), __builtin_fmaf(sg1, cy, uy));
+        }
+    }
+    RA_WAVE_SYNC();
+    // ---- split step X_k <- (Z_k, Z_{H-k}), k = 0 .. H/2, in place; X_0 and X_H are real
+    for (int k = t; k <= H / 2; k += LR) {
+        const float2 zk = *reinterpret_cast<const float2 *>(buf + 2 * k);
+        if (k == 0) {
+            if (NYQ1 && 2 * H == g.maxrin) {
+                *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, zk.x - zk.y);
+            } else {
+                *reinterpret_cast<float2 *>(buf) = make_float2(zk.x + zk.y, 0.f);
+                *reinterpret_cast<float2 *>(buf + 2 * H) = make_float2(zk.x - zk.y, 0.f);
+            }
+        } else {
+            const float2 zm = *reinterpret_cast<const float2 *>(buf + 2 * (H - k));
+            v2f xk, xm;
+            vsplit_pair(to_v(zk), to_v(zm), to_v(tw_s[k << (g.lg_maxrin - 9)]), xk, xm);
+            *reinterpret_cast<float2 *>(buf + 2 * k) = to_f2(xk);
+            if (2 * k != H) *reinterpret_cast<float2 *>(buf + 2 * (H - k)) = to_f2(xm);
+        }
+    }
+    // Normalize_ring partial sums over the 32 lanes of the ring: two DPP rows, then the neighbouring row (fixed order)
+    av = group_sum_dpp<16>(av); sq = group_sum_dpp<16>(sq);
+    av += __shfl_xor(av, 16); sq += __shfl_xor(sq, 16);
+    if (t == 0) { part[2 * (slot * g.nring + ring)] = av; part[2 * (slot * g.nring + ring) + 1] = sq; }
+}
+
 __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, const float *__restrict__ particles,
                                                                      const float *__restrict__ state, int n,
                                                                      float *__restrict__ A)

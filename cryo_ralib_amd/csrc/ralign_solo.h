@@ -395,6 +395,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target};
 #endif
                 switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+                case 11: ring_job512<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
+                case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
                 case 10: ring_job<16, 16, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
                 case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
                 case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
