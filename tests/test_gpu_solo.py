@@ -29,6 +29,15 @@ def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
     polar_stage_check(nx, ou, xr, mode)
 
 
+def test_solo_light_ring_jobs_bin_for_bin(monkeypatch):
+    """RALIGN_SOLO_JOBS=1: the 8 x 8 x 4 job for 512-sample rings (ring_job512, 32 lanes per ring) and the 16-lane job for
+    256-sample rings -- kept as a measured alternative (slower: the ring jobs are bound by the LDS array)"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
+    monkeypatch.setenv("RALIGN_SOLO_JOBS", "1")
+    polar_stage_check(128, 60, 3, api.RA_MODE_MREF)
+    polar_stage_check(130, 52, 3, api.RA_MODE_REFFREE)
+
+
 def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
     """the size-generic polar kernel at a geometry the solo kernel took over (RALIGN_SOLO=0)"""
     monkeypatch.setenv("RALIGN_SOLO", "0")
