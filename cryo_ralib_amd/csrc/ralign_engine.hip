@@ -18,6 +18,7 @@
 #include "ralign_fused.h"
 #include "ralign_tiled.h"
 #include "ralign_solo.h"
+#include "ralign_duo.h"
 #include "ralign_exact.h"
 #include "ralign_refine.h"
 
@@ -106,6 +107,7 @@ struct ra_engine {
     bool fused = false;                 // plan valid and not disabled (RALIGN_FUSED=0)
     bool tiled = false;                 // the plan is search_tiled_kernel's (ralign_tiled.h: reference tiles, more than RF_MAXREF references)
     bool solo = false;                  // search_solo_kernel (ralign_solo.h: maxrin 512, one offset resident per pass) on top of the generic tables
+    bool duo = false;                   // ... as search_duo_kernel (ralign_duo.h): two offsets per pass through the one ring buffer
     float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
     size_t f_cap_b = 0;
@@ -162,6 +164,14 @@ static bool solo_wanted(const ra_engine *e)
 {
     if (!e->generic || e->geo.maxrin != 512 || e->geo.nring > 4 * RS_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
     return !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
+}
+
+// two offsets per pass (search_duo_kernel, ralign_duo.h) for the solo class: the default (measured against search_solo_kernel:
+// +4.5 % at 128 / 60 / nref 10, +24 % at 130 / 52 / nref 50); RALIGN_DUO=0: one offset per pass
+static bool duo_wanted(const ra_engine *e)
+{
+    if (!solo_wanted(e)) return false;
+    return !(getenv("RALIGN_DUO") && atoi(getenv("RALIGN_DUO")) == 0);
 }
 
 static bool fused_wanted(const ra_engine *e)
@@ -304,7 +314,7 @@ static int build_device_geometry(ra_engine *e)
             // jobs -- code 11 (32 lanes per ring, 8 x 8 x 4: ring_job512) and code 0 -- which keep all 16 waves busy but measured
             // SLOWER (295 k against 324 k particles/s at 128 / 60 / nref 10): the ring jobs of a pass are bound by the LDS array
             // (~10 k cycles of tap reads and transposes per offset), not by the number of waves that issue them
-            const bool lightjobs = solo && getenv("RALIGN_SOLO_JOBS") && atoi(getenv("RALIGN_SOLO_JOBS")) == 1;
+            const bool lightjobs = solo && ((getenv("RALIGN_SOLO_JOBS") && atoi(getenv("RALIGN_SOLO_JOBS")) == 1) || duo_wanted(e));
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
@@ -715,6 +725,18 @@ static solo_fn select_solo(int maxrin, int nh, int ntile)
     }
 }
 
+static solo_fn select_duo(int maxrin, int nh)
+{
+    if (maxrin != 512) return nullptr;
+    switch (nh) {
+    case 1: return search_duo_kernel<512, 1, RS_NQ>;
+    case 2: return search_duo_kernel<512, 2, RS_NQ>;
+    case 3: return search_duo_kernel<512, 3, RS_NQ>;
+    case 4: return search_duo_kernel<512, 4, RS_NQ>;
+    default: return nullptr;
+    }
+}
+
 // plan of search_solo_kernel (ralign_solo.h) for an engine of the size-generic class whose rings end at 512 samples; the generic
 // kernels stay available underneath (reference preparation, RALIGN_SOLO=0, geometries whose image and one ring buffer exceed
 // the LDS)
@@ -724,8 +746,9 @@ static int setup_solo(ra_engine *e)
     if (!solo_wanted(e)) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (!build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
-    const solo_fn fk = select_solo(g.maxrin, fp.f.nh, fp.f.ntile);
+    e->duo = duo_wanted(e) && build_duo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp) && select_duo(g.maxrin, fp.f.nh);
+    if (!e->duo && !build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
+    const solo_fn fk = e->duo ? select_duo(g.maxrin, fp.f.nh) : select_solo(g.maxrin, fp.f.nh, fp.f.ntile);
     if (!fk) { fp.f.on = 0; return RA_OK; }
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
@@ -733,8 +756,11 @@ static int setup_solo(ra_engine *e)
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
     hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    if (he == hipSuccess)          // ra_debug_spectra: the polar stage through the solo kernel's debug path
+        he = hipFuncSetAttribute((const void *)search_solo_kernel<512, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
     if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(solo): ") + hipGetErrorString(he); return RA_ERR_HIP; }
-    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: solo plan: %zu bytes of LDS, image %d x %d, ring buffer %d floats, %d jobs, %d tiles of %d reference pairs\n",
+    if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: %s plan:", e->duo ? "duo" : "solo");
+    if (getenv("RALIGN_INFO")) fprintf(stderr, " %zu bytes of LDS, image %d x %d, ring buffer %d floats, %d jobs, %d tiles of %d reference pairs\n",
                                        fp.lds_bytes, fp.f.s_rows, fp.f.s_pst, fp.f.s_sbuf, e->dg.n_job, fp.f.ntile, fp.f.nh);
     e->solo = true;
     return RA_OK;
@@ -1317,7 +1343,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
     if (e->solo) {
         // particle-resident search, one offset resident per pass (ralign_solo.h): one persistent workgroup per CU
         const FusedGeom f = e->fplan.f;
-        const solo_fn fk = select_solo(g.maxrin, f.nh, f.ntile);
+        const solo_fn fk = e->duo ? select_duo(g.maxrin, f.nh) : select_solo(g.maxrin, f.nh, f.ntile);
         const int rch = resident_batch(e, n);
         {
             int rcw = ensure_resident_ws(e, rch);
@@ -1452,7 +1478,7 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
         if (he == hipSuccess) he = hipMemsetAsync(d_raw, 0, rawcnt * sizeof(float), e->stream);
         if (he == hipSuccess) {
             const FusedGeom f = e->fplan.f;
-            hipLaunchKernelGGL(select_solo(g.maxrin, f.nh, f.ntile), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
+            hipLaunchKernelGGL((search_solo_kernel<512, 1, true>), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
                                d_state, n, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, d_raw);
             hipLaunchKernelGGL(unpack_solo_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, (const float *)d_raw, n,
                                (const int *)e->d_numr, (const int *)e->d_ring_off, d_out);

@@ -66,6 +66,7 @@ struct FusedGeom {
     int s_rank[16];                // wave w runs ring jobs s_rank[w], s_rank[w] + 16, ..; the highest ranks have none
     int s_call[16];                // the transform (reference of the tile) wave w carries in every tile, -1: none
     int s_stat, s_ctr, s_rec;      // waves that reduce the Normalize_ring partials, write the next centre, merge the records
+    int s_r2;                      // search_duo_kernel: a second round of ring jobs starts at rank 16 - s_r2
 };
 
 struct FusedPlanHost {

@@ -29,6 +29,32 @@ def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
     polar_stage_check(nx, ou, xr, mode)
 
 
+def test_two_offsets_per_pass_equal_one_offset_per_pass_bit_for_bit(monkeypatch):
+    """search_duo_kernel (the default: two offsets per pass through the one ring buffer, the first offset's slice held in registers)
+    against search_solo_kernel with the same ring jobs (RALIGN_DUO=0 RALIGN_SOLO_JOBS=1): the same spectra, the same chain of
+    matrix instructions per block row, the same transforms -- every record equal to the bit, odd offset counts and edge-limited
+    windows included"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_DUO")
+    nx, ou, xr = 130, 52, 3
+    for nref, n in ((50, 64), (10, 96), (3, 48)):
+        refs = synth.make_references(nref, nx, ou)
+        parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+        rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+        st0 = np.zeros((n, 2), np.float32)
+        st0[::4] = (11, -12); st0[1::7] = (-12, 3)          # windows cut at the edge: odd numbers of live offsets
+        out = []
+        for duo in ("1", "0"):
+            monkeypatch.setenv("RALIGN_DUO", duo)
+            monkeypatch.setenv("RALIGN_SOLO_JOBS", "1")
+            eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=st0)
+            assert eng.search_path == SOLO
+            out.append((api.Engine.result_to_numpy(res).copy(), st.cpu().numpy().copy()))
+            eng.close()
+        for f in ("ref_id", "mirror", "angle_bin", "shift_idx", "peak", "alpha", "sx", "sy"):
+            np.testing.assert_array_equal(out[0][0][f], out[1][0][f], err_msg=f)
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_solo_light_ring_jobs_bin_for_bin(monkeypatch):
     """RALIGN_SOLO_JOBS=1: the 8 x 8 x 4 job for 512-sample rings (ring_job512, 32 lanes per ring) and the 16-lane job for
     256-sample rings -- kept as a measured alternative (slower: the ring jobs are bound by the LDS array)"""
