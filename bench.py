@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo (one offset resident per pass)"}
+SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo / duo (rings of 512 samples: one ring buffer next to the image)"}
 
 WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
@@ -345,6 +345,7 @@ def run_workload(args, rank, local, world, dev):
     ms_a, n_a, ms_b, n_b = al.engine.kernel_time(False)
     path = al.engine.search_path
     tiled = al.engine.search_tiled
+    opp = al.engine.search_offsets_per_pass
 
     if rank == 0:
         total = n * world * args.steps
@@ -358,9 +359,10 @@ def run_workload(args, rank, local, world, dev):
         per_launch = n * args.steps / max(n_a, 1)
         kernels = {}
         if path == 3:
-            kernels["search_solo_kernel<%d>" % M] = {
+            kernels[("search_duo_kernel<%d>" if opp == 2 else "search_solo_kernel<%d>") % M] = {
                 "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + 512-point inverse FFT + argmax, "
-                        "particle-resident, one search offset per pass, reference tiles of <= 10 with the A operand in registers",
+                        "particle-resident, %s, reference tiles with the A operand in registers" %
+                        ("two search offsets per pass through one LDS ring buffer" if opp == 2 else "one search offset per pass"),
                 "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
         elif path == 1:
             kernels[("search_tiled_kernel<%d>" if tiled else "search_fused_kernel<%d>") % M] = {

@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "pre_align_run", "pre_align_run_m", "mref_align_run", "mref_align_run_m", "get_num_ref", "reset_shifts",
     "ref_free_alignment_2D_init", "ref_free_alignment_2D_size_check", "ref_free_alignment_2D",
     "ref_free_alignment_2D_filter_references", "ra_isac_get_references", "ra_legacy_bytes",
-    "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_search_tiled", "ra_set_nomirror", "ra_set_mask",
+    "ra_last_error", "ra_create", "ra_destroy", "ra_set_stream", "ra_num_shifts", "ra_maxrin", "ra_lcirc", "ra_search_path", "ra_search_tiled", "ra_search_offsets_per_pass", "ra_set_nomirror", "ra_set_mask",
     "ra_reset_shifts", "ra_set_references", "ra_get_prepared_references", "ra_align", "ra_state_from_params", "ra_set_refine", "ra_set_class_references", "ra_align_classes",
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
@@ -94,6 +94,7 @@ def load_library(path=None):
     L.ra_lcirc.argtypes = [vp]
     L.ra_search_path.argtypes = [vp]
     L.ra_search_tiled.argtypes = [vp]
+    L.ra_search_offsets_per_pass.argtypes = [vp]
     L.ra_set_nomirror.argtypes = [vp, ctypes.c_int]
     L.ra_set_mask.argtypes = [vp, vp]
     L.ra_reset_shifts.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float]
@@ -289,6 +290,11 @@ class Engine:
     @property
     def search_tiled(self):
         return bool(self.lib.ra_search_tiled(self.handle))
+
+    @property
+    def search_offsets_per_pass(self):
+        """search_path == 3 (rings of 512 samples): 2 = search_duo_kernel, 1 = search_solo_kernel; 0 otherwise"""
+        return self.lib.ra_search_offsets_per_pass(self.handle)
 
     def set_refine(self, threshold):
         """sub-bin angle refinement with the CPU path's arithmetic (ra_set_refine): threshold on |c3| / max |b| of prb1d,

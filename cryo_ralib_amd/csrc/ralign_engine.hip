@@ -1062,6 +1062,7 @@ extern "C" int ra_last_refine_count(ra_engine *e)
 }
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->generic ? 2 : e->fused ? 1 : 0; }
+extern "C" int ra_search_offsets_per_pass(const ra_engine *e) { return !e ? RA_ERR_ARG : !e->solo ? 0 : e->duo ? 2 : 1; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
 extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }

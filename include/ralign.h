@@ -142,8 +142,11 @@ int  ra_num_shifts(const ra_engine *e);
 int  ra_maxrin(const ra_engine *e);
 int  ra_lcirc(const ra_engine *e);
 /* which kernels ra_align runs for the current geometry and window: 1 = particle-resident fused search kernel,
- * 0 = polar + contraction kernel pair, 2 = size-generic kernels (large boxes) */
+ * 0 = polar + contraction kernel pair, 2 = size-generic kernels (large boxes), 3 = particle-resident search for rings of
+ * 512 samples (ou = 41 .. ~62: one ring buffer next to the image; search_solo_kernel / search_duo_kernel) */
 int  ra_search_path(const ra_engine *e);
+/* with ra_search_path == 3: search offsets per pass, 2 (search_duo_kernel, the default) or 1 (search_solo_kernel); 0 otherwise */
+int  ra_search_offsets_per_pass(const ra_engine *e);
 /* 1 when the particle-resident path is search_tiled_kernel (reference tiles: 15 and more references), 0 otherwise */
 int  ra_search_tiled(const ra_engine *e);
 /* change the search window without re-allocating (reset_shifts analogue); the number of
