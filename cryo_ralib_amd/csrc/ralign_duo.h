@@ -88,7 +88,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     float2 *qt_s = tw_s + N;
     int4 *inst_s = reinterpret_cast<int4 *>(reinterpret_cast<float *>(qt_s) + ((2 * g.n_qtab + 3) & ~3));
     int4 *jobs_s = inst_s + g.n_inst;
-    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);
+    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job + g.n_job_b);
     // [6] counter, [7] zero, [8 + o] avg, [12 + o] 1 / sigma, [16 + 2 o] centre, [24 + 2 nring o ..] ring partials of offset o
     float *red = instw_s + ((g.n_inst + 3) & ~3);
     float2 *tws = reinterpret_cast<float2 *>(red + ((24 + 4 * g.nring + 3) & ~3));      // inverse-FFT twiddles: [8][64], then [8][8]
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     for (int i = tid; i < N; i += RF_THREADS) tw_s[i] = g.tw[i];
     for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
     for (int i = tid; i < g.n_inst; i += RF_THREADS) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
-    for (int i = tid; i < g.n_job; i += RF_THREADS) jobs_s[i] = g.jobs[i];
+    for (int i = tid; i < g.n_job + g.n_job_b; i += RF_THREADS) jobs_s[i] = g.jobs[i];
     static_assert(N == 512, "ifft512_wave_argmax");
     ifft512_twiddles(g.tw, tws, tws + N, tid, RF_THREADS);
     for (int i = tid; i < f.s_sbuf; i += RF_THREADS) bufs[i] = 0.f;       // slack between rings must hold finite values
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     const int rank = f.s_rank[wave], call = f.s_call[wave];
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bf), 0, (f.b_floats + 256) * 4, 0x00020000);
     const int ntile = f.ntile, nx1 = 2 * g.nkx + 1;
-    const int4 jd0 = g.jobs[min(rank, g.n_job - 1)];
+    // job tables: [0, n_job) for the first offset of a pass (any job: no slice is live yet), [n_job, n_job + n_job_b) -- the
+    // register-light jobs -- for the second; n_job_b = 0: one table for both
+    const int jb0 = g.n_job_b ? g.n_job : 0, jbn = g.n_job_b ? g.n_job_b : g.n_job;
+    const int4 jd0 = g.jobs[min(rank, g.n_job - 1)], jd1 = g.jobs[jb0 + min(rank, jbn - 1)];
 
     bool pend = false;                     // a pass whose last inverse FFTs and records are outstanding
     int p_prev = 0, s_prev0 = 0, s_prev1 = -1;
@@ -167,12 +170,14 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     // ring jobs of one offset (slot o of the pass: centre red[16 + 2 o], partials red[24 + 2 nring o]); the first of a pass waits for
     // the previous pass's inverse FFTs inside the job, between its sampling and its first write to the ring buffer
     // (a second round of jobs -- more than 16 -- starts at rank 16 - s_r2)
-    auto ring_jobs = [&](int o, bool wait, const int *counter, int target) {
+    auto ring_jobs = [&](auto oc, bool wait, const int *counter, int target) {
+        constexpr int o = decltype(oc)::value;
+        const int base = o ? jb0 : 0, njob = o ? jbn : g.n_job;
 #pragma unroll 1
-        for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
+        for (int jr = 0; jr * RF_WAVES < njob; jr++) {
             const int job = jr == 0 ? rank : jr * RF_WAVES + ((rank + f.s_r2) & (RF_WAVES - 1));
-            if (job >= g.n_job) continue;
-            const int4 jd = jr == 0 ? jd0 : jobs_s[job];
+            if (job >= njob) continue;
+            const int4 jd = jr == 0 ? (o ? jd1 : jd0) : jobs_s[base + job];
 #ifdef RALIGN_PROFILE_SWITCHES
             const PassSync ps = {wait && jr == 0, counter, target, nullptr};
 #else
@@ -181,6 +186,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
             const float *ctr = red + 16 + 2 * o;
             float *part = red + 24 + 2 * g.nring * o;
             switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+            case 10: if constexpr (o == 0) ring_job<16, 16, true>(g, imgb, bufs, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
+            case 6: if constexpr (o == 0) ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
             case 11: ring_job512<true>(g, imgb, bufs, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
             case 0: ring_job<8, 16, true>(g, imgb, bufs, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
             case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, ctr, part, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, 1, ps); break;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
             default: break;
             }
         }
-        if (wait && rank >= g.n_job) {
+        if (wait && rank >= njob) {
 #ifdef RALIGN_PROFILE_SWITCHES
             const PassSync ps = {true, counter, target, nullptr};
 #else
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
             RA_STAMP(g, tl, ipass, wave, 0);
             // ---- offset A: ring jobs, statistics, the slice of its spectra into the lanes of block rows 0 and 1 (all lanes load: the
             // lanes of rows 2 and 3 are overwritten below, or multiply into rows nobody stores)
-            ring_jobs(0, pend, ifft_done, done_target);
+            ring_jobs(std::integral_constant<int, 0>{}, pend, ifft_done, done_target);
             if (pend) {
                 merge_records(ntile - 1, true, p_prev, s_prev0, 0);
                 if (s_prev1 >= 0) merge_records(ntile - 1, true, p_prev, s_prev1, 1);
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
                 slice_target += RF_WAVES;
                 RA_STAMP(g, tl, ipass, wave, 4);
                 // ---- offset B: the same through the same buffer; the lanes of rows 2 and 3 replace their part of the slice
-                ring_jobs(1, true, slice_done, slice_target);
+                ring_jobs(std::integral_constant<int, 1>{}, true, slice_done, slice_target);
                 RA_STAMP(g, tl, ipass, wave, 5);
                 RF_LDS_BARRIER();
                 RA_STAMP(g, tl, ipass, wave, 6);

@@ -307,14 +307,14 @@ static int build_device_geometry(ra_engine *e)
         // (4 lanes x 8 pairs).  Measured: polar stage 5.64 -> 5.2 ms per 7143 particles.
         // nslot = 4: the four offset slots of a pass of the LDS-resident kernels; nslot = 1: search_solo_kernel (rings up to 512
         // samples, code 10: 16 lanes per ring)
-        auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W) {
+        auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W, bool lightjobs) {
             const int lanes_of[12] = {16, 8, 8, 4, 4, 4, 8, 4, 0, 0, 16, 32};
             const bool solo = nslot == 1;
-            // solo: code 10 (512-sample rings, 16 lanes per ring) and code 6 by default; RALIGN_SOLO_JOBS=1: the short, register-light
-            // jobs -- code 11 (32 lanes per ring, 8 x 8 x 4: ring_job512) and code 0 -- which keep all 16 waves busy but measured
-            // SLOWER (295 k against 324 k particles/s at 128 / 60 / nref 10): the ring jobs of a pass are bound by the LDS array
-            // (~10 k cycles of tap reads and transposes per offset), not by the number of waves that issue them
-            const bool lightjobs = solo && ((getenv("RALIGN_SOLO_JOBS") && atoi(getenv("RALIGN_SOLO_JOBS")) == 1) || duo_wanted(e));
+            // solo class, lightjobs: the short, register-light jobs -- code 11 (512-sample rings, 32 lanes per ring, 8 x 8 x 4:
+            // ring_job512) and code 0 -- instead of codes 10 / 6 (16 sample pairs per lane).  They keep all 16 waves busy but are
+            // SLOWER in search_solo_kernel (295 k against 324 k particles/s at 128 / 60 / nref 10: the ring jobs of a pass are bound
+            // by the LDS array, ~10 k cycles of tap reads and transposes per offset, not by the number of waves that issue them);
+            // search_duo_kernel needs them for its second offset, whose ring jobs run next to a live A slice
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
@@ -362,8 +362,15 @@ static int build_device_geometry(ra_engine *e)
                 flush();
             }
         };
-        if (!e->generic) make_jobs(4, jobs, inst, instw);
-        else if (solo_wanted(e)) make_jobs(1, jobs, inst, instw);
+        const bool light_only = getenv("RALIGN_SOLO_JOBS") && atoi(getenv("RALIGN_SOLO_JOBS")) == 1;
+        if (!e->generic) make_jobs(4, jobs, inst, instw, false);
+        else if (solo_wanted(e)) {
+            // table A (every kernel of the class; the first offset of a duo pass), then -- duo -- table B: the light jobs of the second offset
+            make_jobs(1, jobs, inst, instw, light_only);
+            d.n_job_b = 0;
+            const int na = (int)jobs.size();
+            if (duo_wanted(e) && !light_only) { make_jobs(1, jobs, inst, instw, true); d.n_job_b = (int)jobs.size() - na; }
+        }
         if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
             std::vector<int4> perm;
             for (const char *c = po; *c;) {
@@ -375,7 +382,8 @@ static int build_device_geometry(ra_engine *e)
             if (perm.size() == jobs.size()) jobs = perm;
         }
     }
-    d.n_job = (int)jobs.size(); d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
+    if (!(e->generic && solo_wanted(e))) d.n_job_b = 0;
+    d.n_job = (int)jobs.size() - d.n_job_b; d.n_qtab = (int)qtab.size(); d.n_inst = (int)inst.size();
     e->ringw_h = ringw;
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
@@ -746,8 +754,8 @@ static int setup_solo(ra_engine *e)
     if (!solo_wanted(e)) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    e->duo = duo_wanted(e) && build_duo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp) && select_duo(g.maxrin, fp.f.nh);
-    if (!e->duo && !build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
+    e->duo = duo_wanted(e) && build_duo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job + e->dg.n_job_b, fp) && select_duo(g.maxrin, fp.f.nh);
+    if (!e->duo && !build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job + e->dg.n_job_b, fp)) { fp.f.on = 0; return RA_OK; }
     const solo_fn fk = e->duo ? select_duo(g.maxrin, fp.f.nh) : select_solo(g.maxrin, fp.f.nh, fp.f.ntile);
     if (!fk) { fp.f.on = 0; return RA_OK; }
     int rc;

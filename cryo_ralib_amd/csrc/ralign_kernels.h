@@ -77,6 +77,7 @@ struct DevGeom {
     const float *mask;            // model_circle(last_ring) [nx*nx]
     // wave-job schedule of the polar kernel (4 search offsets per pass)
     int n_job, n_qtab, n_inst;
+    int n_job_b;                  // search_duo_kernel: jobs [n_job, n_job + n_job_b) = the ring jobs of a pass's second offset (0: as the first)
     int bd, pst;                  // zero border and row stride of the padded LDS image
     const int4 *jobs;             // {size code, first instance, instance count, 0}
     const int4 *inst;             // {offset slot 0..3 | ring << 8, ring_off, qtab offset, radius}, by ring length

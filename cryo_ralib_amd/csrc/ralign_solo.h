@@ -161,7 +161,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     float2 *qt_s = tw_s + N;
     int4 *inst_s = reinterpret_cast<int4 *>(reinterpret_cast<float *>(qt_s) + ((2 * g.n_qtab + 3) & ~3));
     int4 *jobs_s = inst_s + g.n_inst;
-    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job);
+    float *instw_s = reinterpret_cast<float *>(jobs_s + g.n_job + g.n_job_b);
     float *red = instw_s + ((g.n_inst + 3) & ~3);      // [6] counter, [7] zero, [8] avg, [12] 1 / sigma, [16] centre, [24 ..] ring partials
     float2 *tws = reinterpret_cast<float2 *>(red + ((24 + 2 * g.nring + 3) & ~3));      // inverse-FFT twiddles: [8][64], then [8][8]
     CandT *pc = reinterpret_cast<CandT *>(tws + N + 64);               // [RZ] records of the tile
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     for (int i = tid; i < N; i += RF_THREADS) tw_s[i] = g.tw[i];
     for (int i = tid; i < g.n_qtab; i += RF_THREADS) qt_s[i] = g.qtab[i];
     for (int i = tid; i < g.n_inst; i += RF_THREADS) { inst_s[i] = g.inst[i]; instw_s[i] = g.instw[i]; }
-    for (int i = tid; i < g.n_job; i += RF_THREADS) jobs_s[i] = g.jobs[i];
+    for (int i = tid; i < g.n_job + g.n_job_b; i += RF_THREADS) jobs_s[i] = g.jobs[i];
     static_assert(N == 512, "ifft512_wave_argmax");
     ifft512_twiddles(g.tw, tws, tws + N, tid, RF_THREADS);
     for (int i = tid; i < f.s_sbuf; i += RF_THREADS) bufs[i] = 0.f;       // slack between rings must hold finite values
