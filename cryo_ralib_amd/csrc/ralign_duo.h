@@ -320,45 +320,51 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
                 const int ref_lo = t * RZ, nrz = min(RZ, nref - ref_lo);
                 const int ns = (nq + 1) & ~1;
                 const unsigned voff = (unsigned)ln * 16u;
-                f32x4 acc[NH];
-                {
-                    unsigned row[NH];
-                    const unsigned pad = ns > nq ? 0x80000000u : 0u;
+                // the tile's reference pairs in chunks of at most two or three (NH = 4: 2 + 2): slice, accumulators and operands of
+                // four pairs at once spilled 75 registers
+                constexpr int NH0 = NH > 3 ? (NH + 1) / 2 : NH, NH1 = NH - NH0;
+                auto chunk = [&](auto nhc_c, int h0) {
+                    constexpr int NHC = decltype(nhc_c)::value;
+                    f32x4 acc[NHC];
+                    {
+                        unsigned row[NHC];
+                        const unsigned pad = ns > nq ? 0x80000000u : 0u;
 #pragma unroll
-                    for (int h = 0; h < NH; h++)
-                        row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)((ns - nq) * 1024);
-                    switch (ns) {
-                    case 2: rs_contract<NH, 2, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 4: rs_contract<NH, 4, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 6: rs_contract<NH, 6, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 8: rs_contract<NH, 8, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 10: rs_contract<NH, 10, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 12: rs_contract<NH, 12, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    case 14: if constexpr (NQT >= 14) rs_contract<NH, 14, NQT>(a, brsrc, voff, row, pad, acc); break;
-                    default: if constexpr (NQT >= 16) rs_contract<NH, 16, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        for (int h = 0; h < NHC; h++)
+                            row[h] = (unsigned)(f.grp_boff[xm] + min(t * NH + h0 + h, f.nrp - 1) * nq * 256) * 4u - (unsigned)((ns - nq) * 1024);
+                        switch (ns) {
+                        case 2: rs_contract<NHC, 2, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 4: rs_contract<NHC, 4, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 6: rs_contract<NHC, 6, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 8: rs_contract<NHC, 8, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 10: rs_contract<NHC, 10, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 12: rs_contract<NHC, 12, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        case 14: if constexpr (NQT >= 14) rs_contract<NHC, 14, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        default: if constexpr (NQT >= 16) rs_contract<NHC, 16, NQT>(a, brsrc, voff, row, pad, acc); break;
+                        }
                     }
-                }
-                RA_STAMP(g, tl && t == 0, ipass, wave, 8);
-                RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
-                RA_STAMP(g, tl && t == 0, ipass, wave, 9);
-                if (t > 0) { merge_records(t - 1, false, p, s0, 0); if (two) merge_records(t - 1, false, p, s1, 1); }
-                {
+                    if (h0 == 0) {
+                        RA_STAMP(g, tl && t == 0, ipass, wave, 8);
+                        RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
+                        RA_STAMP(g, tl && t == 0, ipass, wave, 9);
+                        if (t > 0) { merge_records(t - 1, false, p, s0, 0); if (two) merge_records(t - 1, false, p, s1, 1); }
+                    }
                     // Z_k = Q_k + i T_k and Z_{N-k} = conj Q_k + i conj T_k for this lane's bin of every reference pair: the even lane
                     // of a pair keeps offset A (rows 0, 1), the odd lane offset B (rows 2, 3), after the 2 x 2 exchange of
                     // search_fused_kernel's store (Util::Crosrng_ms: Q = (a + d) + i (c - b), T = (a - d) - i (b + c))
                     typedef ZLayout<N> ZL;
                     const int k = 16 * xm + xb, km = k ? N - k : N / 2;
-                    const int ref_b = ref_lo + (xj >> 1);
-                    float *zk = bufs + (odd * RZ + (xj >> 1)) * ZL::kPairStride + 2 * (k + (k >> 4));
+                    const int ref_b = ref_lo + 2 * h0 + (xj >> 1);
+                    float *zk = bufs + (odd * RZ + 2 * h0 + (xj >> 1)) * ZL::kPairStride + 2 * (k + (k >> 4));
                     const int dkm = 2 * (km + (km >> 4)) - 2 * (k + (k >> 4));
-                    float dcv[NH];
+                    float dcv[NHC];
                     if (xm == 0) {
                         const float av = red[8 + odd];
 #pragma unroll
-                        for (int h = 0; h < NH; h++) dcv[h] = av * cdc_s[min(ref_b + 2 * h, nref - 1)];
+                        for (int h = 0; h < NHC; h++) dcv[h] = av * cdc_s[min(ref_b + 2 * h, nref - 1)];
                     }
 #pragma unroll
-                    for (int h = 0; h < NH; h++) {
+                    for (int h = 0; h < NHC; h++) {
                         const int ref = ref_b + 2 * h;
                         const f32x4 c4 = acc[h];
                         const float s0v = odd ? c4[0] : c4[2], s1v = odd ? c4[1] : c4[3];
@@ -383,7 +389,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
                             *reinterpret_cast<float2 *>(z + dkm) = vm;
                         }
                     }
-                }
+                };
+                chunk(std::integral_constant<int, NH0>{}, 0);
+                if constexpr (NH1 > 0) chunk(std::integral_constant<int, NH1>{}, NH0);
                 RA_STAMP(g, tl && t == 0, ipass, wave, 10);
                 RF_LDS_BARRIER();         // the spectra of the tile are complete
                 RA_STAMP(g, tl && t == 0, ipass, wave, 11);
