@@ -1175,6 +1175,23 @@ def test_large_box_hundred_references_config4():
     eng.close()
 
 
+@pytest.mark.timeout(900)
+def test_large_box_hundred_references_config4_noisy_sample():
+    """BASELINE configs[4] at the bench's noise level: 32 particles at sigma = 1.0 against the oracle's full search over 100
+    references x 121 offsets x 2 x 1024 angles -- identical integer assignments, peaks within 1e-4"""
+    nx, ou, nref, xr, n = 256, 120, 100, 5, 32
+    refs = synth.make_references(nref, nx, ou)
+    parts, truth = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == 2
+    flips = compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    _log_flips("256^2 nref=100 sigma=1", n, flips)
+    eng.close()
+
+
 def test_large_box_is_refined_to_the_ulp():
     """the sub-bin refinement on a geometry whose rings exceed the LDS (256 x 256, ou = 120: 271 KB per offset; the exact kernels
     then work on global scratch): with every particle refined alpha equals the oracle's float32 to the ulp, 32 particles at
