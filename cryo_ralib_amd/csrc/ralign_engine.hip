@@ -19,6 +19,7 @@
 #include "ralign_tiled.h"
 #include "ralign_solo.h"
 #include "ralign_duo.h"
+#include "ralign_pair.h"
 #include "ralign_exact.h"
 #include "ralign_refine.h"
 
@@ -108,6 +109,7 @@ struct ra_engine {
     bool tiled = false;                 // the plan is search_tiled_kernel's (ralign_tiled.h: reference tiles, more than RF_MAXREF references)
     bool solo = false;                  // search_solo_kernel (ralign_solo.h: maxrin 512, one offset resident per pass) on top of the generic tables
     bool duo = false;                   // ... as search_duo_kernel (ralign_duo.h): two offsets per pass through the one ring buffer
+    bool pair = false;                  // ... search_pair_kernel (ralign_pair.h): maxrin 256 in boxes too large for four ring buffers, two per pass
     float *d_Bf = nullptr;
     int *d_fbsrc = nullptr;
     size_t f_cap_b = 0;
@@ -164,6 +166,15 @@ static bool solo_wanted(const ra_engine *e)
 {
     if (!e->generic || e->geo.maxrin != 512 || e->geo.nring > 4 * RS_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
     return !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
+}
+
+// search_pair_kernel is planned for this engine: a geometry of the size-generic class whose rings end at 256 samples -- a box
+// too large for the four ring buffers of the LDS-resident kernels (RALIGN_PAIR=0: the generic kernels)
+static bool pair_wanted(const ra_engine *e)
+{
+    if (!e->generic || e->geo.maxrin != 256 || e->geo.nring > 4 * RP_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
+    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;      // the switch that forces the generic kernels
+    return !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0);
 }
 
 // two offsets per pass (search_duo_kernel, ralign_duo.h) for the solo class: the default (measured against search_solo_kernel:
@@ -309,7 +320,7 @@ static int build_device_geometry(ra_engine *e)
         // samples, code 10: 16 lanes per ring)
         auto make_jobs = [&](int nslot, std::vector<int4> &J, std::vector<int4> &I, std::vector<float> &W, bool lightjobs) {
             const int lanes_of[12] = {16, 8, 8, 4, 4, 4, 8, 4, 0, 0, 16, 32};
-            const bool solo = nslot == 1;
+            const bool solo = nslot == 1, pairj = nslot == 2;
             // solo class, lightjobs: the short, register-light jobs -- code 11 (512-sample rings, 32 lanes per ring, 8 x 8 x 4:
             // ring_job512) and code 0 -- instead of codes 10 / 6 (16 sample pairs per lane).  They keep all 16 waves busy but are
             // SLOWER in search_solo_kernel (295 k against 324 k particles/s at 128 / 60 / nref 10: the ring jobs of a pass are bound
@@ -318,11 +329,11 @@ static int build_device_geometry(ra_engine *e)
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
-            const bool mixed = solo || (nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
+            const bool mixed = solo || pairj || (nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
             for (int lg = solo ? 9 : 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
                 const int code = lightjobs && n == 512 ? 11 : lightjobs && n == 256 ? 0 :
-                                 (n == 256 && (nslot == 4 || solo)) ? 6 : ((n == 64 && (nslot == 4 || solo)) ? 7 : code_of(n));
+                                 (n == 256 && (nslot == 4 || solo || pairj)) ? 6 : ((n == 64 && (nslot == 4 || solo || pairj)) ? 7 : code_of(n));
                 std::vector<int4> cls;
                 std::vector<float> clsw;
                 for (int sft = 0; sft < nslot; sft++)
@@ -370,7 +381,7 @@ static int build_device_geometry(ra_engine *e)
             d.n_job_b = 0;
             const int na = (int)jobs.size();
             if (duo_wanted(e) && !light_only) { make_jobs(1, jobs, inst, instw, true); d.n_job_b = (int)jobs.size() - na; }
-        }
+        } else if (pair_wanted(e)) make_jobs(2, jobs, inst, instw, false);
         if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
             std::vector<int4> perm;
             for (const char *c = po; *c;) {
@@ -745,15 +756,44 @@ static solo_fn select_duo(int maxrin, int nh)
     }
 }
 
+static solo_fn select_pair(int maxrin, int nhw)
+{
+    if (maxrin != 256) return nullptr;
+    switch (nhw) {
+    case 1: return search_pair_kernel<256, 1>;
+    case 2: return search_pair_kernel<256, 2>;
+    case 3: return search_pair_kernel<256, 3>;
+    default: return nullptr;
+    }
+}
+
 // plan of search_solo_kernel (ralign_solo.h) for an engine of the size-generic class whose rings end at 512 samples; the generic
 // kernels stay available underneath (reference preparation, RALIGN_SOLO=0, geometries whose image and one ring buffer exceed
 // the LDS)
 static int setup_solo(ra_engine *e)
 {
-    e->solo = false;
-    if (!solo_wanted(e)) return RA_OK;
+    e->solo = false; e->duo = false; e->pair = false;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
+    if (pair_wanted(e)) {
+        // maxrin 256 in a box too large for four ring buffers: two offsets per pass in two (ralign_pair.h)
+        if (!build_pair_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
+        const solo_fn fk = select_pair(g.maxrin, fp.f.nrpw);
+        if (!fk) { fp.f.on = 0; return RA_OK; }
+        int rc;
+        if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
+        if (!e->d_Bf && (rc = dev_alloc(e, &e->d_Bf, (size_t)fp.f.b_floats + 256, true))) return rc;
+        if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
+        fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
+        hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)search_pair_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+        if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(pair): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+        if (getenv("RALIGN_INFO")) fprintf(stderr, "libralign_hip: pair plan: %zu bytes of LDS, image %d x %d, 2 ring buffers of %d floats, %d jobs, %d tiles of 2 x %d reference pairs\n",
+                                           fp.lds_bytes, fp.f.s_rows, fp.f.s_pst, fp.f.s_sbuf, e->dg.n_job, fp.f.ntile, fp.f.nrpw);
+        e->solo = true; e->pair = true;
+        return RA_OK;
+    }
+    if (!solo_wanted(e)) return RA_OK;
     e->duo = duo_wanted(e) && build_duo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job + e->dg.n_job_b, fp) && select_duo(g.maxrin, fp.f.nh);
     if (!e->duo && !build_solo_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job + e->dg.n_job_b, fp)) { fp.f.on = 0; return RA_OK; }
     const solo_fn fk = e->duo ? select_duo(g.maxrin, fp.f.nh) : select_solo(g.maxrin, fp.f.nh, fp.f.ntile);
@@ -1070,7 +1110,7 @@ extern "C" int ra_last_refine_count(ra_engine *e)
 }
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->generic ? 2 : e->fused ? 1 : 0; }
-extern "C" int ra_search_offsets_per_pass(const ra_engine *e) { return !e ? RA_ERR_ARG : !e->solo ? 0 : e->duo ? 2 : 1; }
+extern "C" int ra_search_offsets_per_pass(const ra_engine *e) { return !e ? RA_ERR_ARG : !e->solo ? 0 : (e->duo || e->pair) ? 2 : 1; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
 extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }
@@ -1352,7 +1392,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
     if (e->solo) {
         // particle-resident search, one offset resident per pass (ralign_solo.h): one persistent workgroup per CU
         const FusedGeom f = e->fplan.f;
-        const solo_fn fk = e->duo ? select_duo(g.maxrin, f.nh) : select_solo(g.maxrin, f.nh, f.ntile);
+        const solo_fn fk = e->pair ? select_pair(g.maxrin, f.nrpw) : e->duo ? select_duo(g.maxrin, f.nh) : select_solo(g.maxrin, f.nh, f.ntile);
         const int rch = resident_batch(e, n);
         {
             int rcw = ensure_resident_ws(e, rch);
@@ -1487,7 +1527,8 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
         if (he == hipSuccess) he = hipMemsetAsync(d_raw, 0, rawcnt * sizeof(float), e->stream);
         if (he == hipSuccess) {
             const FusedGeom f = e->fplan.f;
-            hipLaunchKernelGGL((search_solo_kernel<512, 1, true>), dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
+            const solo_fn dk = e->pair ? (solo_fn)search_pair_kernel<256, 1> : (solo_fn)search_solo_kernel<512, 1, true>;
+            hipLaunchKernelGGL(dk, dim3(std::min(n, e->n_cu)), dim3(RF_THREADS), e->fplan.lds_bytes, e->stream, e->dg, f, d_particles,
                                d_state, n, (const float *)e->d_Bf, e->cfg.nref, e->d_fcand, d_raw);
             hipLaunchKernelGGL(unpack_solo_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, (const float *)d_raw, n,
                                (const int *)e->d_numr, (const int *)e->d_ring_off, d_out);
