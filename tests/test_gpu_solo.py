@@ -1,6 +1,8 @@
-"""GPU parity tests of the particle-resident search for rings of 512 samples (search_solo_kernel, ralign_solo.h): ou = 41 .. ~62,
-the geometry class of the reference's own documented run (notebook/00_Multireference_Alignment.ipynb cell 3: 130 x 130, ou = 52,
-nref = 50).  Same bars as tests/test_gpu_parity.py: identical integer assignments (no tie allowance), CCF peaks within 1e-4."""
+"""GPU parity tests of the particle-resident search kernels for boxes that do not fit the four ring buffers of the 90 x 90 kernels:
+rings of 512 samples (search_solo_kernel / search_duo_kernel, ralign_solo.h / ralign_duo.h: ou = 41 .. ~62, the geometry class of the
+reference's own documented run, notebook/00_Multireference_Alignment.ipynb cell 3: 130 x 130, ou = 52, nref = 50) and rings of 256
+samples in boxes of ~96 .. 150 pixels (search_pair_kernel, ralign_pair.h).  Same bars as tests/test_gpu_parity.py: identical integer
+assignments (no tie allowance), CCF peaks within 1e-4."""
 import numpy as np
 import pytest
 import torch
@@ -18,13 +20,14 @@ SOLO = 3        # ra_search_path: particle-resident, one offset per pass
 
 
 @pytest.mark.parametrize("nx,ou,xr,mode", [(130, 52, 3, api.RA_MODE_MREF), (128, 60, 3, api.RA_MODE_MREF),
-                                           (128, 60, 3, api.RA_MODE_REFFREE), (101, 44, 2, api.RA_MODE_MREF)])
+                                           (128, 60, 3, api.RA_MODE_REFFREE), (101, 44, 2, api.RA_MODE_MREF),
+                                           (100, 40, 3, api.RA_MODE_MREF), (128, 38, 4, api.RA_MODE_REFFREE)])      # the last two: search_pair_kernel
 def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
-    """Polar2Dm -> (Normalize_ring) -> Frngs of every in-window search offset through the ring jobs of the solo kernel (the
+    """Polar2Dm -> (Normalize_ring) -> Frngs of every in-window search offset through the ring jobs of the solo / pair kernels (the
     512-sample job included), element by element against the oracle in EMAN2's packed ring layout"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     eng = api.Engine(nx, ou, xr, xr, 1.0, 2 if mode == api.RA_MODE_MREF else 1, mode)
-    assert eng.search_path == SOLO and eng.maxrin == 512
+    assert eng.search_path == SOLO and eng.maxrin == (512 if ou > 40 else 256)
     eng.close()
     polar_stage_check(nx, ou, xr, mode)
 
@@ -77,9 +80,11 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
                                                 (128, 60, 10, 384, 0.25), (128, 60, 10, 384, 1.0),
                                                 (128, 60, 7, 96, 1.0),                                   # odd reference count: a half-filled pair
                                                 (130, 52, 12, 96, 1.0),                                  # two tiles of three pairs
-                                                (131, 58, 3, 64, 0.5)])                                  # odd box
+                                                (131, 58, 3, 64, 0.5),                                   # odd box
+                                                (100, 40, 10, 384, 1.0), (128, 40, 50, 128, 1.0),        # search_pair_kernel: one tile, five tiles
+                                                (101, 37, 7, 96, 0.25), (144, 40, 1, 64, 1.0)])          # odd box and reference count; one reference
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     xr = 3
     refs = synth.make_references(nref, nx, ou)
     parts, truth = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
@@ -104,21 +109,23 @@ def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     eng.close()
 
 
-def test_solo_search_equals_generic_search(monkeypatch):
-    """same inputs through the solo kernel and through the size-generic kernels it replaces: identical integer assignments"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
-    nx, ou, nref, xr, n = 128, 60, 10, 3, 96
+@pytest.mark.parametrize("nx,ou,switch", [(128, 60, "RALIGN_SOLO"), (100, 40, "RALIGN_PAIR")])
+def test_solo_search_equals_generic_search(monkeypatch, nx, ou, switch):
+    """same inputs through the solo / duo / pair kernel and through the size-generic kernels it replaces: identical integer assignments"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    nref, xr, n = 10, 3, 96
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
     rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
     st0 = np.zeros((n, 2), np.float32)
-    st0[::3] = (2, -1); st0[1::5] = (-3, 3)          # edge-limited windows: the solo kernel skips their out-of-window offsets
+    m = nx // 2 + 1 - ou - 2
+    st0[::3] = (m - 1, -1); st0[1::5] = (-m, m)      # edge-limited windows: the resident kernels skip their out-of-window offsets
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=st0)
     assert eng.search_path == SOLO
     solo = api.Engine.result_to_numpy(res).copy()
     st_solo = st.cpu().numpy().copy()
     eng.close()
-    monkeypatch.setenv("RALIGN_SOLO", "0")
+    monkeypatch.setenv(switch, "0")
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=st0)
     assert eng.search_path == 2
     gen = api.Engine.result_to_numpy(res).copy()
@@ -129,11 +136,12 @@ def test_solo_search_equals_generic_search(monkeypatch):
     eng.close()
 
 
-def test_solo_edge_limited_windows_and_reset_rule():
+@pytest.mark.parametrize("nx,ou", [(130, 52), (100, 40)])
+def test_solo_edge_limited_windows_and_reset_rule(nx, ou):
     """accumulated shifts at and beyond the edge of the box: search_range cuts the window, |shift| > mashi resets it
-    (test_mref_gpu_align.py:1030-1038); the solo kernel never samples an out-of-window offset"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
-    nx, ou, nref, xr, n = 130, 52, 4, 3, 40
+    (test_mref_gpu_align.py:1030-1038); the solo / duo / pair kernels never sample an out-of-window offset"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    nref, xr, n = 4, 3, 40
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
     rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
@@ -150,10 +158,12 @@ def test_solo_edge_limited_windows_and_reset_rule():
     eng.close()
 
 
-def test_solo_reference_free_and_nomirror():
-    """ormq's rules (no Normalize_ring, one reference) and its nomirror form (Crosrng_ns) at maxrin 512"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
-    nx, ou, xr, n = 128, 56, 3, 96
+@pytest.mark.parametrize("nx,ou", [(128, 56), (112, 40)])
+def test_solo_reference_free_and_nomirror(nx, ou):
+    """ormq's rules (no Normalize_ring, one reference) and its nomirror form (Crosrng_ns) at maxrin 512 (duo kernel) and at
+    maxrin 256 in a large box (pair kernel)"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    xr, n = 3, 96
     refs = synth.make_references(1, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
     rg = orc.rings(1, ou, 1)
