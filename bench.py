@@ -13,6 +13,8 @@ scaling) and the only collective is the RCCL all-reduce of the class sums.
     python bench.py --workload reffree                                  # BASELINE configs[2]
     python bench.py --workload largebox                                 # BASELINE configs[4] geometry, one GPU's share
     python bench.py --workload mref50                                   # BASELINE configs[3], one GPU's share (125k particles, nref=50)
+    python bench.py --workload nb00 | box128 | box100                   # boxes beyond the 90 x 90 kernels: the reference notebook's 130 x 130 / ou 52 /
+                                                                        # nref 50, 128 x 128 / ou 60, 100 x 100 / ou 40
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -33,7 +35,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo / duo (rings of 512 samples: one ring buffer next to the image)"}
+SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo / duo / pair (particle-resident, one or two ring buffers next to the image)"}
 
 WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
@@ -47,6 +49,8 @@ WORKLOADS = {
     # 50 - 90 ms longer -- the driver unmapping the gigabytes the previous workload freed --, scripts/dev/two_workloads2.py)
     "nb00": ("reference notebook/00 cell 3 geometry", 130, 52, 3.0, 50, 5000, 3, 2),
     "box128": ("128 x 128 box, ou = 60 (maxrin 512)", 128, 60, 3.0, 10, 16384, 3, 2),
+    # rings of 256 samples in a box too large for four LDS ring buffers (search_pair_kernel)
+    "box100": ("100 x 100 box, ou = 40 (maxrin 256, two ring buffers)", 100, 40, 3.0, 10, 32768, 3, 2),
 }
 
 
@@ -359,10 +363,11 @@ def run_workload(args, rank, local, world, dev):
         per_launch = n * args.steps / max(n_a, 1)
         kernels = {}
         if path == 3:
-            kernels[("search_duo_kernel<%d>" if opp == 2 else "search_solo_kernel<%d>") % M] = {
-                "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + 512-point inverse FFT + argmax, "
+            kernels[("search_pair_kernel<%d>" if M == 256 else "search_duo_kernel<%d>" if opp == 2 else "search_solo_kernel<%d>") % M] = {
+                "what": "polar resampling + Normalize_ring + ring FFT + Crosrng_ms contraction (4x4x1 MFMA) + %d-point inverse FFT + argmax, "
                         "particle-resident, %s, reference tiles with the A operand in registers" %
-                        ("two search offsets per pass through one LDS ring buffer" if opp == 2 else "one search offset per pass"),
+                        (M, "two search offsets per pass in two LDS ring buffers" if M == 256 else
+                         "two search offsets per pass through one LDS ring buffer" if opp == 2 else "one search offset per pass"),
                 "avg_launch_ms": ms_a / max(n_a, 1), "launches": n_a, "flops_per_particle": polar_f + ccf_f}
         elif path == 1:
             kernels[("search_tiled_kernel<%d>" if tiled else "search_fused_kernel<%d>") % M] = {
@@ -431,7 +436,7 @@ def run_workload(args, rank, local, world, dev):
 
 
 # what the default run adds to the headline line: the other BASELINE configs at one GPU's share, a few steps each
-OTHER_WORKLOADS = ("reffree", "mref50", "largebox", "nb00", "box128")
+OTHER_WORKLOADS = ("reffree", "mref50", "largebox", "nb00", "box128", "box100")
 
 
 def main():

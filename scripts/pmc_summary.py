@@ -29,7 +29,7 @@ out = {"bench_args": bench_args, "_what": "rocprofv3 --pmc summaries (scripts/pr
                 "bench.py --steps 1 --warmup 0 --particles 14000 (7000 particles per dispatch of the hot kernels); "
                 "FETCH_SIZE / WRITE_SIZE in KB as reported", "particles_per_dispatch": 7000, "kernels": acc}
 # the particle-resident kernels take the whole shard in one launch since round 4: 14000 particles over the dispatches of the search kernel
-nd = [v["dispatches"] for k, v in acc.items() if "search_fused" in k or "search_tiled" in k or "search_solo" in k or "search_duo" in k]
+nd = [v["dispatches"] for k, v in acc.items() if "search_fused" in k or "search_tiled" in k or "search_solo" in k or "search_duo" in k or "search_pair" in k]
 if nd:
     out["particles_per_dispatch"] = 14000.0 / nd[0]
     out["_what"] = out["_what"].replace("(7000 particles per dispatch of the hot kernels)", "(14000 / dispatches particles per dispatch of the search kernel)")
