@@ -493,13 +493,18 @@ template <typename T> static int dev_grow(ra_engine *e, T **p, size_t count, boo
 static bool resident_expected(const Geometry &g, const ra_config &cfg, bool generic, size_t *b_floats)
 {
     if (generic) {
-        // search_solo_kernel (setup_solo): rings of 512 samples, image and one ring buffer in the LDS
-        if (g.maxrin != 512 || g.nring > 4 * RS_NQ || g.numr[2] < 8 || cfg.nref > 127 || (getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0)) return false;
+        // search_solo_kernel / search_duo_kernel (setup_solo): rings of 512 samples, image and one ring buffer in the LDS;
+        // search_pair_kernel: rings of 256 samples, image and two ring buffers
+        const bool c512 = g.maxrin == 512 && g.nring <= 4 * RS_NQ && !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
+        const bool c256 = g.maxrin == 256 && g.nring <= 4 * RP_NQ && !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0) &&
+                          !(getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0);
+        if (!(c512 || c256) || g.numr[2] < 8 || cfg.nref > 127) return false;
         int pst = g.nx + 1;
         while (!((pst & 1) && ((pst - 1) & 7) && ((pst + 1) & 7))) pst++;
         const int nrp = (cfg.nref + 1) / 2, ntile = (nrp + RS_MAXNH - 1) / RS_MAXNH, nh = (nrp + ntile - 1) / ntile;
-        const int sbuf = std::max((g.lring + 31) / 32 * 32 + 16, 2 * nh * (2 * (g.maxrin + g.maxrin / 16) + 2));
-        if ((size_t)((g.nx + 1) * pst + sbuf + 4600 + 2 * g.nring + 5 * (g.nring + 16)) * sizeof(float) > 160 * 1024) return false;
+        const int sbuf = c256 ? 2 * ((g.lring + 31) / 32 * 32 + 16)
+                              : std::max((g.lring + 31) / 32 * 32 + 16, 2 * nh * (2 * (g.maxrin + g.maxrin / 16) + 2));
+        if ((size_t)((g.nx + 1) * pst + sbuf + 4600 + 2 * g.nring + 10 * (g.nring + 16)) * sizeof(float) > 160 * 1024) return false;
         size_t quads = 0;
         for (int m = 0; m < g.maxrin / 32; m++) {
             int r0 = 0;
