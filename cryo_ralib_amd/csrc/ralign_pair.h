@@ -148,6 +148,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
 
     bool pend = false;
     int p_prev = 0, s_prev0 = 0, s_prev1 = -1;
+    int ipass = 0;                         // profiling builds: the wave timeline covers the first 64 passes of workgroup 0 (stamps as search_solo_kernel)
     // records of tile t for offset slot o: best reference with the runner-up inside and across tiles (search_solo_kernel)
     auto merge_records = [&](int t, bool last, int pw, int sw, int o) {
         constexpr int W = sizeof(CandT) / 4;
@@ -224,6 +225,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
             const bool two = s1 < g.nshift;
             const int nlive = two ? 2 : 1;
             const int n0 = next_live(s1 + 1), n1 = next_live(n0 + 1);
+            const bool tl = blockIdx.x == 0 && ipass < 64;
+            RA_STAMP(g, tl, ipass, wave, 0);
             // ---- ring jobs of both offsets (slots 0, 1 of the job table) into the two ring buffers; the previous pass's last inverse
             // FFTs are awaited inside the job, between its sampling and its first write to the ring buffers
 #pragma unroll 1
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                 if (job >= g.n_job) continue;
                 const int4 jd = jr == 0 ? jd0 : jobs_s[job];
 #ifdef RALIGN_PROFILE_SWITCHES
-                const PassSync ps = {pend && jr == 0, ifft_done, done_target, nullptr};
+                const PassSync ps = {pend && jr == 0, ifft_done, done_target, g.timeline && tl ? g.timeline + (ipass * 16 + wave) * 16 : nullptr};
 #else
                 const PassSync ps = {pend && jr == 0, ifft_done, done_target};
 #endif
@@ -257,7 +260,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                 if (s_prev1 >= 0) merge_records(ntile - 1, true, p_prev, s_prev1, 1);
             }
             const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
+            RA_STAMP(g, tl, ipass, wave, 1);
             RF_LDS_BARRIER();
+            RA_STAMP(g, tl, ipass, wave, 2);
             // Normalize_ring statistics (fixed order: reproducible), one wave per offset, and the next pass's centres
             if (wave == f.s_stat || (wave == f.s_rec && two)) {
                 const int o = wave == f.s_stat ? 0 : 1;
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                     }
                 }
             }
+            RA_STAMP(g, tl, ipass, wave, 3);
             // ---- tiles of RZ references: this wave contracts pairs share * NHW .. + NHW - 1 of the tile
 #pragma unroll 1
             for (int t = 0; t < ntile; t++) {
@@ -323,7 +329,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                     default: rs_contract<NHW, 12, RP_NQ>(a, brsrc, voff, row, pad, acc); break;
                     }
                 }
+                RA_STAMP(g, tl && t == 0, ipass, wave, 4);
                 RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
+                RA_STAMP(g, tl && t == 0, ipass, wave, 5);
                 if (t > 0) { merge_records(t - 1, false, p, s0, 0); if (two) merge_records(t - 1, false, p, s1, 1); }
                 {
                     // Z_k = Q_k + i T_k and Z_{N-k} = conj Q_k + i conj T_k for this lane's bin of the wave's reference pairs: the even
@@ -367,14 +375,19 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                         }
                     }
                 }
+                RA_STAMP(g, tl && t == 0, ipass, wave, 6);
                 RF_LDS_BARRIER();         // the spectra of the tile are complete
+                RA_STAMP(g, tl && t == 0, ipass, wave, 7);
                 if (call >= 0) {          // four transforms per call, 16 lanes each: slot zs = offset * RZ + reference
                     const int j = ln & 15, zs = 4 * call + (ln >> 4);
                     const int o = zs >= RZ ? 1 : 0, rr = zs - o * RZ;
                     if (zs < 2 * RZ && rr < nrz && (two || !o))
                         ifft_argmax<N, 1, 0>(bufs, pc, tws + j, zs, zs, j, ref_lo + rr, g.nomirror != 0);
                 }
+                RA_STAMP(g, tl && t == 0, ipass, wave, 8);
             }
+            RA_STAMP(g, tl, ipass, wave, 9);
+            ipass++;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             done_target += RF_WAVES;
