@@ -222,3 +222,32 @@ def test_solo_in_the_iteration_loop():
         diff = np.abs(al.refs.cpu().numpy() - cur)
         assert (diff > 2e-6 * np.abs(cur).max()).sum() <= 4 and diff.max() < 1e-3 * np.abs(cur).max(), (diff.max(), (diff > 2e-6 * np.abs(cur).max()).sum())
     al.close()
+
+
+@pytest.mark.parametrize("nx,ou", [(104, 40), (128, 52)])
+def test_multi_stage_schedule_with_fractional_steps(nx, ou):
+    """--xr "2 1" --ts "1 0.5" (reset_shifts between the stages, a half-pixel grid in the second) through the pair / duo kernels:
+    fractional sampling centres, windows from search_range with a fractional step, every iteration against ali2d_single_iter"""
+    from cryo_ralib_amd.mref import RefFreeAligner
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    n = 96
+    refs = synth.make_references(1, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 2, 2, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    al = RefFreeAligner(parts, ou, "2 1", "-1", "1 0.5")
+    assert al.engine.search_path == SOLO and al.engine.num_shifts == 25
+    for stage in (0, 1):
+        al.set_stage(stage)
+        x, y, t = al.stages[stage]
+        for it in range(2):
+            prev = al.params().copy()
+            d = al.state.cpu().numpy().copy()
+            al.iterate(0, None)
+            al.engine.sync()
+            _, cref = orc.prepare_refs(al.tavg.cpu().numpy(), None, rg)
+            params = np.zeros((n, 6), np.float32)
+            params[:, 0] = prev["alpha"]; params[:, 1] = prev["sx"]; params[:, 2] = prev["sy"]; params[:, 3] = prev["mirror"]
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, x, y, t, (0, 0), d, params, nthreads=16)
+            flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d)
+            _log_flips("%d/%d stage %d it %d" % (nx, ou, stage, it), n, flips)
+    al.close()
