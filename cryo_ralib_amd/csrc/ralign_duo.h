@@ -133,8 +133,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     // records of tile t for offset slot o (see search_solo_kernel): best reference with the runner-up inside and across tiles
     auto merge_records = [&](int t, bool last, int pw, int sw, int o) {
         constexpr int W = sizeof(CandT) / 4;
-        if (wave == f.s_rec && lane >= 16 * o && lane < 16 * o + W) {      // lanes 0 .. 9: offset 0, lanes 16 .. 25: offset 1
-            const int wd = lane - 16 * o;
+        if (wave != f.s_rec) return;
+        const int wd = rf_own_lane(lane) - 16 * o;                         // lanes 0 .. 9: offset 0, lanes 16 .. 25: offset 1
+        if (wd >= 0 && wd < W) {
             const CandT *pco = pc + o * RZ;
             CandT *pb = pbest + 2 * o;
             const int nrz = min(RZ, nref - t * RZ);
@@ -209,14 +210,15 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
     auto statistics = [&](int o) {
         float a = 0.f, q = 0.f;
         const float *part = red + 24 + 2 * g.nring * o;
-        for (int i = lane; i < g.nring; i += 64) { a += part[2 * i]; q += part[2 * i + 1]; }
+        const int l0 = rf_own_lane(lane);
+        for (int i = l0; i < g.nring; i += 64) { a += part[2 * i]; q += part[2 * i + 1]; }
         a = wave_sum_dpp(a); q = wave_sum_dpp(q);
         float avg = 0.f, rsg = 1.f;
         if (g.mode == RA_MODE_MREF) {
             avg = a * g.inv_nn_weight;
             rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
         }
-        if (lane == 0) { red[8 + o] = avg; red[12 + o] = rsg; }
+        if (l0 == 0) { red[8 + o] = avg; red[12 + o] = rsg; }
     };
 
 #pragma unroll 1
@@ -242,9 +244,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
         };
         auto next_live = [&](int s) { while (s < g.nshift && !in_window(s)) s++; return s; };
         auto write_centres = [&](int s0, int s1) {          // two lanes of the centre wave: the pass's offsets
-            if (wave == f.s_ctr && lane < 2) {
-                const int s = lane ? s1 : s0;
-                if (s < g.nshift) { red[16 + 2 * lane] = cxf + g.shift_x[s]; red[17 + 2 * lane] = cyf + g.shift_y[s]; }
+            if (wave != f.s_ctr) return;
+            const int cl = rf_own_lane(lane);
+            if (cl < 2) {
+                const int s = cl ? s1 : s0;
+                if (s < g.nshift) { red[16 + 2 * cl] = cxf + g.shift_x[s]; red[17 + 2 * cl] = cyf + g.shift_y[s]; }
             }
         };
         int s0 = next_live(0);
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
         while (s0 < g.nshift) {
             const bool two = s1 < g.nshift;
             const int n0 = next_live(s1 + 1), n1 = next_live(n0 + 1);      // the next pass's offsets
-            const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
-            const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
+            // the lane's block (bin of the group) and row (offset, Re / Im) in the multiplies; taken anew after each round of ring jobs
+            // (rf_own_lane): nothing derived from it lives through the jobs
+            int ln, xb, xj, odd;
+            auto take_lane = [&]() { ln = rf_own_lane(lane); xb = ln >> 2; xj = ln & 3; odd = ln & 1; };
             // profiling builds, stamps: 0 pass start, 1 ring jobs of A done, 2 behind their barrier, 3 slice of A loaded, 4 behind the barrier
             // that frees the ring buffer, 5 ring jobs of B done, 6 behind their barrier, 7 slice of B loaded, 8 contraction of tile 0
             // done, 9 behind barrier A, 10 spectra stored, 11 behind barrier B, 12 transforms of tile 0 done, 15 end of the pass
@@ -274,8 +280,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
             RF_LDS_BARRIER();
             RA_STAMP(g, tl, ipass, wave, 2);
             if (wave == f.s_stat) statistics(0);
+            take_lane();
             float a[4 * NQT];
-            const char *abase = reinterpret_cast<const char *>(bufs + 2 * (16 * xm + xb) + (xj & 1));
+            const char *abase = reinterpret_cast<const char *>(bufs + 2 * (16 * xm + xb) + (xj & 1));      // the lane's bin in ring 0's place
             const int4 *gq = reinterpret_cast<const int4 *>(goff_s + xm * RS_GSTR);
 #pragma unroll
             for (int sl = 0; sl < NQT; sl++) {
@@ -301,6 +308,8 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
                 RF_LDS_BARRIER();
                 RA_STAMP(g, tl, ipass, wave, 6);
                 if (wave == f.s_stat) statistics(1);
+                take_lane();
+                abase = reinterpret_cast<const char *>(bufs + 2 * (16 * xm + xb) + (xj & 1));
                 if (xj & 2) {
 #pragma unroll
                     for (int sl = 0; sl < NQT; sl++) {
@@ -398,7 +407,13 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
                 if (call >= 0) {          // slot z = offset * RZ + reference
                     const int o = call >= RZ ? 1 : 0, rr = call - o * RZ;
                     if (rr < nrz && (two || !o))
-                        ifft512_wave_argmax(bufs, pc + call, tws, tws + N, call, ln, ref_lo + rr, g.nomirror != 0);
+                        {
+                        // NQT 16 (ou 57 .. 62): the lane's twiddles and addresses of the transform are rebuilt per tile -- held over the tile
+                        // loop they pushed 18 registers to scratch, reloaded inside the contraction (box128: 533 k -> 540 k particles/s);
+                        // NQT 14 has room for them (nb00, 9 tiles per pass: 141 k -> 148 k with them held)
+                        const int il = NQT > 14 ? rf_own_lane(lane) : ln;
+                        ifft512_wave_argmax(bufs, pc + call, tws, tws + N, call, il, ref_lo + rr, g.nomirror != 0);
+                    }
                 }
                 RA_STAMP(g, tl && t == 0, ipass, wave, 12);
             }

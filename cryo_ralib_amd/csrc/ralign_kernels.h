@@ -1198,6 +1198,15 @@ __device__ __forceinline__ void ifft512_twiddles(const float2 *__restrict__ tw51
         twb[i] = make_float2(w.x, -w.y);
     }
 }
+// an opaque copy of a lane index: what is computed from it stays where it is used.  The persistent kernels hold ~120 live registers
+// in their passes; lane-dependent addresses of one-wave tasks (records, statistics, centres) and of the later phases of a pass that the
+// compiler hoists out of the particle loop end up in scratch, and every reload is a round trip to L2 in front of a barrier
+__device__ __forceinline__ int rf_own_lane(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ float wave_max_dpp(float v)
 {
 #define RA_DPP_FMAX(X, CTRL) X = __builtin_fmaxf(X, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xF, 0xF, true)))

@@ -152,8 +152,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
     // records of tile t for offset slot o: best reference with the runner-up inside and across tiles (search_solo_kernel)
     auto merge_records = [&](int t, bool last, int pw, int sw, int o) {
         constexpr int W = sizeof(CandT) / 4;
-        if (wave == f.s_rec && lane >= 16 * o && lane < 16 * o + W) {
-            const int wd = lane - 16 * o;
+        if (wave != f.s_rec) return;
+        const int wd = rf_own_lane(lane) - 16 * o;
+        if (wd >= 0 && wd < W) {
             const CandT *pco = pc + o * RZ;
             CandT *pb = pbest + 2 * o;
             const int nrz = min(RZ, nref - t * RZ);
@@ -210,9 +211,11 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
         };
         auto next_live = [&](int s) { while (s < g.nshift && !in_window(s)) s++; return s; };
         auto write_centres = [&](int s0, int s1) {
-            if (wave == f.s_ctr && lane < 2) {
-                const int s = lane ? s1 : s0;
-                if (s < g.nshift) { red[16 + 2 * lane] = cxf + g.shift_x[s]; red[17 + 2 * lane] = cyf + g.shift_y[s]; }
+            if (wave != f.s_ctr) return;
+            const int cl = rf_own_lane(lane);
+            if (cl < 2) {
+                const int s = cl ? s1 : s0;
+                if (s < g.nshift) { red[16 + 2 * cl] = cxf + g.shift_x[s]; red[17 + 2 * cl] = cyf + g.shift_y[s]; }
             }
         };
         int s0 = next_live(0);
@@ -259,22 +262,22 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                 merge_records(ntile - 1, true, p_prev, s_prev0, 0);
                 if (s_prev1 >= 0) merge_records(ntile - 1, true, p_prev, s_prev1, 1);
             }
-            const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
             RA_STAMP(g, tl, ipass, wave, 1);
             RF_LDS_BARRIER();
             RA_STAMP(g, tl, ipass, wave, 2);
+            const int ln = rf_own_lane(lane);         // nothing derived from the lane index lives through the ring jobs
             // Normalize_ring statistics (fixed order: reproducible), one wave per offset, and the next pass's centres
             if (wave == f.s_stat || (wave == f.s_rec && two)) {
                 const int o = wave == f.s_stat ? 0 : 1;
                 float a = 0.f, q = 0.f;
-                for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (o * g.nring + i)]; q += red[25 + 2 * (o * g.nring + i)]; }
+                for (int i = ln; i < g.nring; i += 64) { a += red[24 + 2 * (o * g.nring + i)]; q += red[25 + 2 * (o * g.nring + i)]; }
                 a = wave_sum_dpp(a); q = wave_sum_dpp(q);
                 float avg = 0.f, rsg = 1.f;
                 if (g.mode == RA_MODE_MREF) {
                     avg = a * g.inv_nn_weight;
                     rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
                 }
-                if (lane == 0) { red[8 + o] = avg; red[12 + o] = rsg; }
+                if (ln == 0) { red[8 + o] = avg; red[12 + o] = rsg; }
             }
             write_centres(n0, n1);
             if (dbg_spec) {           // tests only: both ring buffers and the statistics of the pass's offsets

@@ -116,11 +116,14 @@ __device__ __forceinline__ void rs_contract(const float (&a)[4 * NQT], __amdgpu_
                                             const unsigned (&row)[NH], unsigned pad0, f32x4 (&acc)[NH])
 {
     constexpr int A0 = 4 * (NQT - NS);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // one operand buffer per reference pair, refilled for the next slot right after its four multiplies.  (Two buffers -- the rows of
+    // slot sl + 2 requested while slot sl + 1 multiplies -- cost 12 more registers: 1 - 4 % slower on both maxrin-512 workloads with
+    // the spills that brought, scripts/dev/pf_runs.sh.)
     float4 bc[NH];
     // pad0 != 0: slot 0 is padding (zero A); its B requests are sent out of the buffer's range and return zeros without a fetch
 #pragma unroll
     for (int h = 0; h < NH; h++) bc[h] = rt_load_b(rsrc, voff, row[h] | pad0);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     // of the jtot word when it lies within RA_TIE_RTOL of the winner (finalize_kernel hands both to refine_winner_kernel)
     auto merge_records = [&](int t, bool last, int pw, int sw) {
         constexpr int W = sizeof(CandT) / 4;
-        if (wave == f.s_rec && lane < W) {
-            const int wd = lane;
+        if (wave != f.s_rec) return;
+        const int wd = rf_own_lane(lane);
+        if (wd < W) {
             const int nrz = min(RZ, nref - t * RZ);
             float bv = pc[0].val, sv = -3.0e38f; int br = 0, sr = 0;
             for (int q3 = 1; q3 < nrz; q3++) {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
             RA_STAMP(g, tl && t == 0, ipass, wave, 6);
             RF_LDS_BARRIER();         // the spectra of the tile are complete
             RA_STAMP(g, tl && t == 0, ipass, wave, 7);
-            if (call >= 0 && call < nrz) ifft512_wave_argmax(bufs, pc + call, tws, tws + N, call, ln, ref_lo + call, g.nomirror != 0);
+            if (call >= 0 && call < nrz) ifft512_wave_argmax(bufs, pc + call, tws, tws + N, call, rf_own_lane(ln), ref_lo + call, g.nomirror != 0);
             RA_STAMP(g, tl && t == 0, ipass, wave, 8);
         }
     };
@@ -415,22 +419,22 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
             }
             if (pend) merge_records(ntile - 1, true, p_prev, s_prev);
             RA_STAMP(g, tl, ipass, wave, 1);
-            const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
             RF_LDS_BARRIER();
             RA_STAMP(g, tl, ipass, wave, 2);
+            const int ln = rf_own_lane(lane);         // nothing derived from the lane index lives through the ring jobs
             // Normalize_ring statistics of the offset (fixed order: reproducible) and the next pass's sampling centre
             if (wave == f.s_stat) {
                 float a = 0.f, q = 0.f;
-                for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * i]; q += red[25 + 2 * i]; }
+                for (int i = ln; i < g.nring; i += 64) { a += red[24 + 2 * i]; q += red[25 + 2 * i]; }
                 a = wave_sum_dpp(a); q = wave_sum_dpp(q);
                 float avg = 0.f, rsg = 1.f;
                 if (g.mode == RA_MODE_MREF) {
                     avg = a * g.inv_nn_weight;
                     rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
                 }
-                if (lane == 0) { red[8] = avg; red[12] = rsg; }
+                if (ln == 0) { red[8] = avg; red[12] = rsg; }
             }
-            if (wave == f.s_ctr && lane == 0 && sn < g.nshift) {
+            if (wave == f.s_ctr && ln == 0 && sn < g.nshift) {
                 red[16] = cxf + g.shift_x[sn];
                 red[17] = cyf + g.shift_y[sn];
             }

@@ -205,15 +205,20 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
         red[16 + 2 * tid] = cxf + g.shift_x[si];
         red[17 + 2 * tid] = cyf + g.shift_y[si];
         red[7] = 0.f;
+        red[0] = cxf; red[1] = cyf;      // for the wave that writes the later passes' centres
     }
     RF_LDS_BARRIER();
+    // the one-wave tasks of a pass (records, statistics, centres) start from an opaque copy of the lane index (rf_own_lane)
+    auto own_lane = [](int v) { return rf_own_lane(v); };
     const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     // records of tile t (ascending reference, ">=": later wins) against the best of the earlier tiles (a later tile wins
     // ties, as a later reference does); the last tile of a pass scales by 1/sigma and writes the pass's records out
     auto merge_records = [&](int t, bool last, int gr, int nl) {
         constexpr int W = sizeof(CandT) / 4;
-        if (wave == 2 && lane < nl * W) {
-            const int o = lane / W, wd = lane - o * W;
+        if (wave != 2) return;
+        const int ml = own_lane(lane);
+        if (ml < nl * W) {
+            const int o = ml / W, wd = ml - o * W;
             const int nrz = min(RZ, nref - t * RZ);
             float bv = pc[o * RZ].val; int br = 0;
             for (int q3 = 1; q3 < nrz; q3++) {
@@ -284,20 +289,24 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
         const int os = wave == f.stat_wave[0] ? 0 : wave == f.stat_wave[1] ? 1 : wave == f.stat_wave[2] ? 2 : wave == f.stat_wave[3] ? 3 : -1;
         if (os >= 0) {
             float a = 0.f, q = 0.f;
-            for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
+            const int sl0 = own_lane(lane);
+            for (int i = sl0; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum_dpp(a); q = wave_sum_dpp(q);
             float avg = 0.f, rsg = 1.f;
             if (g.mode == RA_MODE_MREF) {
                 avg = a * g.inv_nn_weight;
                 rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
             }
-            if (lane == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
+            if (sl0 == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
         }
-        if (wave == 5 && lane < 4 && grp + 1 < ngroup) {
-            const int si = min((grp + 1) * 4 + (int)lane, g.nshift - 1);
-            red[16 + 2 * lane] = cxf + g.shift_x[si];
-            red[17 + 2 * lane] = cyf + g.shift_y[si];
-            red[7] = 0.f;
+        if (wave == 5 && grp + 1 < ngroup) {
+            const int cl = own_lane(lane);
+            if (cl < 4) {
+                const int si = min((grp + 1) * 4 + cl, g.nshift - 1);
+                red[16 + 2 * cl] = red[0] + g.shift_x[si];
+                red[17 + 2 * cl] = red[1] + g.shift_y[si];
+                red[7] = 0.f;
+            }
         }
         // ---- this wave's slice of the spectra: bins 16 xm .. 16 xm + 15 of its offset pair, every ring that has them
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
