@@ -56,21 +56,26 @@ inline bool build_pair_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     if (g.maxrin != 256 || g.numr[2] < 8 || g.nring > 4 * RP_NQ || nref > 127 || nref < 1) return false;
     f.ng = g.maxrin / 32; f.wpg = 2;
     f.nrp = (nref + 1) / 2;
-    f.s_sbuf = (g.lring + 31) / 32 * 32 + 16;
     const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
-    const int rzmax = std::min(RP_MAXRZ, (2 * f.s_sbuf) / (2 * zstride)) & ~1;      // references per tile: 2 offsets x RZ spectra in two ring buffers
-    if (rzmax < 2) return false;
-    const int nhmax = rzmax / 2;                                                   // reference pairs per tile
-    f.ntile = (f.nrp + nhmax - 1) / nhmax;
-    f.nh = (f.nrp + f.ntile - 1) / f.ntile;
-    f.nrpw = (f.nh + 1) / 2;                     // pairs per wave (template parameter): the two waves of a group share a tile's pairs
-    f.nh = 2 * f.nrpw;
-    f.rz = 2 * f.nh; f.nzr = f.ntile;
-    if (2 * f.rz * zstride > 2 * f.s_sbuf) return false;
-    rf_layout_b(g, nref, f, out.bsrc);
     f.s_rows = g.nx + 1;
     f.s_pst = g.nx + 1;
     while (!((f.s_pst & 1) && ((f.s_pst - 1) & 7) && ((f.s_pst + 1) & 7))) f.s_pst++;
+    // references per tile: 2 offsets x RZ spectra in the two ring buffers, which grow past the rings' own length when the LDS has the
+    // room (ou 36: 12 spectra need 6552 floats, the rings 5.7 k -- without the slack 96 x 96 / ou 36 fell back to the generic kernels)
+    bool found = false;
+    for (int nhmax = RP_MAXRZ / 2; nhmax >= 1 && !found; nhmax--) {
+        f.ntile = (f.nrp + nhmax - 1) / nhmax;
+        f.nh = (f.nrp + f.ntile - 1) / f.ntile;
+        f.nrpw = (f.nh + 1) / 2;                 // pairs per wave (template parameter): the two waves of a group share a tile's pairs
+        f.nh = 2 * f.nrpw;
+        f.rz = 2 * f.nh; f.nzr = f.ntile;
+        if (f.rz > RP_MAXRZ || f.nrpw > RP_MAXNHW) continue;
+        f.s_sbuf = (std::max(g.lring, f.rz * zstride) + 31) / 32 * 32 + 16;
+        const SoloLds L = pair_lds_plan(g.maxrin, f.s_rows, f.s_pst, f.s_sbuf, n_qtab, n_inst, n_job, g.nring, nref);
+        found = (size_t)L.total * sizeof(float) <= 160 * 1024;
+    }
+    if (!found) return false;
+    rf_layout_b(g, nref, f, out.bsrc);
     // wave w: ring jobs rank w (longest first); bin group w & 7, share w >> 3 of the tile's pairs; the inverse-FFT calls of a tile
     // (4 transforms each) from the highest rank down
     const int ncall = (2 * f.rz + 3) / 4;

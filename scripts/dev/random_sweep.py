@@ -1,5 +1,6 @@
 """random geometries through the engine against the CPU checker (run on the GPU box: python scripts/dev/random_sweep.py [n] [seed]);
-prints one line per case and the search path the engine took; exits non-zero on the first mismatch."""
+prints one line per case and the search path the engine took; exits non-zero on the first mismatch.  A third argument "big" draws
+boxes of 64 .. 160 pixels with rings up to 512 samples and up to 60 references (search_pair / search_duo / the generic kernels)."""
 import os
 import sys
 
@@ -15,16 +16,17 @@ from test_gpu_parity import compare_search     # noqa: E402
 
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 for case in range(ncase):
     xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
-    nx = int(rng.integers(36, 101))
+    nx = int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
     oumax = (nx - 1) // 2 - max(xr, yr) - 1
-    ou = int(rng.integers(8, min(40, oumax) + 1))
+    ou = int(rng.integers(24, min(78, oumax) + 1)) if big else int(rng.integers(8, min(40, oumax) + 1))
     ir = int(rng.integers(1, 4)); rs = int(rng.integers(1, 3))
     ts = float(rng.choice([1.0, 1.0, 0.5]))
     mode = api.RA_MODE_MREF if rng.random() < 0.7 else api.RA_MODE_REFFREE
-    nref = int(rng.integers(1, 17)) if mode == api.RA_MODE_MREF else 1
-    n = int(rng.integers(3, 20))
+    nref = (int(rng.integers(1, 61)) if big else int(rng.integers(1, 17))) if mode == api.RA_MODE_MREF else 1
+    n = int(rng.integers(3, 9)) if big else int(rng.integers(3, 20))
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, yr, 0.25, ou=ou)
     rg = orc.rings(ir, ou, rs)
@@ -42,7 +44,7 @@ for case in range(ncase):
     st, res = eng.new_state(n), eng.new_result(n)
     eng.align(tp, st, res)
     eng.sync()
-    path = eng.search_path
+    path = "%d (%d offsets per pass)" % (eng.search_path, eng.search_offsets_per_pass)
     compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     eng.close()
     print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path), flush=True)

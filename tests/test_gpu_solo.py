@@ -82,7 +82,8 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
                                                 (130, 52, 12, 96, 1.0),                                  # two tiles of three pairs
                                                 (131, 58, 3, 64, 0.5),                                   # odd box
                                                 (100, 40, 10, 384, 1.0), (128, 40, 50, 128, 1.0),        # search_pair_kernel: one tile, five tiles
-                                                (101, 37, 7, 96, 0.25), (144, 40, 1, 64, 1.0)])          # odd box and reference count; one reference
+                                                (101, 37, 7, 96, 0.25), (144, 40, 1, 64, 1.0),           # odd box and reference count; one reference
+                                                (96, 36, 10, 128, 1.0), (112, 36, 24, 96, 0.5)])         # ring buffers grown to hold a tile's 12 spectra
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     xr = 3
