@@ -1436,7 +1436,9 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
     if (e->fused) {
         // particle-resident search: one workgroup per particle, spectra stay on the CU; launched per chunk so that a
         // launch stays a bounded unit of work (timing, candidate workspace)
-        const FusedGeom f = e->fplan.f;
+        FusedGeom f = e->fplan.f;
+        // dense offset stream: a template parameter of search_fused_kernel, a run-time flag of search_tiled_kernel (RALIGN_PACK=0: off)
+        f.pack = e->tiled && g.nshift % 4 != 0 && g.nshift >= 4 && !(getenv("RALIGN_PACK") && atoi(getenv("RALIGN_PACK")) == 0);
         fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, pack_ok(e));
         const int rch = resident_batch(e, n);
         {

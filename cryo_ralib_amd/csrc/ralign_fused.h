@@ -49,6 +49,7 @@ struct FusedGeom {
     int rz, nzr, rz_inv;           // references per inverse-FFT round, rounds, ceil(2^16 / rz) (division by multiply-shift)
     int b_floats;
     int grp_ring0[16];             // first ring that has bins of group m (rings are sorted by length)
+    int pack;                      // search_tiled_kernel: dense offset stream over the workgroup's particles (set at launch)
     int grp_boff[16];              // float offset of group m's B block: [pair][ring quad][lane][4 rings]
     int grp_nq[16];                // ring quads of group m
     const int *bsrc;               // [b_floats] (entry << 5 | reference << 1 | imaginary part), -1 = 0

@@ -179,14 +179,21 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
     const int nq = f.grp_nq[xm];
     // the B stream as a buffer resource (scalar descriptor; requests carry a scalar row offset and the lane's 16 bytes)
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bf), 0, (f.b_floats + 256) * 4, 0x00020000);
-    const int ngroup = g.nshift_pad / 4, ntile = f.ntile;
-#pragma unroll 1
-    for (int p = blockIdx.x; p < n; p += gridDim.x) {
-    RF_LDS_BARRIER();
-    const float *src = particles + (size_t)p * g.nx * g.nx;
-    {
-        // pixels only (the zero border is written once, above), global -> LDS without a stop in registers, every request of the
-        // wave in flight at once (search_fused_kernel: load_image)
+    const int ntile = f.ntile;
+    // The workgroup's particles p(i) = blockIdx.x + i gridDim.x form one stream of search offsets cut into passes of 4, as in
+    // search_fused_kernel: dense (f.pack: nshift slots per particle -- 4 particles x 49 offsets = 49 full passes, and a pass may hold
+    // the last offsets of one particle and the first of the next: its ring jobs then run twice, over the slots of the resident image
+    // and, after the next image has replaced it, over the rest) or padded (nshift_pad slots: every particle starts a pass; 49 offsets
+    // = 13 passes, the last one with a single live offset -- 5.8 % of the passes for 2 % of the work).  Everything behind the sampling
+    // is per slot (centres, statistics, spectra, records): the results are the same to the bit.
+    const int SPP = f.pack ? g.nshift : g.nshift_pad;
+    const int npw = (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nslots = npw * SPP, npass = (nslots + 3) >> 2;
+    auto particle_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    // pixels only (the zero border is written once, above), global -> LDS without a stop in registers, every request of the wave in
+    // flight at once (search_fused_kernel: load_image)
+    auto load_image = [&](int i) {
+        const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
 #pragma unroll 1
         for (int y = wave; y < g.nx; y += RF_WAVES) {
             const float *row = src + y * g.nx;
@@ -197,23 +204,28 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
                     __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    const float cxf = (float)g.cnx + w.sxi, cyf = (float)g.cnx + w.syi;
-    if (tid < 4) {
-        const int si = min((int)tid, g.nshift - 1);
-        red[16 + 2 * tid] = cxf + g.shift_x[si];
-        red[17 + 2 * tid] = cyf + g.shift_y[si];
+    };
+    // sampling centre of slot k of the pass that starts at (particle i0, offset s0): lanes 0 .. 3 of one wave
+    auto write_centre = [&](int i0, int s0, int k) {
+        int i = i0, sk = s0 + k;
+        if (sk >= SPP) { sk -= SPP; i++; }
+        i = min(i, npw - 1);
+        const int pk = particle_of(i);
+        const Window wk = particle_window(g, state[2 * pk], state[2 * pk + 1]);
+        const int si = min(sk, g.nshift - 1);
+        red[16 + 2 * k] = ((float)g.cnx + wk.sxi) + g.shift_x[si];
+        red[17 + 2 * k] = ((float)g.cnx + wk.syi) + g.shift_y[si];
         red[7] = 0.f;
-        red[0] = cxf; red[1] = cyf;      // for the wave that writes the later passes' centres
-    }
+    };
+    if (tid < 4 && npw > 0) write_centre(0, 0, (int)tid);          // sampling centres of the stream's first pass
     RF_LDS_BARRIER();
+    const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     // the one-wave tasks of a pass (records, statistics, centres) start from an opaque copy of the lane index (rf_own_lane)
     auto own_lane = [](int v) { return rf_own_lane(v); };
-    const int4 jd0 = jobs_s[min((int)wave, g.n_job - 1)];
     // records of tile t (ascending reference, ">=": later wins) against the best of the earlier tiles (a later tile wins
-    // ties, as a later reference does); the last tile of a pass scales by 1/sigma and writes the pass's records out
-    auto merge_records = [&](int t, bool last, int gr, int nl) {
+    // ties, as a later reference does); the last tile of a pass scales by 1/sigma and writes the records of the pass that started at
+    // (particle i0r, offset s0r) out
+    auto merge_records = [&](int t, bool last, int i0r, int s0r, int nl) {
         constexpr int W = sizeof(CandT) / 4;
         if (wave != 2) return;
         const int ml = own_lane(lane);
@@ -238,49 +250,70 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             if (wd == 1 && lv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(cand_jtot(word), *runr);
             if (last) {
                 if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
-                reinterpret_cast<int *>(cand + (size_t)p * g.nshift_pad + gr * 4 + o)[wd] = word;
+                int io = i0r, so = s0r + o;
+                if (so >= SPP) { so -= SPP; io++; }
+                reinterpret_cast<int *>(cand + (size_t)particle_of(io) * g.nshift_pad + so)[wd] = word;
             } else {
                 reinterpret_cast<int *>(pbest + o)[wd] = word;
             }
         }
     };
-    for (int grp = 0; grp < ngroup; grp++) {
-        const int nlive = min(4, g.nshift - 4 * grp);
+    int i0 = 0, s0 = 0, img_i = -1;             // first slot of the current pass: particle index in the stream, offset; resident image
+    int i0p = 0, s0p = 0, nlp = 4;              // ... and live slots of the previous pass (its last records are merged inside this one)
+#pragma unroll 1
+    for (int grp = 0; grp < npass; grp++) {
+        // live slots of the pass (leading), slots of the first particle, and whether a second particle starts inside it
+        const int nlive = f.pack ? min(4, nslots - 4 * grp) : min(4, g.nshift - s0);
+        const int na = min(4, SPP - s0);
+        const bool split = f.pack && na < nlive;
         const bool pend = grp > 0;
-        // profiling builds: wave timeline of workgroup 0's first particle (stamps: 0 pass start, 1 ring jobs done, 2 behind their
+        // profiling builds: wave timeline of workgroup 0's first passes (stamps: 0 pass start, 1 ring jobs done, 2 behind their
         // barrier, 3 slice in registers; tile t < 2: 4 + 5 t contraction done, + 1 behind barrier A, + 2 spectra stored, + 3 behind
         // barrier B, + 4 transforms done; 15 end of the pass)
-        const bool tl = p == (int)blockIdx.x && blockIdx.x == 0 && grp < 64;
+        const bool tl = blockIdx.x == 0 && grp < 64;
         RA_STAMP(g, tl, grp, wave, 0);
         // ---- ring jobs (as search_fused_kernel): the previous pass's last inverse FFTs are awaited inside the first job,
-        // between its sampling and its first write to the ring buffers
+        // between its sampling and its first write to the ring buffers; a pass that holds the offsets of two particles runs them
+        // twice, over slots [0, na) of the resident image and -- behind the exchange of the image between two barriers -- over [na, nlive)
 #pragma unroll 1
-        for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
-            const int job = jr * RF_WAVES + wave;
-            if (job >= g.n_job) continue;
-            const int4 jd = jr == 0 ? jd0 : jobs_s[job];
+        for (int ph = 0; ph < (split ? 2 : 1); ph++) {
+            if (img_i != i0 + ph) {
+                // at the top of a pass every wave is through with the sampling of the previous pass (its barrier 1): the image may go
+                if (ph) RF_LDS_BARRIER();
+                load_image(i0 + ph);
+                img_i = i0 + ph;
+                RF_LDS_BARRIER();
+            }
+            const int slo = ph ? na : 0, shi = (split && !ph) ? na : nlive;
+            const bool wait = pend && !ph;
+#pragma unroll 1
+            for (int jr = 0; jr * RF_WAVES < g.n_job; jr++) {
+                const int job = jr * RF_WAVES + wave;
+                if (job >= g.n_job) continue;
+                const int4 jd = jr == 0 ? jd0 : jobs_s[job];
 #ifdef RALIGN_PROFILE_SWITCHES
-            const PassSync ps = {pend && jr == 0, ifft_done, done_target, nullptr};
+                const PassSync ps = {wait && jr == 0, ifft_done, done_target, nullptr};
 #else
-            const PassSync ps = {pend && jr == 0, ifft_done, done_target};
+                const PassSync ps = {wait && jr == 0, ifft_done, done_target};
 #endif
-            switch (__builtin_amdgcn_readfirstlane(jd.x)) {
-            case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-            case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-            case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-            case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, nlive, ps); break;
-            default: break;
+                switch (__builtin_amdgcn_readfirstlane(jd.x)) {
+                case 1: ring_job<8, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                case 6: ring_job<16, 8, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                case 7: ring_job<8, 4, true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                case 9: ring_job_mix<true>(g, imgb, bufs, tw_s, qt_s, red + 16, red + 24, inst_s, instw_s, jd.y, jd.z, jd.w, g.sbuf, shi, ps, slo); break;
+                default: break;
+                }
+            }
+            if (wait && wave >= g.n_job) {
+#ifdef RALIGN_PROFILE_SWITCHES
+                const PassSync ps = {true, ifft_done, done_target, nullptr};
+#else
+                const PassSync ps = {true, ifft_done, done_target};
+#endif
+                ps();
             }
         }
-        if (pend && wave >= g.n_job) {
-#ifdef RALIGN_PROFILE_SWITCHES
-            const PassSync ps = {true, ifft_done, done_target, nullptr};
-#else
-            const PassSync ps = {true, ifft_done, done_target};
-#endif
-            ps();
-        }
-        if (pend) merge_records(ntile - 1, true, grp - 1, 4);
+        if (pend) merge_records(ntile - 1, true, i0p, s0p, nlp);
         RA_STAMP(g, tl, grp, wave, 1);
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, __float_as_int(red[7])));
         RF_LDS_BARRIER();
@@ -299,14 +332,12 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             }
             if (sl0 == 0) { red[8 + os] = avg; red[12 + os] = rsg; }
         }
-        if (wave == 5 && grp + 1 < ngroup) {
+        // first slot of the next pass
+        int in = i0, sn = s0 + 4;
+        if (sn >= SPP) { sn -= SPP; in++; }
+        if (wave == 5 && grp + 1 < npass) {
             const int cl = own_lane(lane);
-            if (cl < 4) {
-                const int si = min((grp + 1) * 4 + cl, g.nshift - 1);
-                red[16 + 2 * cl] = red[0] + g.shift_x[si];
-                red[17 + 2 * cl] = red[1] + g.shift_y[si];
-                red[7] = 0.f;
-            }
+            if (cl < 4) write_centre(in, sn, cl);
         }
         // ---- this wave's slice of the spectra: bins 16 xm .. 16 xm + 15 of its offset pair, every ring that has them
         const int xb = ln >> 2, xj = ln & 3, odd = ln & 1;
@@ -353,7 +384,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             RA_STAMP(g, tl && t < 2, grp, wave, 4 + 5 * t);
             RF_LDS_BARRIER();         // t = 0: every slice is in registers; t > 0: the inverse FFTs of tile t - 1 are over
             RA_STAMP(g, tl && t < 2, grp, wave, 5 + 5 * t);
-            if (t > 0) merge_records(t - 1, false, grp, nlive);
+            if (t > 0) merge_records(t - 1, false, i0, s0, nlive);
             {
                 // Z_k = Q_k + i T_k and Z_{N-k} (rf_store_z) for this lane's bin of every reference pair of the tile
                 typedef ZLayout<N> ZL;
@@ -414,15 +445,22 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             RA_STAMP(g, tl && t < 2, grp, wave, 8 + 5 * t);
         }
         RA_STAMP(g, tl, grp, wave, 15);
-        if (grp + 1 < ngroup) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            done_target += RF_WAVES;
-        } else {
-            RF_LDS_BARRIER();
-            merge_records(ntile - 1, true, grp, nlive);
-        }
+        // end of the pass: its last inverse FFTs are counted, not awaited -- the next pass's first ring job (or the end of the stream)
+        // waits for them, and merges the last tile's records
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0) __hip_atomic_fetch_add(ifft_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        done_target += RF_WAVES;
+        i0p = i0; s0p = s0; nlp = nlive;
+        i0 = in; s0 = sn;
     }
+    if (npass > 0) {
+#ifdef RALIGN_PROFILE_SWITCHES
+        const PassSync ps = {true, ifft_done, done_target, nullptr};
+#else
+        const PassSync ps = {true, ifft_done, done_target};
+#endif
+        ps();
+        merge_records(ntile - 1, true, i0p, s0p, nlp);
     }
 }
 

@@ -1651,7 +1651,10 @@ def test_tiled_kernel_in_the_iteration_loop():
 
 
 @pytest.mark.parametrize("nx,ou,xr,yr,n,nref", [(90, 36, 3, 3, 23, 3), (90, 36, 3, 3, 1, 2), (32, 12, 2, 1, 37, 1), (32, 12, 1, 1, 5, 4),
-                                               (32, 12, 1, 0, 9, 2), (32, 12, 0, 0, 7, 2)])
+                                               (32, 12, 1, 0, 9, 2), (32, 12, 0, 0, 7, 2),
+                                               # search_tiled_kernel (a run-time flag of the same stream): 49, 15, 9 and 3 offsets
+                                               (90, 36, 3, 3, 23, 18), (90, 36, 3, 3, 1, 16), (64, 28, 2, 1, 19, 20), (64, 28, 1, 1, 7, 24),
+                                               (64, 28, 1, 0, 10, 15)])
 def test_dense_offset_stream_is_bitwise_the_padded_one(nx, ou, xr, yr, n, nref):
     """search_fused_kernel's PACK: the offsets of a workgroup's consecutive particles fill the passes without padding (49
     offsets: 4 particles = 49 passes), a pass may hold offsets of two particles.  Everything behind the sampling is per offset
@@ -1672,7 +1675,7 @@ def test_dense_offset_stream_is_bitwise_the_padded_one(nx, ou, xr, yr, n, nref):
             eng, tp, st, res = run_engine(parts, refs_n[:nref] if nref > 1 else refs_n[:1], ou, xr, yr, 1.0, mode=mode)
         finally:
             os.environ.pop("RALIGN_PACK", None); os.environ.pop("RALIGN_GRID", None)
-        assert eng.search_path == 1
+        assert eng.search_path == 1 and bool(eng.search_tiled) == (nref >= 15)
         outs.append((eng.result_to_numpy(res).copy(), st.cpu().numpy().copy()))
         eng.close()
     for f in api.RESULT_DTYPE.names:
