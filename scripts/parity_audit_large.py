@@ -35,6 +35,7 @@ CASES = {
     "nb00": (130, 52, 3, 50, None),                     # the reference notebook's geometry (search_solo_kernel)
     "box128": (128, 60, 3, 10, None),
     "box100": (100, 40, 3, 10, None),                   # search_pair_kernel
+    "box96": (96, 36, 3, 10, None),                     # search_pair_kernel with ring buffers grown to hold a tile's spectra
 }
 
 
@@ -117,7 +118,7 @@ def main():
     threads = bench.host_cores()
     recs = []
     for w in a.workloads:
-        n = a.n if CASES[w][0] <= 100 else min(a.n, 8192)
+        n = a.n
         recs.append(run_case(w, n, a.sigma, dev, threads))
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         with open(a.out, "w") as f:
