@@ -223,17 +223,23 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
 
 #pragma unroll 1
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
-        const float *src = particles + (size_t)p * g.nx * g.nx;
-#pragma unroll 1
-        for (int y = wave; y < g.nx; y += RF_WAVES) {
-            const float *row = src + y * g.nx;
-            float *dst = img + y * g.pst;
-#pragma unroll 1
-            for (int c0 = 0; c0 < g.nx; c0 += 64)
-                if (c0 + lane < g.nx)
-                    __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
-        }
         Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+        {
+            const int side = f.s_crop ? f.s_crop : g.nx;
+            const int ox0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.sxi)) : 0;
+            const int oy0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.syi)) : 0;
+            const float *src = particles + (size_t)p * g.nx * g.nx + oy0 * g.nx + ox0;
+#pragma unroll 1
+            for (int y = wave; y < side; y += RF_WAVES) {
+                const float *row = src + y * g.nx;
+                float *dst = img + y * g.pst;
+#pragma unroll 1
+                for (int c0 = 0; c0 < side; c0 += 64)
+                    if (c0 + lane < side)
+                        __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
+            }
+            imgb = img - g.pst - 1 - (oy0 * g.pst + ox0);      // 1-based (ix, iy) of the BOX -> img[(iy - 1 - oy0) pst + ix - 1 - ox0]
+        }
         w.lkx = __builtin_amdgcn_readfirstlane(w.lkx); w.rkx = __builtin_amdgcn_readfirstlane(w.rkx);
         w.lky = __builtin_amdgcn_readfirstlane(w.lky); w.rky = __builtin_amdgcn_readfirstlane(w.rky);
         const float cxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)g.cnx + w.sxi)));

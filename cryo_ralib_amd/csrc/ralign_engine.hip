@@ -1607,24 +1607,34 @@ static xs_fn select_xs(int nx, int *nband = nullptr)
     if (npt <= 24) { if (nband) *nband = 3; return transform_sum_kernel<8, 24>; }
     return nullptr;
 }
+// the whole image in LDS (transform_sum_kernel), or -- larger boxes -- output tiles with the source box of each in LDS
+// (transform_sum_tile_kernel; RALIGN_XTILE=0: the aligned stack + class_sum_kernel as before)
+static bool xs_whole_image(const ra_engine *e)
+{
+    if (e->xf_generic || !select_xs(e->geo.nx)) return false;
+    return (size_t)(e->geo.nx + 2) * ((e->geo.nx + 2) | 1) * sizeof(float) <= RA_XS_LDS_MAX;
+}
 static bool xs_usable(const ra_engine *e)
 {
-    const int npix = e->geo.nx * e->geo.nx;
-    if (e->xf_generic || e->atomic_sums || !select_xs(e->geo.nx)) return false;
-    if ((size_t)(e->geo.nx + 2) * ((e->geo.nx + 2) | 1) * sizeof(float) > RA_XS_LDS_MAX) return false;
-    return !(getenv("RALIGN_XSUM") && atoi(getenv("RALIGN_XSUM")) == 0);
+    if (e->atomic_sums) return false;
+    if (getenv("RALIGN_XSUM") && atoi(getenv("RALIGN_XSUM")) == 0) return false;
+    if (xs_whole_image(e)) return true;
+    return e->geo.nx >= RA_XT_BB && !(getenv("RALIGN_XTILE") && atoi(getenv("RALIGN_XTILE")) == 0);
 }
 static int transform_sum(ra_engine *e, const float *d_particles, int n, int index0, const ra_result *d_result, float *d_sums, int *d_counts)
 {
     const int nx = e->geo.nx, npix = nx * nx, nseg = 2 * e->cfg.nref;
     int nband = 1;
-    const xs_fn fn = select_xs(nx, &nband);
-    const size_t xs_lds = (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float);
+    const bool tiles = !xs_whole_image(e);
+    const xs_fn fn = tiles ? transform_sum_tile_kernel : select_xs(nx, &nband);
+    const int ntile = ((nx + RA_XT_TS - 1) / RA_XT_TS) * ((nx + RA_XT_TS - 1) / RA_XT_TS);
+    const size_t xs_lds = tiles ? (size_t)2 * RA_XT_BB * RA_XT_BB * sizeof(float) : (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float);
     if (xs_lds > 64 * 1024) RA_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_lds));
     for (int start = 0; start < n; start += RA_XS_BATCH) {
         const int cn = std::min(RA_XS_BATCH, n - start);
         // runs per segment: ~1024 workgroups, at least ~8 members per run on average
         int nrun = std::max(1, std::min(512, (1024 + nseg - 1) / nseg));
+        if (tiles) nrun = std::max(1, std::min(64, 2048 / (nseg * ntile)));      // ntile workgroups per (segment, run) already
         nrun = std::max(1, std::min(nrun, cn / (8 * nseg)));
         const size_t need_m = (size_t)nseg * cn, need_p = (size_t)nrun * nseg * npix;
         if (need_m > e->xs_cap_members) {
@@ -1648,7 +1658,7 @@ static int transform_sum(ra_engine *e, const float *d_particles, int n, int inde
         hipLaunchKernelGGL(class_members_wide_kernel, dim3(nseg), dim3(1024), 0, e->stream, d_result + start, cn, index0 + start,
                            e->d_xs_members, e->d_xs_mcount, cn, d_counts);
         RA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(fn, dim3(nseg, nrun, nband), dim3(RA_XS_THREADS), (size_t)(nx + 2) * ((nx + 2) | 1) * sizeof(float), e->stream, nx,
+        hipLaunchKernelGGL(fn, dim3(nseg, nrun, tiles ? ntile : nband), dim3(tiles ? RA_XT_THREADS : RA_XS_THREADS), xs_lds, e->stream, nx,
                            d_particles + (size_t)start * npix, cn, index0 + start, d_result + start, (const float2 *)e->d_xs_trig, (const int *)e->d_xs_members,
                            (const int *)e->d_xs_mcount, cn, e->d_xs_partial);
         RA_HIP(hipGetLastError());

@@ -49,6 +49,8 @@ struct FusedGeom {
     int rz, nzr, rz_inv;           // references per inverse-FFT round, rounds, ceil(2^16 / rz) (division by multiply-shift)
     int b_floats;
     int grp_ring0[16];             // first ring that has bins of group m (rings are sorted by length)
+    int s_crop, s_cropm;           // solo / duo / pair kernels: side of the LDS image when it is a crop around the particle's sampling centre (0: the whole image), and
+                                   // the distance of its first column from that centre (crop_plan)
     int pack;                      // search_tiled_kernel: dense offset stream over the workgroup's particles (set at launch)
     int grp_boff[16];              // float offset of group m's B block: [pair][ring quad][lane][4 rings]
     int grp_nq[16];                // ring quads of group m

@@ -1821,6 +1821,137 @@ __global__ __launch_bounds__(RA_XS_THREADS) void transform_sum_kernel(int nx, co
     for (int k = 0; k < NPT; k++) { const int o = tid + (band + k) * S; if (live && o < npix) dst[o] = acc[k]; }
 }
 
+// K4d: the same for boxes whose image does not fit the LDS (transform_sum_kernel stops at ~140 pixels): workgroup = (segment, run,
+// OUTPUT TILE of 64 x 64 pixels).  The taps of a tile's pixels lie in the rotated tile's bounding box in the source image, at most
+// 63 (|cos| + |sin|) <= 89.1 pixels wide plus the neighbours of quadri and a margin for rounding: a box of 98 x 98 source pixels is brought in per member --
+// global -> LDS without a stop in registers, periodic in both directions as quadri's own neighbour rule (ip1 / im1 wrap around), two
+// boxes so that the next member's box travels while this one is interpolated -- and every thread adds its 8 pixels (column tx,
+// rows ty + 8 k) to accumulators in registers (256 threads: 3.1 ms per 8192 x 256 x 256, 512: 1.9 ms, 1024: 2.6 ms).  A pixel whose source position lies outside the image takes the particle's own
+// pixel (quadri_background's rule: the interpolation at the integer position (xnew, ynew) is that pixel, to the bit), read from
+// global memory.  Arithmetic and association of the sums are transform_sum_kernel's: partial[run][segment][pixel], runs added in
+// run order by class_sum_combine_kernel.
+#define RA_XT_TS 64
+#define RA_XT_BB 98
+#define RA_XT_THREADS 512
+__global__ __launch_bounds__(RA_XT_THREADS) void transform_sum_tile_kernel(int nx, const float *__restrict__ particles, int n, int index0,
+                                                                           const ra_result *__restrict__ res, const float2 *__restrict__ trig,
+                                                                           const int *__restrict__ members,
+                                                                           const int *__restrict__ mcount, int mstride,
+                                                                           float *__restrict__ partial)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) float box[];          // [2][RA_XT_BB * RA_XT_BB]
+    constexpr int BB = RA_XT_BB, NB = BB * BB, NW = RA_XT_THREADS / 64, NK = RA_XT_TS / NW;
+    const int seg = blockIdx.x, run = blockIdx.y, nrun = gridDim.y, tid = threadIdx.x, npix = nx * nx;
+    const int ntx = (nx + RA_XT_TS - 1) / RA_XT_TS;
+    const int tx0 = (blockIdx.z % ntx) * RA_XT_TS, ty0 = (blockIdx.z / ntx) * RA_XT_TS;
+    const int cnt = mcount[seg];
+    const int j0 = (int)((long long)cnt * run / nrun), j1 = (int)((long long)cnt * (run + 1) / nrun);
+    const int *mem = members + (size_t)seg * mstride;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = tx0 + lane, ty = ty0 + wave;            // destination column; first destination row (then + NW k)
+    const int xc = nx / 2, yc = nx / 2, mstart = 1 - nx % 2;
+    float acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) acc[k] = 0.f;
+    struct Pose { float shiftxc, shiftyc, cang, sang; int mirror, bx0, by0; };
+    // the member's pose and the origin (1-based source coordinates of box element (0, 0)) of its tile's box
+    auto pose_of = [&](int j) {
+        Pose q;
+        const ra_result r = res[mem[j]];
+        const float2 cs = trig[mem[j]];
+        float delx = r.sx, dely = r.sy;
+        while (delx >= (float)nx) delx -= nx;
+        while (delx <= -(float)nx) delx += nx;
+        while (dely >= (float)nx) dely -= nx;
+        while (dely <= -(float)nx) dely += nx;
+        q.shiftxc = xc + delx; q.shiftyc = yc + dely; q.cang = cs.x; q.sang = cs.y; q.mirror = r.mirror;
+        // source columns of the tile's destination columns (mirror reverses [mstart, nx)), rows ty0 .. ty0 + 63
+        // (even nx: column 0 is not mirrored and its source lies a box away from its neighbours': it goes through global memory)
+        const int c0 = (r.mirror && tx0 < mstart) ? mstart : tx0, c1 = min(tx0 + RA_XT_TS - 1, nx - 1);
+        const int ia = r.mirror ? mstart + (nx - 1) - c1 : c0, ib = r.mirror ? mstart + (nx - 1) - c0 : c1;
+        const float xa = (float)ia - q.shiftxc, xb = (float)ib - q.shiftxc;
+        const float ya = (float)ty0 - q.shiftyc, yb = (float)min(ty0 + RA_XT_TS - 1, nx - 1) - q.shiftyc;
+        float lox = 3.0e38f, loy = 3.0e38f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float x = (c & 1) ? xb : xa, y = (c & 2) ? yb : ya;
+            lox = fminf(lox, x * q.cang - y * q.sang); loy = fminf(loy, x * q.sang + y * q.cang);
+        }
+        q.bx0 = (int)floorf(lox + xc + 1.0f) - 3; q.by0 = (int)floorf(loy + yc + 1.0f) - 3;
+        return q;
+    };
+    // box element e = (row e / BB, column e % BB) <- source pixel ((by0 + row - 1) mod nx, (bx0 + col - 1) mod nx)
+    auto stage = [&](int j, const Pose &q, float *dstbox) {
+        const float *src = particles + (size_t)mem[j] * npix;
+        int cb = (q.bx0 - 1) % nx, rb = (q.by0 - 1) % nx;
+        if (cb < 0) cb += nx;
+        if (rb < 0) rb += nx;
+#pragma unroll 1
+        for (int e0 = wave * 64; e0 < NB; e0 += RA_XT_THREADS) {
+            const int e = min(e0 + lane, NB - 1), row = e / BB, col = e - row * BB;
+            int sr = rb + row, sc = cb + col;
+            if (sr >= nx) sr -= nx;
+            if (sc >= nx) sc -= nx;
+            if (sr >= nx) sr %= nx;              // boxes wider than the image (nx < 96): not the geometry this kernel is for, but exact
+            if (sc >= nx) sc %= nx;
+            if (e0 + lane < NB)
+                __builtin_amdgcn_global_load_lds(src + sr * nx + sc, (__attribute__((address_space(3))) void *)(dstbox + e0), 4, 0, 0);
+        }
+    };
+    Pose cur{}, nxt{};
+    if (j0 < j1) { cur = pose_of(j0); stage(j0, cur, box); }
+#pragma unroll 1
+    for (int j = j0; j < j1; j++) {
+        float *bx = box + ((j - j0) & 1) * NB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // this member's box is complete; the other box is free
+        if (j + 1 < j1) { nxt = pose_of(j + 1); stage(j + 1, nxt, box + ((j + 1 - j0) & 1) * NB); }
+        if (tx < nx) {
+            const int ix = (cur.mirror && tx >= mstart) ? mstart + (nx - 1) - tx : tx;
+            const float x = (float)ix - cur.shiftxc;
+            const float xcang = x * cur.cang, xsang = x * cur.sang;
+            const float *P = bx - (cur.by0 * BB + cur.bx0);
+            const float *own = particles + (size_t)mem[j] * npix + ix;
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const int iy = min(ty + NW * k, nx - 1);
+                const float y = (float)iy - cur.shiftyc;
+                const float ycang = y * cur.cang + yc;
+                const float ysang = -y * cur.sang + xc;
+                const float xold = xcang + ysang;
+                const float yold = xsang + ycang;
+                const float X = xold + 1.0f, Y = yold + 1.0f;
+                float v;
+                if ((X < 1.0f) || (X >= (float)(nx + 1)) || (Y < 1.0f) || (Y >= (float)(nx + 1))) {
+                    v = own[iy * nx];
+                } else if (cur.mirror && tx < mstart) {
+                    v = quadri_background_1b(particles + (size_t)mem[j] * npix, nx, nx, X, Y, ix + 1, iy + 1);
+                } else {
+                    const int i = (int)X, jj = (int)Y;
+                    const float dx0 = X - i, dy0 = Y - jj;
+                    const float *q = P + jj * BB + i;
+                    const float f0 = q[0];
+                    const float c1 = q[1] - f0;
+                    const float c2 = (c1 - f0 + q[-1]) * 0.5f;
+                    const float c3 = q[BB] - f0;
+                    const float c4 = (c3 - f0 + q[-BB]) * 0.5f;
+                    const float dxb = dx0 - 1, dyb = dy0 - 1;
+                    const float c5 = q[BB + 1] - f0 - c1 - c3;
+                    v = f0 + dx0 * (c1 + dxb * c2 + dy0 * c5) + dy0 * (c3 + dyb * c4);
+                }
+                acc[k] += v;
+            }
+        }
+        cur = nxt;
+    }
+    float *dst = partial + ((size_t)run * gridDim.x + seg) * npix;
+    if (tx < nx) {
+#pragma unroll
+        for (int k = 0; k < NK; k++) { const int iy = ty + NW * k; if (iy < nx) dst[iy * nx + tx] = acc[k]; }
+    }
+}
+
 // (float)cos / sin of the angle in double, once per particle, exactly as transform_kernel forms them
 __global__ void transform_trig_kernel(const ra_result *__restrict__ res, int n, float2 *__restrict__ trig)
 {

@@ -57,9 +57,7 @@ inline bool build_pair_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     f.ng = g.maxrin / 32; f.wpg = 2;
     f.nrp = (nref + 1) / 2;
     const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
-    f.s_rows = g.nx + 1;
-    f.s_pst = g.nx + 1;
-    while (!((f.s_pst & 1) && ((f.s_pst - 1) & 7) && ((f.s_pst + 1) & 7))) f.s_pst++;
+    crop_plan(g, f);
     // references per tile: 2 offsets x RZ spectra in the two ring buffers, which grow past the rings' own length when the LDS has the
     // room (ou 36: 12 spectra need 6552 floats, the rings 5.7 k -- without the slack 96 x 96 / ou 36 fell back to the generic kernels)
     bool found = false;
@@ -195,17 +193,23 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
 
 #pragma unroll 1
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
-        const float *src = particles + (size_t)p * g.nx * g.nx;
-#pragma unroll 1
-        for (int y = wave; y < g.nx; y += RF_WAVES) {
-            const float *row = src + y * g.nx;
-            float *dst = img + y * g.pst;
-#pragma unroll 1
-            for (int c0 = 0; c0 < g.nx; c0 += 64)
-                if (c0 + lane < g.nx)
-                    __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
-        }
         Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+        {
+            const int side = f.s_crop ? f.s_crop : g.nx;
+            const int ox0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.sxi)) : 0;
+            const int oy0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.syi)) : 0;
+            const float *src = particles + (size_t)p * g.nx * g.nx + oy0 * g.nx + ox0;
+#pragma unroll 1
+            for (int y = wave; y < side; y += RF_WAVES) {
+                const float *row = src + y * g.nx;
+                float *dst = img + y * g.pst;
+#pragma unroll 1
+                for (int c0 = 0; c0 < side; c0 += 64)
+                    if (c0 + lane < side)
+                        __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
+            }
+            imgb = img - g.pst - 1 - (oy0 * g.pst + ox0);      // 1-based (ix, iy) of the BOX -> img[(iy - 1 - oy0) pst + ix - 1 - ox0]
+        }
         w.lkx = __builtin_amdgcn_readfirstlane(w.lkx); w.rkx = __builtin_amdgcn_readfirstlane(w.rkx);
         w.lky = __builtin_amdgcn_readfirstlane(w.lky); w.rky = __builtin_amdgcn_readfirstlane(w.rky);
         const float cxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)g.cnx + w.sxi)));

@@ -62,6 +62,30 @@ inline SoloLds solo_lds_plan(int N, int rows, int pst, int sbuf, int n_qtab, int
     return L;
 }
 
+// LDS image of the solo / duo / pair kernels.  The rings of every in-window offset of a particle touch the pixels within
+// ou + (largest search shift) + 1 of its sampling centre only, so a box much larger than the rings (256 x 256 around ou = 40) need
+// not be resident: the image is a CROP of 2 (ou + S) + 5 columns and rows whose origin follows the particle's centre (clamped to
+// the box), plus the never-written zero row / column the tap of weight 0 at the box's edge may read.  Returns the resident columns.
+inline int crop_plan(const Geometry &g, FusedGeom &f)
+{
+    const int S = (int)std::ceil(std::max(g.nkx, g.nky) * g.step - 1e-6);
+    const int side = 2 * (S + g.last_ring) + 5;
+    const bool crop = side < g.nx && !(getenv("RALIGN_CROP") && atoi(getenv("RALIGN_CROP")) == 0);
+    f.s_crop = crop ? side : 0;
+    f.s_cropm = S + g.last_ring + 1;
+    const int cols = crop ? side : g.nx;
+    f.s_rows = cols + 1;
+    f.s_pst = cols + 1;
+    while (!((f.s_pst & 1) && ((f.s_pst - 1) & 7) && ((f.s_pst + 1) & 7))) f.s_pst++;
+    return cols;
+}
+
+// first column / row (0-based) of a particle's crop: its sampling centre (1-based, float) minus s_cropm, inside the box
+__device__ __forceinline__ int crop_origin(const FusedGeom &f, int nx, float centre)
+{
+    return min(max((int)floorf(centre) - 1 - f.s_cropm, 0), nx - f.s_crop);
+}
+
 // n_qtab, n_inst, n_job: sizes of the job tables build_device_geometry made for ONE offset slot
 inline bool build_solo_plan(const Geometry &g, int nref, int n_qtab, int n_inst, int n_job, FusedPlanHost &out)
 {
@@ -79,9 +103,7 @@ inline bool build_solo_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     rf_layout_b(g, nref, f, out.bsrc);
     // image without a search-range border; the row stride keeps vertical and diagonal neighbours out of one LDS bank
     // (as build_device_geometry does for the bordered image)
-    f.s_rows = g.nx + 1;
-    f.s_pst = g.nx + 1;
-    while (!((f.s_pst & 1) && ((f.s_pst - 1) & 7) && ((f.s_pst + 1) & 7))) f.s_pst++;
+    crop_plan(g, f);
     const int zstride = 2 * (g.maxrin + g.maxrin / 16) + 2;
     f.s_sbuf = std::max((g.lring + 31) / 32 * 32 + 16, f.rz * zstride);
     // ring jobs: longest first, wave w runs jobs rank[w], rank[w] + 16, ..; the waves with the highest ranks have no job in a
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
         goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
     }
     // 1-based coordinates (ix, iy) -> img[(iy - 1) pst + ix - 1]
-    const float *imgb = img - g.pst - 1;
+    const float *imgb = img - g.pst - 1;          // (re-based per particle when the image is a crop)
     int *ifft_done = reinterpret_cast<int *>(red + 6);
     if (tid == 0) { *ifft_done = 0; red[7] = 0.f; }
     int done_target = 0;
@@ -350,17 +372,23 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
         // every wave is past the barrier behind the ring jobs of the previous particle's last pass: its image may go.
         // Pixels only (the zero row / column were written once, above), global -> LDS without a stop in registers
-        const float *src = particles + (size_t)p * g.nx * g.nx;
-#pragma unroll 1
-        for (int y = wave; y < g.nx; y += RF_WAVES) {
-            const float *row = src + y * g.nx;
-            float *dst = img + y * g.pst;
-#pragma unroll 1
-            for (int c0 = 0; c0 < g.nx; c0 += 64)
-                if (c0 + lane < g.nx)
-                    __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
-        }
         Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+        {
+            const int side = f.s_crop ? f.s_crop : g.nx;
+            const int ox0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.sxi)) : 0;
+            const int oy0 = f.s_crop ? __builtin_amdgcn_readfirstlane(crop_origin(f, g.nx, (float)g.cnx + w.syi)) : 0;
+            const float *src = particles + (size_t)p * g.nx * g.nx + oy0 * g.nx + ox0;
+#pragma unroll 1
+            for (int y = wave; y < side; y += RF_WAVES) {
+                const float *row = src + y * g.nx;
+                float *dst = img + y * g.pst;
+#pragma unroll 1
+                for (int c0 = 0; c0 < side; c0 += 64)
+                    if (c0 + lane < side)
+                        __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
+            }
+            imgb = img - g.pst - 1 - (oy0 * g.pst + ox0);      // 1-based (ix, iy) of the BOX -> img[(iy - 1 - oy0) pst + ix - 1 - ox0]
+        }
         // wave-uniform values: keep them in scalar registers
         w.lkx = __builtin_amdgcn_readfirstlane(w.lkx); w.rkx = __builtin_amdgcn_readfirstlane(w.rkx);
         w.lky = __builtin_amdgcn_readfirstlane(w.lky); w.rky = __builtin_amdgcn_readfirstlane(w.rky);

@@ -36,7 +36,9 @@ CASES = {
     "box128": (128, 60, 3, 10, None),
     "box100": (100, 40, 3, 10, None),                   # search_pair_kernel
     "box96": (96, 36, 3, 10, None),                     # search_pair_kernel with ring buffers grown to hold a tile's spectra
+    "largebox": (256, 120, 5, 100, None),               # BASELINE configs[4] geometry (generic kernels); at most 8192 particles: the oracle needs ~0.5 s of 16 threads each
 }
+CAPS = {"largebox": 8192}
 
 
 def classify(r, params, jt, d_new, d_old, shifts, maxrin):
@@ -118,7 +120,7 @@ def main():
     threads = bench.host_cores()
     recs = []
     for w in a.workloads:
-        n = a.n
+        n = min(a.n, CAPS.get(w, a.n))
         recs.append(run_case(w, n, a.sigma, dev, threads))
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         with open(a.out, "w") as f:

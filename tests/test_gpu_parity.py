@@ -661,13 +661,16 @@ def test_command_line_entry_points(tmp_path):
     assert "EMAN.xform.align2d" in at[0] and int(at[5]["EMAN.source_n"]) == 5
 
 
-def _xs_runs(n, nseg):
-    """runs per (class, parity) list of transform_sum_kernel (ralign_engine.hip: transform_sum)"""
+def _xs_runs(n, nseg, nx=0):
+    """runs per (class, parity) list of transform_sum_kernel / transform_sum_tile_kernel (ralign_engine.hip: transform_sum)"""
     nrun = max(1, min(512, (1024 + nseg - 1) // nseg))
+    if nx > 141:          # output tiles of 64 x 64 pixels: that many workgroups per run already
+        nrun = max(1, min(64, 2048 // (nseg * ((nx + 63) // 64) ** 2)))
     return max(1, min(nrun, n // (8 * nseg)))
 
 
-@pytest.mark.parametrize("nx,ou,xr", [(90, 36, 3), (33, 12, 2), (64, 24, 3), (130, 52, 3)])
+@pytest.mark.parametrize("nx,ou,xr", [(90, 36, 3), (33, 12, 2), (64, 24, 3), (130, 52, 3),
+                                      (200, 40, 3), (161, 45, 2), (256, 30, 4)])      # transform_sum_tile_kernel: even, odd, 16 full tiles
 def test_class_sums_are_bitwise_reproducible(nx, ou, xr):
     """class sums are accumulated in a fixed order -- per batch and (class, parity) the member list is cut into `nrun`
     contiguous runs, each added in particle order (like Util.add_img on the CPU path) by one workgroup of
@@ -675,7 +678,7 @@ def test_class_sums_are_bitwise_reproducible(nx, ou, xr):
     restatement of exactly that association on the aligned images of transform_kernel (the two kernels interpolate bit for
     bit alike: even and odd box sizes, mirrored and straight particles); the path that also returns the aligned images
     (class_sum_kernel, 16 runs per chunk) is pinned the same way"""
-    default_path_only("RALIGN_XSUM")
+    default_path_only("RALIGN_XSUM", "RALIGN_XTILE")
     nref, n = 4, 300
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
@@ -722,7 +725,7 @@ def test_class_sums_are_bitwise_reproducible(nx, ou, xr):
         return want
 
     # transform_sum_kernel: one batch (n < 65536), runs from a zero partial sum even when there is one run only
-    nrun = _xs_runs(n, 2 * nref)
+    nrun = _xs_runs(n, 2 * nref, nx)
     want = np.zeros((nref, 2, nx, nx), np.float32)
     for c in range(nref):
         for par in range(2):

@@ -83,7 +83,8 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
                                                 (131, 58, 3, 64, 0.5),                                   # odd box
                                                 (100, 40, 10, 384, 1.0), (128, 40, 50, 128, 1.0),        # search_pair_kernel: one tile, five tiles
                                                 (101, 37, 7, 96, 0.25), (144, 40, 1, 64, 1.0),           # odd box and reference count; one reference
-                                                (96, 36, 10, 128, 1.0), (112, 36, 24, 96, 0.5)])         # ring buffers grown to hold a tile's 12 spectra
+                                                (96, 36, 10, 128, 1.0), (112, 36, 24, 96, 0.5),          # ring buffers grown to hold a tile's 12 spectra
+                                                (200, 40, 10, 64, 1.0), (192, 56, 6, 48, 1.0)])          # boxes far larger than the rings: cropped LDS image
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     xr = 3
@@ -137,7 +138,8 @@ def test_solo_search_equals_generic_search(monkeypatch, nx, ou, switch):
     eng.close()
 
 
-@pytest.mark.parametrize("nx,ou", [(130, 52), (100, 40)])
+@pytest.mark.parametrize("nx,ou", [(130, 52), (100, 40),
+                                   (200, 40), (256, 36), (192, 56), (161, 45)])      # the LDS image is a crop that follows the particle's centre
 def test_solo_edge_limited_windows_and_reset_rule(nx, ou):
     """accumulated shifts at and beyond the edge of the box: search_range cuts the window, |shift| > mashi resets it
     (test_mref_gpu_align.py:1030-1038); the solo / duo / pair kernels never sample an out-of-window offset"""
