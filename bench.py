@@ -51,6 +51,9 @@ WORKLOADS = {
     "box128": ("128 x 128 box, ou = 60 (maxrin 512)", 128, 60, 3.0, 10, 16384, 3, 2),
     # rings of 256 samples in a box too large for four LDS ring buffers (search_pair_kernel)
     "box100": ("100 x 100 box, ou = 40 (maxrin 256, two ring buffers)", 100, 40, 3.0, 10, 32768, 3, 2),
+    # a box far larger than the rings: the LDS image is a crop around the particle's centre (search_pair_kernel), rot_shift2D +
+    # class sums by output tiles (transform_sum_tile_kernel)
+    "box256": ("256 x 256 box, ou = 36 (cropped LDS image)", 256, 36, 3.0, 10, 8192, 3, 2),
 }
 
 
@@ -436,7 +439,7 @@ def run_workload(args, rank, local, world, dev):
 
 
 # what the default run adds to the headline line: the other BASELINE configs at one GPU's share, a few steps each
-OTHER_WORKLOADS = ("reffree", "mref50", "largebox", "nb00", "box128", "box100")
+OTHER_WORKLOADS = ("reffree", "mref50", "largebox", "nb00", "box128", "box100", "box256")
 
 
 def main():
