@@ -193,12 +193,13 @@ def test_solo_reference_free_and_nomirror(nx, ou):
         eng.close()
 
 
-def test_solo_in_the_iteration_loop():
+@pytest.mark.parametrize("nx,ou", [(130, 52), (176, 40)])      # the second: cropped LDS image, class sums by output tiles
+def test_solo_in_the_iteration_loop(nx, ou):
     """three mref_ali2d iterations of the host driver at the notebook's geometry (search, rot_shift2D + class sums, reference
     update, state round trip through the header values) against the same loop built from oracle calls"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC")
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     from test_gpu_parity import _oracle_mref_loop_step, assert_alpha_equal_to_the_ulp
-    nx, ou, nref, xr, n = 130, 52, 4, 3, 96
+    nref, xr, n = 4, 3, 96
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
     al = MrefAligner(parts, refs, ou, xr, xr, 1.0, preprocess=True, refine=-1)
