@@ -1166,7 +1166,11 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
     e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad;
     e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
-    return setup_fused(e);
+    int rc = setup_fused(e);
+    // the solo / duo / pair kernels keep a crop of the image whose side follows the search range: plan again (a wider range at a
+    // constant offset count, e.g. xr = 1, ts = 0.5 -> xr = 4, ts = 2, would otherwise let taps leave the crop)
+    if (!rc && e->generic && e->solo) rc = setup_solo(e);
+    return rc;
 }
 
 extern "C" int ra_set_references(ra_engine *e, const float *d_refs)

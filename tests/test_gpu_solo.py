@@ -255,3 +255,32 @@ def test_multi_stage_schedule_with_fractional_steps(nx, ou):
             flips = compare_search(al.params(), al.state.cpu().numpy(), params, infos, d)
             _log_flips("%d/%d stage %d it %d" % (nx, ou, stage, it), n, flips)
     al.close()
+
+
+def test_reset_shifts_to_a_wider_range_replans_the_cropped_image():
+    """ra_reset_shifts at a constant offset count but a wider pixel range (xr = 1, ts = 0.5 -> xr = 4, ts = 2: 25 offsets both): the crop
+    of the image the pair kernel keeps in LDS is sized by the range, so the engine plans it again -- results equal those of an engine
+    created with the wide range, and the oracle's"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    nx, ou, nref, n = 176, 40, 3, 48
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 4, 4, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, 4, 4, 2.0, d, nthreads=8)
+    outs = []
+    for first in ((1, 1, 0.5), (4, 4, 2.0)):
+        eng = api.Engine(nx, ou, first[0], first[1], first[2], nref, api.RA_MODE_MREF)
+        assert eng.search_path == SOLO
+        eng.reset_shifts(4, 4, 2.0)
+        assert eng.search_path == SOLO
+        eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+        st, res = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+        eng.sync()
+        outs.append((eng.result_to_numpy(res).copy(), st.cpu().numpy().copy()))
+        eng.close()
+    for f in api.RESULT_DTYPE.names:
+        np.testing.assert_array_equal(outs[0][0][f], outs[1][0][f], err_msg=f)
+    flips = compare_search(outs[0][0], outs[0][1], params, infos, d)
+    _log_flips("pair kernel after reset_shifts to a wider range", n, flips)
