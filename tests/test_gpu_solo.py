@@ -76,6 +76,12 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
     polar_stage_check(128, 50, 2, api.RA_MODE_MREF, n=2, rtol=2e-5)
 
 
+def needs_crop(nx):
+    """boxes the solo / duo / pair kernels reach only because their LDS image is a crop: skipped under RALIGN_CROP=0"""
+    if nx > 150:
+        default_path_only("RALIGN_CROP")
+
+
 @pytest.mark.parametrize("nx,ou,nref,n,sigma", [(130, 52, 50, 160, 0.25), (130, 52, 50, 160, 1.0),       # the reference notebook's geometry
                                                 (128, 60, 10, 384, 0.25), (128, 60, 10, 384, 1.0),
                                                 (128, 60, 7, 96, 1.0),                                   # odd reference count: a half-filled pair
@@ -87,6 +93,7 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
                                                 (200, 40, 10, 64, 1.0), (192, 56, 6, 48, 1.0)])          # boxes far larger than the rings: cropped LDS image
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    needs_crop(nx)
     xr = 3
     refs = synth.make_references(nref, nx, ou)
     parts, truth = synth.make_particles(refs, n, xr, xr, sigma, ou=ou)
@@ -144,6 +151,7 @@ def test_solo_edge_limited_windows_and_reset_rule(nx, ou):
     """accumulated shifts at and beyond the edge of the box: search_range cuts the window, |shift| > mashi resets it
     (test_mref_gpu_align.py:1030-1038); the solo / duo / pair kernels never sample an out-of-window offset"""
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    needs_crop(nx)
     nref, xr, n = 4, 3, 40
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
@@ -199,6 +207,7 @@ def test_solo_in_the_iteration_loop(nx, ou):
     update, state round trip through the header values) against the same loop built from oracle calls"""
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
     from test_gpu_parity import _oracle_mref_loop_step, assert_alpha_equal_to_the_ulp
+    needs_crop(nx)
     nref, xr, n = 4, 3, 96
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
@@ -261,7 +270,7 @@ def test_reset_shifts_to_a_wider_range_replans_the_cropped_image():
     """ra_reset_shifts at a constant offset count but a wider pixel range (xr = 1, ts = 0.5 -> xr = 4, ts = 2: 25 offsets both): the crop
     of the image the pair kernel keeps in LDS is sized by the range, so the engine plans it again -- results equal those of an engine
     created with the wide range, and the oracle's"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP")
     nx, ou, nref, n = 176, 40, 3, 48
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, 4, 4, 0.5, ou=ou)
