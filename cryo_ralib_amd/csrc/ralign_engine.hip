@@ -86,6 +86,8 @@ struct ra_engine {
     float *d_wr = nullptr;
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
+    bool tcrop = false;                 // generic class, but the search runs search_tiled_kernel over a CROP of the image (tcrop_wanted)
+    int crop_S = 0;                     // ... whose side was planned for search shifts of up to this many pixels
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
@@ -185,6 +187,33 @@ static bool duo_wanted(const ra_engine *e)
     return !(getenv("RALIGN_DUO") && atoi(getenv("RALIGN_DUO")) == 0);
 }
 
+typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
+static fused_fn select_tiled(int nh, int sbuf);
+// search_tiled_kernel for an engine of the size-generic class: rings of 256 samples (ou <= 36) in a box so much larger than the rings
+// that the whole image does not fit next to four ring buffers, but a crop around the particle's sampling centre does (crop_plan,
+// ralign_solo.h).  Four offsets per pass with every wave in a ring job instead of the pair kernel's two: 1.6 x its rate.
+// RALIGN_TCROP=0: the pair kernel
+static bool tcrop_wanted(const ra_engine *e)
+{
+    const Geometry &g = e->geo;
+    if (!e->generic || g.maxrin != 256 || g.nring > 4 * RT_NQ || g.numr[2] < 8 || e->cfg.nref > 127) return false;
+    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;
+    if (getenv("RALIGN_TCROP") && atoi(getenv("RALIGN_TCROP")) == 0) return false;
+    if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
+    if (getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) == 0) return false;
+    FusedGeom t{};
+    crop_plan(g, t);
+    if (!t.s_crop) return false;
+    // the job tables and the image stride are laid out for this kernel before its plan is made (build_device_geometry), so the
+    // answer has to be the plan's: the same plan on an upper estimate of the polar part's LDS (tables of 4 offset slots)
+    const int sbuf = (g.lring + 31) / 32 * 32 + 16;
+    const size_t polar = (size_t)t.s_pst * t.s_pst + 4 * (size_t)std::max(sbuf, sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf) + 2 * g.maxrin + 3000;
+    FusedPlanHost tmp;
+    for (int sb : {sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf, sbuf})
+        if (build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
+    return false;
+}
+
 static bool fused_wanted(const ra_engine *e)
 {
     if (e->generic) return false;
@@ -219,12 +248,14 @@ static int build_device_geometry(ra_engine *e)
     // ring-buffer stride.  Kernel pair: == 8 (mod 32), the 4 offsets of an entry hit disjoint banks in the write-out gather.
     // Fused kernel: == 16 (mod 32), the two offsets a 4x4x1 MFMA A operand reads (16 bins x Re/Im each) sit in disjoint
     // halves of the 32 banks (RALIGN_SBUF_PAD overrides: experiments)
-    int sbuf = (g.lring + 31) / 32 * 32 + (getenv("RALIGN_SBUF_PAD") ? atoi(getenv("RALIGN_SBUF_PAD")) : (fused_wanted(e) ? 16 : 8));
+    int sbuf = (g.lring + 31) / 32 * 32 + (getenv("RALIGN_SBUF_PAD") ? atoi(getenv("RALIGN_SBUF_PAD")) : ((fused_wanted(e) || e->tcrop) ? 16 : 8));
     // fused kernel at maxrin 256: pad the stride to the compile-time value of its fixed-stride instantiations when the image
     // and four such buffers (+ 16 KB of tables and records) still fit the LDS (RALIGN_SBUF_FIXED=0: keep the run-time stride)
-    if (fused_wanted(e) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !getenv("RALIGN_SBUF_PAD") &&
+    if ((fused_wanted(e) || e->tcrop) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !getenv("RALIGN_SBUF_PAD") &&
         !(getenv("RALIGN_SBUF_FIXED") && atoi(getenv("RALIGN_SBUF_FIXED")) == 0)) {
-        const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = g.nx + 2 * bd0 + 3;
+        FusedGeom tcr{};
+        if (e->tcrop) crop_plan(g, tcr);
+        const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = e->tcrop ? tcr.s_pst : g.nx + 2 * bd0 + 3;
         if ((size_t)(pst0 * pst0 + 4 * RF_SBUF_FIXED + 3400) * sizeof(float) <= 160 * 1024) sbuf = RF_SBUF_FIXED;
     }
     d.sbuf = sbuf;
@@ -329,7 +360,7 @@ static int build_device_geometry(ra_engine *e)
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
-            const bool mixed = solo || pairj || (nslot == 4 && (fused_wanted(e) || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
+            const bool mixed = solo || pairj || (nslot == 4 && (fused_wanted(e) || e->tcrop || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
             for (int lg = solo ? 9 : 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
                 const int code = lightjobs && n == 512 ? 11 : lightjobs && n == 256 ? 0 :
@@ -381,7 +412,8 @@ static int build_device_geometry(ra_engine *e)
             d.n_job_b = 0;
             const int na = (int)jobs.size();
             if (duo_wanted(e) && !light_only) { make_jobs(1, jobs, inst, instw, true); d.n_job_b = (int)jobs.size() - na; }
-        } else if (pair_wanted(e)) make_jobs(2, jobs, inst, instw, false);
+        } else if (e->tcrop) make_jobs(4, jobs, inst, instw, false);
+        else if (pair_wanted(e)) make_jobs(2, jobs, inst, instw, false);
         if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
             std::vector<int4> perm;
             for (const char *c = po; *c;) {
@@ -398,6 +430,11 @@ static int build_device_geometry(ra_engine *e)
     e->ringw_h = ringw;
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
+    if (e->tcrop) {          // borderless crop (search_tiled_kernel: load_image): rows / columns 0 .. side - 1 + one spare
+        FusedGeom tcr{};
+        crop_plan(g, tcr);
+        d.bd = 0; d.pst = tcr.s_pst;
+    }
     // row stride of the padded LDS image: the lanes of a ring job sit along an arc and across consecutive radii, so
     // bilinear taps step through the image by +-1 column, +-1 row (= pst words) or a diagonal (pst +- 1).  A stride
     // that is a multiple of 32 (96 at nx = 90) puts every vertical neighbour into the same LDS bank; pick the next
@@ -499,12 +536,15 @@ static bool resident_expected(const Geometry &g, const ra_config &cfg, bool gene
         const bool c256 = g.maxrin == 256 && g.nring <= 4 * RP_NQ && !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0) &&
                           !(getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0);
         if (!(c512 || c256) || g.numr[2] < 8 || cfg.nref > 127) return false;
-        int pst = g.nx + 1;
+        // the LDS image is a crop around the particle's centre when the box is larger than the rings need (crop_plan)
+        const int S = (int)std::ceil(std::max(g.nkx, g.nky) * g.step - 1e-6), side = 2 * (S + g.last_ring) + 5;
+        const int cols = (side < g.nx && !(getenv("RALIGN_CROP") && atoi(getenv("RALIGN_CROP")) == 0)) ? side : g.nx;
+        int pst = cols + 1;
         while (!((pst & 1) && ((pst - 1) & 7) && ((pst + 1) & 7))) pst++;
         const int nrp = (cfg.nref + 1) / 2, ntile = (nrp + RS_MAXNH - 1) / RS_MAXNH, nh = (nrp + ntile - 1) / ntile;
         const int sbuf = c256 ? 2 * ((g.lring + 31) / 32 * 32 + 16)
                               : std::max((g.lring + 31) / 32 * 32 + 16, 2 * nh * (2 * (g.maxrin + g.maxrin / 16) + 2));
-        if ((size_t)((g.nx + 1) * pst + sbuf + 4600 + 2 * g.nring + 10 * (g.nring + 16)) * sizeof(float) > 160 * 1024) return false;
+        if ((size_t)((cols + 1) * pst + sbuf + 4600 + 2 * g.nring + 10 * (g.nring + 16)) * sizeof(float) > 160 * 1024) return false;
         size_t quads = 0;
         for (int m = 0; m < g.maxrin / 32; m++) {
             int r0 = 0;
@@ -620,7 +660,6 @@ static ccf_fn select_ccf(int maxrin)
     }
 }
 
-typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
 static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack = false)
 {
     if (nref > RF_MAXREF) return nullptr;
@@ -707,12 +746,20 @@ static int setup_fused(ra_engine *e)
 {
     e->fused = false; e->tiled = false;
     e->fplan.f.on = 0;
-    if (e->generic) return RA_OK;
+    if (e->generic && !e->tcrop) return RA_OK;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if (tiled_wanted(e) && build_tiled_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp) && select_tiled(fp.f.nh, e->dg.sbuf)) {
+    if ((tiled_wanted(e) || e->tcrop) && build_tiled_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp) && select_tiled(fp.f.nh, e->dg.sbuf)) {
         e->tiled = true;
+        if (e->tcrop) {
+            FusedGeom tcr{};
+            crop_plan(g, tcr);
+            fp.f.s_crop = tcr.s_crop; fp.f.s_cropm = tcr.s_cropm;
+        }
+    } else if (e->tcrop) {
+        g_last_error = "search_tiled_kernel over a crop: the plan tcrop_wanted promised does not fit";
+        return RA_ERR_STATE;
     } else {
         if (!select_fused(g.maxrin, e->cfg.nref, 1, 0)) return RA_OK;
         if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
@@ -796,6 +843,7 @@ static int setup_solo(ra_engine *e)
     e->solo = false; e->duo = false; e->pair = false;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
+    if (e->fused) return RA_OK;          // tcrop: search_tiled_kernel over a crop of the image took this engine of the generic class
     if (pair_wanted(e)) {
         // maxrin 256 in a box too large for four ring buffers: two offsets per pass in two (ralign_pair.h)
         if (!build_pair_plan(g, e->cfg.nref, e->dg.n_qtab, e->dg.n_inst, e->dg.n_job, fp)) { fp.f.on = 0; return RA_OK; }
@@ -988,6 +1036,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         return RA_ERR_ARG;
     }
     e->generic = !fits_specialised_kernels(e->geo, *cfg);
+    e->tcrop = tcrop_wanted(e);
+    e->crop_S = (int)std::ceil(std::max(e->geo.nkx, e->geo.nky) * e->geo.step - 1e-6);
     if (e->generic && e->geo.maxrin <= 1024 && !(getenv("RALIGN_QUAD_ALIGN") && atoi(getenv("RALIGN_QUAD_ALIGN")) == 0)) align_ring_quads(e->geo);
     if (e->geo.maxrin > 4096) {
         g_last_error = "rings longer than 4096 samples are not supported";
@@ -1130,7 +1180,7 @@ extern "C" int ra_last_refine_count(ra_engine *e)
     return h;
 }
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
-extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->generic ? 2 : e->fused ? 1 : 0; }
+extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->fused ? 1 : e->generic ? 2 : 0; }
 extern "C" int ra_search_offsets_per_pass(const ra_engine *e) { return !e ? RA_ERR_ARG : !e->solo ? 0 : (e->duo || e->pair) ? 2 : 1; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
@@ -1155,6 +1205,10 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     // a wider window (possible at a constant offset count, e.g. xr=1,ts=0.5 -> xr=4,ts=2) would let taps leave it
     if (!e->generic && (int)std::ceil(std::max(xrng, yrng)) + 2 > e->dg.bd) {
         g_last_error = "reset_shifts: search range exceeds the image border the engine was created with";
+        return RA_ERR_ARG;
+    }
+    if (e->tcrop && (int)std::ceil(std::max(g2.nkx, g2.nky) * g2.step - 1e-6) > e->crop_S) {
+        g_last_error = "reset_shifts: search range exceeds the image crop the engine was created with";
         return RA_ERR_ARG;
     }
     RA_HIP(hipStreamSynchronize(e->stream));

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
         const int m = i / f.gstr, j = i - m * f.gstr;
         goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
     }
-    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);          // (f.s_crop: re-based with every image, load_image)
     int *ifft_done = reinterpret_cast<int *>(red + 6);
     if (tid == 0) *ifft_done = 0;
     int done_target = 0;
@@ -194,6 +194,32 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
     // flight at once (search_fused_kernel: load_image)
     auto load_image = [&](int i) {
         const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
+        if (f.s_crop) {
+            // a box far larger than the rings (engines of the size-generic class): the LDS holds a CROP of f.s_crop rows and columns
+            // whose origin follows the particle's sampling centre (crop_plan, ralign_solo.h) -- NOT clamped to the box: this kernel
+            // samples every offset of the window, and the taps of the offsets search_range excludes (their records are never read)
+            // may lie outside the box, where the crop keeps whatever finite values it held
+            const int pk = particle_of(i);
+            const Window wk = particle_window(g, state[2 * pk], state[2 * pk + 1]);
+            const int ox0 = __builtin_amdgcn_readfirstlane((int)floorf((float)g.cnx + wk.sxi) - 1 - f.s_cropm);
+            const int oy0 = __builtin_amdgcn_readfirstlane((int)floorf((float)g.cnx + wk.syi) - 1 - f.s_cropm);
+#pragma unroll 1
+            for (int y = wave; y < f.s_crop; y += RF_WAVES) {
+                const int sy = oy0 + y;
+                if (sy < 0 || sy >= g.nx) continue;
+                const float *row = src + sy * g.nx + ox0;
+                float *dst = img + y * g.pst;
+#pragma unroll 1
+                for (int c0 = 0; c0 < f.s_crop; c0 += 64) {
+                    const int sx = ox0 + c0 + lane;
+                    if (c0 + lane < f.s_crop && sx >= 0 && sx < g.nx)
+                        __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
+                }
+            }
+            imgb = img - g.pst - 1 - (oy0 * g.pst + ox0);      // 1-based (ix, iy) of the BOX -> img[(iy - 1 - oy0) pst + ix - 1 - ox0]
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
 #pragma unroll 1
         for (int y = wave; y < g.nx; y += RF_WAVES) {
             const float *row = src + y * g.nx;

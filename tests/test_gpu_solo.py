@@ -3,6 +3,8 @@ rings of 512 samples (search_solo_kernel / search_duo_kernel, ralign_solo.h / ra
 reference's own documented run, notebook/00_Multireference_Alignment.ipynb cell 3: 130 x 130, ou = 52, nref = 50) and rings of 256
 samples in boxes of ~96 .. 150 pixels (search_pair_kernel, ralign_pair.h).  Same bars as tests/test_gpu_parity.py: identical integer
 assignments (no tie allowance), CCF peaks within 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -89,7 +91,7 @@ def needs_crop(nx):
                                                 (131, 58, 3, 64, 0.5),                                   # odd box
                                                 (100, 40, 10, 384, 1.0), (128, 40, 50, 128, 1.0),        # search_pair_kernel: one tile, five tiles
                                                 (101, 37, 7, 96, 0.25), (144, 40, 1, 64, 1.0),           # odd box and reference count; one reference
-                                                (96, 36, 10, 128, 1.0), (112, 36, 24, 96, 0.5),          # ring buffers grown to hold a tile's 12 spectra
+                                                (96, 36, 10, 128, 1.0), (112, 36, 24, 96, 0.5),          # search_tiled_kernel on a crop (ou <= 36, 7 and more references)
                                                 (200, 40, 10, 64, 1.0), (192, 56, 6, 48, 1.0)])          # boxes far larger than the rings: cropped LDS image
 def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
@@ -101,7 +103,9 @@ def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     d = np.zeros((n, 2), np.float32)
     params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
-    assert eng.search_path == SOLO
+    # four offsets per pass: the tiled kernel on a crop of the image (unless a switch takes it away: then the pair kernel)
+    tcrop = ou <= 36 and nref >= 7 and not any(os.environ.get(sw) == "0" for sw in ("RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED", "RALIGN_CROP"))
+    assert eng.search_path == (1 if tcrop else SOLO) and bool(eng.search_tiled) == tcrop
     r = eng.result_to_numpy(res)
     flips = compare_search(r, st.cpu().numpy(), params, infos, d)
     _log_flips("solo %d/%d nref=%d sigma=%g" % (nx, ou, nref, sigma), n, flips)
@@ -293,3 +297,82 @@ def test_reset_shifts_to_a_wider_range_replans_the_cropped_image():
         np.testing.assert_array_equal(outs[0][0][f], outs[1][0][f], err_msg=f)
     flips = compare_search(outs[0][0], outs[0][1], params, infos, d)
     _log_flips("pair kernel after reset_shifts to a wider range", n, flips)
+
+
+@pytest.mark.parametrize("nx,ou,nref", [(96, 36, 10), (112, 36, 24)])
+def test_pair_kernel_with_grown_ring_buffers(nx, ou, nref, monkeypatch):
+    """RALIGN_TCROP=0: the geometries search_tiled_kernel takes on a crop of the image go through search_pair_kernel, whose ring
+    buffers grow to hold the 12 spectra of a six-pair tile (at ou = 36 the rings of an offset are shorter than that)"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR")
+    monkeypatch.setenv("RALIGN_TCROP", "0")
+    xr, n = 3, 96
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 1.0, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
+    eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
+    assert eng.search_path == SOLO and eng.search_offsets_per_pass == 2
+    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    _log_flips("pair kernel, grown ring buffers %d/%d nref=%d" % (nx, ou, nref), n, flips)
+    eng.close()
+
+
+@pytest.mark.parametrize("nx,ou,nref,xr,ts", [(256, 36, 10, 3, 1.0), (160, 30, 24, 2, 0.5), (200, 34, 50, 3, 1.0), (141, 36, 7, 3, 1.0)])
+def test_tiled_kernel_on_a_cropped_image(nx, ou, nref, xr, ts):
+    """boxes far larger than rings of 256 samples (engines of the size-generic class): search_tiled_kernel, four offsets per pass, over
+    a crop of the image that follows the particle's centre WITHOUT being clamped to the box (the kernel samples every offset of the
+    window; those search_range excludes read whatever the crop holds there and are never looked at).  Shifts up to and beyond mashi,
+    the dense offset stream with partial last passes, a half-pixel grid, 1 - 5 reference tiles"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP", "RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED")
+    n = 61
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    rng = np.random.default_rng(9)
+    mashi = nx // 2 + 1 - ou - 2
+    d0 = np.zeros((n, 2), np.float32)
+    d0[:24] = rng.integers(-mashi - 2, mashi + 3, size=(24, 2)).astype(np.float32)
+    d0[:4] = [(mashi, mashi), (-mashi, mashi), (mashi + 1, 0), (0, -mashi - 1)]
+    d = d0.copy()
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, ts, d, nthreads=16)
+    os.environ["RALIGN_GRID"] = "7"          # workgroups walk over several particles: passes that hold offsets of two
+    try:
+        eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, ts, state=d0)
+    finally:
+        os.environ.pop("RALIGN_GRID", None)
+    assert eng.search_path == 1 and eng.search_tiled
+    flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    _log_flips("tiled kernel on a crop %d/%d nref=%d ts=%g" % (nx, ou, nref, ts), n, flips)
+    eng.close()
+
+
+def test_tiled_kernel_on_a_crop_follows_reset_shifts():
+    """ra_reset_shifts on an engine whose search runs over a crop of the image: a narrower range keeps the crop (results equal a
+    fresh engine's), a wider one at the same offset count is refused -- the crop was sized for the range of ra_create, like the
+    image border of the 90 x 90 kernels"""
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP", "RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED")
+    nx, ou, nref, n = 176, 36, 10, 40
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 1, 1, 0.5, ou=ou)
+    rg, mask, refs_n, cref = oracle_setup(refs, ou, nx)
+    outs = []
+    for first in ((2, 2, 1.0), (1, 1, 0.5)):
+        eng = api.Engine(nx, ou, first[0], first[1], first[2], nref, api.RA_MODE_MREF)
+        assert eng.search_path == 1 and eng.search_tiled
+        eng.reset_shifts(1, 1, 0.5)
+        eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+        st, res = eng.new_state(n), eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+        eng.sync()
+        outs.append((eng.result_to_numpy(res).copy(), st.cpu().numpy().copy()))
+        if first[0] == 1:
+            with pytest.raises(api.EngineError):
+                eng.reset_shifts(4, 4, 2.0)
+        eng.close()
+    for f in api.RESULT_DTYPE.names:
+        np.testing.assert_array_equal(outs[0][0][f], outs[1][0][f], err_msg=f)
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, 1, 1, 0.5, d, nthreads=8)
+    flips = compare_search(outs[0][0], outs[0][1], params, infos, d)
+    _log_flips("tiled kernel on a crop after reset_shifts", n, flips)
