@@ -189,6 +189,7 @@ static bool duo_wanted(const ra_engine *e)
 
 typedef void (*fused_fn)(DevGeom, FusedGeom, const float *, const float *, int, const float *, int, CandT *, const int *);
 static fused_fn select_tiled(int nh, int sbuf);
+static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack = false, bool crop = false);
 // search_tiled_kernel for an engine of the size-generic class: rings of 256 samples (ou <= 36) in a box so much larger than the rings
 // that the whole image does not fit next to four ring buffers, but a crop around the particle's sampling centre does (crop_plan,
 // ralign_solo.h).  Four offsets per pass with every wave in a ring job instead of the pair kernel's two: 1.6 x its rate.
@@ -200,7 +201,6 @@ static bool tcrop_wanted(const ra_engine *e)
     if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;
     if (getenv("RALIGN_TCROP") && atoi(getenv("RALIGN_TCROP")) == 0) return false;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
-    if (getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) == 0) return false;
     FusedGeom t{};
     crop_plan(g, t);
     if (!t.s_crop) return false;
@@ -209,8 +209,14 @@ static bool tcrop_wanted(const ra_engine *e)
     const int sbuf = (g.lring + 31) / 32 * 32 + 16;
     const size_t polar = (size_t)t.s_pst * t.s_pst + 4 * (size_t)std::max(sbuf, sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf) + 2 * g.maxrin + 3000;
     FusedPlanHost tmp;
-    for (int sb : {sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf, sbuf})
-        if (build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
+    // the kernels' division of the reference counts is that of the 90 x 90 engines: search_fused_kernel up to RT_MINREF - 1
+    // references, search_tiled_kernel from there on (RALIGN_TILED=1: from 7 on, the fewest its tile sizes are instantiated for)
+    const bool force = getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) != 0, no_tiled = getenv("RALIGN_TILED") && !force;
+    for (int sb : {sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf, sbuf}) {
+        if (!no_tiled && (e->cfg.nref >= RT_MINREF || force) && build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
+        if (e->cfg.nref <= RF_MAXREF && build_fused_plan(g, e->cfg.nref, sb, polar, tmp) && select_fused(g.maxrin, e->cfg.nref, tmp.f.nzr, sb, false, true)) return true;
+        if (!no_tiled && build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
+    }
     return false;
 }
 
@@ -660,11 +666,20 @@ static ccf_fn select_ccf(int maxrin)
     }
 }
 
-static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack = false)
+static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack, bool crop)
 {
     if (nref > RF_MAXREF) return nullptr;
     const int nrp = (nref + 1) / 2;
     const bool one = nzr == 1;      // one store / inverse-FFT round per pass
+    if (crop) {                     // the image in LDS is a crop (tcrop_wanted): run-time ring-buffer stride only
+        if (maxrin != 256 || (pack && !one)) return nullptr;
+        switch ((nrp + 1) / 2) {
+        case 1: return pack ? search_fused_kernel<256, 1, true, 0, true, true> : one ? search_fused_kernel<256, 1, true, 0, false, true> : search_fused_kernel<256, 1, false, 0, false, true>;
+        case 2: return pack ? search_fused_kernel<256, 2, true, 0, true, true> : one ? search_fused_kernel<256, 2, true, 0, false, true> : search_fused_kernel<256, 2, false, 0, false, true>;
+        case 3: return pack ? search_fused_kernel<256, 3, true, 0, true, true> : one ? search_fused_kernel<256, 3, true, 0, false, true> : search_fused_kernel<256, 3, false, 0, false, true>;
+        default: return pack ? search_fused_kernel<256, 4, true, 0, true, true> : one ? search_fused_kernel<256, 4, true, 0, false, true> : search_fused_kernel<256, 4, false, 0, false, true>;
+        }
+    }
     if (pack) {                     // dense offset stream over the workgroup's particles (maxrin 256, one round per pass)
         if (maxrin != 256 || !one) return nullptr;
         if (sbuf == RF_SBUF_FIXED)
@@ -737,7 +752,7 @@ static bool pack_ok(const ra_engine *e)
 {
     if (!e->fused || e->tiled || (getenv("RALIGN_PACK") && atoi(getenv("RALIGN_PACK")) == 0)) return false;
     if (e->geo.nshift % 4 == 0 || e->geo.nshift < 4) return false;      // (a pass holds the offsets of at most two particles)
-    return select_fused(e->geo.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, true) != nullptr;
+    return select_fused(e->geo.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, true, e->tcrop) != nullptr;
 }
 
 // plan of the particle-resident search kernel (ralign_fused.h) and its tables.  It covers every search window of a
@@ -750,19 +765,21 @@ static int setup_fused(ra_engine *e)
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return RA_OK;
     const Geometry &g = e->geo;
     FusedPlanHost &fp = e->fplan;
-    if ((tiled_wanted(e) || e->tcrop) && build_tiled_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp) && select_tiled(fp.f.nh, e->dg.sbuf)) {
-        e->tiled = true;
-        if (e->tcrop) {
-            FusedGeom tcr{};
-            crop_plan(g, tcr);
-            fp.f.s_crop = tcr.s_crop; fp.f.s_cropm = tcr.s_cropm;
-        }
-    } else if (e->tcrop) {
-        g_last_error = "search_tiled_kernel over a crop: the plan tcrop_wanted promised does not fit";
+    const bool force_tiled = getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) != 0, no_tiled = getenv("RALIGN_TILED") && !force_tiled;
+    const bool want_tiled = e->tcrop ? (!no_tiled && (e->cfg.nref >= RT_MINREF || force_tiled)) : tiled_wanted(e);
+    auto plan_tiled = [&]() { return build_tiled_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp) && select_tiled(fp.f.nh, e->dg.sbuf); };
+    auto plan_fused = [&]() { return select_fused(g.maxrin, e->cfg.nref, 1, 0, false, e->tcrop) && build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp); };
+    if (want_tiled && plan_tiled()) e->tiled = true;
+    else if (plan_fused()) e->tiled = false;
+    else if (e->tcrop && !no_tiled && plan_tiled()) e->tiled = true;
+    else if (e->tcrop) {
+        g_last_error = "particle-resident search over a crop: the plan tcrop_wanted promised does not fit";
         return RA_ERR_STATE;
-    } else {
-        if (!select_fused(g.maxrin, e->cfg.nref, 1, 0)) return RA_OK;
-        if (!build_fused_plan(g, e->cfg.nref, e->dg.sbuf, e->lds_polar / sizeof(float), fp)) return RA_OK;
+    } else return RA_OK;
+    if (e->tcrop) {
+        FusedGeom tcr{};
+        crop_plan(g, tcr);
+        fp.f.s_crop = tcr.s_crop; fp.f.s_cropm = tcr.s_cropm;
     }
     int rc;
     if ((rc = grow_upload(e, &e->d_fbsrc, &e->f_cap_b, fp.bsrc))) return rc;
@@ -770,7 +787,7 @@ static int setup_fused(ra_engine *e)
     if (!e->d_gcdc && (rc = dev_alloc(e, &e->d_gcdc, (size_t)e->cfg.nref, true))) return rc;
     fp.f.bsrc = e->d_fbsrc; fp.f.cdc_w = e->d_gcdc;
     for (int pk = 0; pk < (e->tiled ? 1 : 2); pk++) {
-        const fused_fn fk = e->tiled ? select_tiled(fp.f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf, pk != 0);
+        const fused_fn fk = e->tiled ? select_tiled(fp.f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, fp.f.nzr, e->dg.sbuf, pk != 0, e->tcrop);
         if (!fk) continue;
         hipError_t he = hipFuncSetAttribute((const void *)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
         if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(fused): ") + hipGetErrorString(he); return RA_ERR_HIP; }
@@ -1391,7 +1408,7 @@ extern "C" int ra_state_from_params_dev(ra_engine *e, const ra_result *d_result,
 extern "C" int ra_set_class_references(ra_engine *e, const float *d_refs, int ncls)
 {
     if (!e || !d_refs || ncls <= 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    if (!e->fused || e->tiled || e->cfg.nref != 1 || e->cfg.mode != RA_MODE_REFFREE) { g_last_error = "class-resident launch needs the fused kernel with one reference"; return RA_ERR_STATE; }
+    if (!e->fused || e->tiled || e->generic || e->cfg.nref != 1 || e->cfg.mode != RA_MODE_REFFREE) { g_last_error = "class-resident launch needs the fused kernel with one reference (and a box its reference preparation holds in LDS)"; return RA_ERR_STATE; }
     const FusedGeom f = e->fplan.f;
     int rc;
     if (ncls > e->cls_cap) {
@@ -1429,7 +1446,7 @@ extern "C" int ra_align_classes(ra_engine *e, const float *d_particles, int n, f
     if (!e || n < 0) { g_last_error = "null argument"; return RA_ERR_ARG; }
     if (n == 0) return RA_OK;
     if (!d_particles || !d_state || !d_result || !d_cls) { g_last_error = "null argument"; return RA_ERR_ARG; }
-    if (!e->fused || e->tiled || e->cfg.nref != 1 || e->cls_ready <= 0) { g_last_error = "ra_set_class_references has not been called"; return RA_ERR_STATE; }
+    if (!e->fused || e->tiled || e->generic || e->cfg.nref != 1 || e->cls_ready <= 0) { g_last_error = "ra_set_class_references has not been called"; return RA_ERR_STATE; }
     const Geometry &g = e->geo;
     const int npix = g.nx * g.nx;
     const FusedGeom f = e->fplan.f;
@@ -1497,7 +1514,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         FusedGeom f = e->fplan.f;
         // dense offset stream: a template parameter of search_fused_kernel, a run-time flag of search_tiled_kernel (RALIGN_PACK=0: off)
         f.pack = e->tiled && g.nshift % 4 != 0 && g.nshift >= 4 && !(getenv("RALIGN_PACK") && atoi(getenv("RALIGN_PACK")) == 0);
-        fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, pack_ok(e));
+        fused_fn fk = e->tiled ? select_tiled(f.nh, e->dg.sbuf) : select_fused(g.maxrin, e->cfg.nref, e->fplan.f.nzr, e->dg.sbuf, pack_ok(e), e->tcrop);
         const int rch = resident_batch(e, n);
         {
             int rcw = ensure_resident_ws(e, rch);

@@ -404,7 +404,9 @@ struct PassSync {
 // read (ds_read2st64_b32: both offset pairs in one instruction): 4 instead of 8 address and LDS instructions per ring quad.
 #define RF_SBUF_FIXED 6432       // >= the stride at ou = 36 (6416); 8 x 6432 bytes is a multiple of 256
 // PACK: the offsets of consecutive particles of a workgroup fill the passes without padding (see the pass loop)
-template <int N, int NRPW, bool ONE, int SB, bool PACK = false>
+// CROP: the LDS image is a crop around the particle's sampling centre (engines of the size-generic class, tcrop_wanted); a template
+// parameter because the run-time branch in load_image cost the 90 x 90 instantiations 0.7 % (two more registers, nine more spilled scalars)
+template <int N, int NRPW, bool ONE, int SB, bool PACK = false, bool CROP = false>
 __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, FusedGeom f, const float *__restrict__ particles,
                                                                   const float *__restrict__ state, int n,
                                                                   const float *__restrict__ Bf0, int nref,
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
         const int m = i / f.gstr, j = i - m * f.gstr;
         goff_s[i] = 4 * f.roff[min(f.grp_ring0[m] + j, g.nring - 1)];
     }
-    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);
+    const float *imgb = img + (g.bd - 1) * g.pst + (g.bd - 1);          // (f.s_crop: re-based with every image, load_image)
     int *ifft_done = reinterpret_cast<int *>(red + 6);      // arrival counter of the inverse-FFT phases (PassSync)
     if (tid == 0) *ifft_done = 0;
     int done_target = 0;
@@ -480,6 +482,30 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
     // after the other.
     auto load_image = [&](int i) {
         const float *src = particles + (size_t)particle_of(i) * g.nx * g.nx;
+        if constexpr (CROP) {
+            // a box far larger than the rings (engines of the size-generic class, tcrop_wanted): the LDS holds a CROP of f.s_crop rows
+            // and columns whose origin follows the particle's sampling centre, not clamped to the box (search_tiled_kernel: load_image)
+            const int pk = particle_of(i);
+            const Window wk = particle_window(g, state[2 * pk], state[2 * pk + 1]);
+            const int ox0 = __builtin_amdgcn_readfirstlane((int)floorf((float)g.cnx + wk.sxi) - 1 - f.s_cropm);
+            const int oy0 = __builtin_amdgcn_readfirstlane((int)floorf((float)g.cnx + wk.syi) - 1 - f.s_cropm);
+#pragma unroll 1
+            for (int y = wave; y < f.s_crop; y += RF_WAVES) {
+                const int sy = oy0 + y;
+                if (sy < 0 || sy >= g.nx) continue;
+                const float *row = src + sy * g.nx + ox0;
+                float *dst = img + y * g.pst;
+#pragma unroll 1
+                for (int c0 = 0; c0 < f.s_crop; c0 += 64) {
+                    const int sx = ox0 + c0 + lane;
+                    if (c0 + lane < f.s_crop && sx >= 0 && sx < g.nx)
+                        __builtin_amdgcn_global_load_lds(row + c0 + lane, (__attribute__((address_space(3))) void *)(dst + c0), 4, 0, 0);
+                }
+            }
+            imgb = img - g.pst - 1 - (oy0 * g.pst + ox0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         // global -> LDS without a stop in registers (global_load_lds_dword: lane l of a request writes LDS dword base + l, i.e. a
         // piece of 64 pixels of one image row).  A rolled loop: the requests carry no registers, so nothing in it waits, and the
         // kernel's code stays small -- unrolled over 8 rows at both call sites it grew by 3.9 KB and every pass slowed down by 4 %.

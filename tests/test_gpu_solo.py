@@ -78,6 +78,13 @@ def test_generic_polar_stage_at_maxrin_512_stays_covered(monkeypatch):
     polar_stage_check(128, 50, 2, api.RA_MODE_MREF, n=2, rtol=2e-5)
 
 
+def crop4_expected(ou, nref):
+    """engines of the size-generic class whose rings end at 256 samples and fit four ring buffers next to a CROP of the image run the
+    kernels of the 90 x 90 boxes (search_fused_kernel up to 14 references, search_tiled_kernel beyond) instead of the pair kernel"""
+    off = any(os.environ.get(sw) == "0" for sw in ("RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_CROP")) or (nref >= 15 and os.environ.get("RALIGN_TILED") == "0")
+    return ou <= 36 and not off
+
+
 def needs_crop(nx):
     """boxes the solo / duo / pair kernels reach only because their LDS image is a crop: skipped under RALIGN_CROP=0"""
     if nx > 150:
@@ -103,9 +110,9 @@ def test_solo_search_against_oracle(nx, ou, nref, n, sigma):
     d = np.zeros((n, 2), np.float32)
     params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=16)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0)
-    # four offsets per pass: the tiled kernel on a crop of the image (unless a switch takes it away: then the pair kernel)
-    tcrop = ou <= 36 and nref >= 7 and not any(os.environ.get(sw) == "0" for sw in ("RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED", "RALIGN_CROP"))
-    assert eng.search_path == (1 if tcrop else SOLO) and bool(eng.search_tiled) == tcrop
+    # four offsets per pass: the fused / tiled kernel on a crop of the image (unless a switch takes it away: then the pair kernel)
+    tcrop = crop4_expected(ou, nref)
+    assert eng.search_path == (1 if tcrop else SOLO) and bool(eng.search_tiled) == (tcrop and nref >= 15)
     r = eng.result_to_numpy(res)
     flips = compare_search(r, st.cpu().numpy(), params, infos, d)
     _log_flips("solo %d/%d nref=%d sigma=%g" % (nx, ou, nref, sigma), n, flips)
@@ -167,7 +174,7 @@ def test_solo_edge_limited_windows_and_reset_rule(nx, ou):
     d = d0.copy()
     params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
     eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, 1.0, state=d0)
-    assert eng.search_path == SOLO
+    assert eng.search_path == (1 if (nx > 150 and crop4_expected(ou, nref)) else SOLO)
     flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     _log_flips("solo edge-limited windows", n, flips)
     eng.close()
@@ -318,10 +325,11 @@ def test_pair_kernel_with_grown_ring_buffers(nx, ou, nref, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("nx,ou,nref,xr,ts", [(256, 36, 10, 3, 1.0), (160, 30, 24, 2, 0.5), (200, 34, 50, 3, 1.0), (141, 36, 7, 3, 1.0)])
+@pytest.mark.parametrize("nx,ou,nref,xr,ts", [(256, 36, 10, 3, 1.0), (160, 30, 24, 2, 0.5), (200, 34, 50, 3, 1.0), (141, 36, 7, 3, 1.0),
+                                              (176, 33, 2, 3, 1.0), (256, 30, 14, 2, 0.5)])
 def test_tiled_kernel_on_a_cropped_image(nx, ou, nref, xr, ts):
-    """boxes far larger than rings of 256 samples (engines of the size-generic class): search_tiled_kernel, four offsets per pass, over
-    a crop of the image that follows the particle's centre WITHOUT being clamped to the box (the kernel samples every offset of the
+    """boxes far larger than rings of 256 samples (engines of the size-generic class): search_fused_kernel (up to 14 references) /
+    search_tiled_kernel, four offsets per pass, over a crop of the image that follows the particle's centre WITHOUT being clamped to the box (the kernel samples every offset of the
     window; those search_range excludes read whatever the crop holds there and are never looked at).  Shifts up to and beyond mashi,
     the dense offset stream with partial last passes, a half-pixel grid, 1 - 5 reference tiles"""
     default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP", "RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED")
@@ -341,9 +349,9 @@ def test_tiled_kernel_on_a_cropped_image(nx, ou, nref, xr, ts):
         eng, tp, st, res = run_engine(parts, refs_n, ou, xr, xr, ts, state=d0)
     finally:
         os.environ.pop("RALIGN_GRID", None)
-    assert eng.search_path == 1 and eng.search_tiled
+    assert eng.search_path == 1 and bool(eng.search_tiled) == (nref >= 15)
     flips = compare_search(eng.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
-    _log_flips("tiled kernel on a crop %d/%d nref=%d ts=%g" % (nx, ou, nref, ts), n, flips)
+    _log_flips("fused / tiled kernel on a crop %d/%d nref=%d ts=%g" % (nx, ou, nref, ts), n, flips)
     eng.close()
 
 
@@ -359,7 +367,7 @@ def test_tiled_kernel_on_a_crop_follows_reset_shifts():
     outs = []
     for first in ((2, 2, 1.0), (1, 1, 0.5)):
         eng = api.Engine(nx, ou, first[0], first[1], first[2], nref, api.RA_MODE_MREF)
-        assert eng.search_path == 1 and eng.search_tiled
+        assert eng.search_path == 1
         eng.reset_shifts(1, 1, 0.5)
         eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
         st, res = eng.new_state(n), eng.new_result(n)
