@@ -197,7 +197,8 @@ static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack 
 static bool tcrop_wanted(const ra_engine *e)
 {
     const Geometry &g = e->geo;
-    if (!e->generic || g.maxrin != 256 || g.nring > 4 * RT_NQ || g.numr[2] < 8 || e->cfg.nref > 127) return false;
+    // (search_tiled_kernel holds slices of at most 36 rings, search_fused_kernel reads its operand from the ring buffers: up to 64)
+    if (!e->generic || g.maxrin != 256 || g.nring > 64 || g.numr[2] < 8 || e->cfg.nref > 127) return false;
     if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;
     if (getenv("RALIGN_TCROP") && atoi(getenv("RALIGN_TCROP")) == 0) return false;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;

@@ -82,7 +82,7 @@ def crop4_expected(ou, nref):
     """engines of the size-generic class whose rings end at 256 samples and fit four ring buffers next to a CROP of the image run the
     kernels of the 90 x 90 boxes (search_fused_kernel up to 14 references, search_tiled_kernel beyond) instead of the pair kernel"""
     off = any(os.environ.get(sw) == "0" for sw in ("RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_CROP")) or (nref >= 15 and os.environ.get("RALIGN_TILED") == "0")
-    return ou <= 36 and not off
+    return ou <= 37 and not off          # (ou = 37: 37 rings, the fused kernel only -- it fits up to there at xr = 3)
 
 
 def needs_crop(nx):
