@@ -1754,7 +1754,8 @@ extern "C" int ra_transform_accumulate(ra_engine *e, const float *d_particles, i
     const int nx = e->geo.nx, npix = nx * nx;
     if (!d_sums || e->atomic_sums) {
         if (e->xf_generic)
-            hipLaunchKernelGGL(transform_generic_kernel, dim3(n, 8), dim3(256), 0, e->stream, nx, d_particles, n, index0,
+            // (a handful of images -- the references of an update step -- are cut into more row blocks: 10 images x 8 blocks left the GPU idle)
+            hipLaunchKernelGGL(transform_generic_kernel, dim3(n, std::max(8, std::min((npix + 255) / 256, (2048 + n - 1) / n))), dim3(256), 0, e->stream, nx, d_particles, n, index0,
                                d_result, d_aligned, d_sums, d_counts);
         else
             hipLaunchKernelGGL(transform_kernel, dim3(n), dim3(RA_XF_THREADS), e->lds_xf, e->stream, nx, d_particles, n, index0,
