@@ -141,9 +141,11 @@ int  ra_set_stream(ra_engine *e, void *hip_stream);
 int  ra_num_shifts(const ra_engine *e);
 int  ra_maxrin(const ra_engine *e);
 int  ra_lcirc(const ra_engine *e);
-/* which kernels ra_align runs for the current geometry and window: 1 = particle-resident fused search kernel,
- * 0 = polar + contraction kernel pair, 2 = size-generic kernels (large boxes), 3 = particle-resident search for rings of
- * 512 samples (ou = 41 .. ~62: one ring buffer next to the image; search_solo_kernel / search_duo_kernel) */
+/* which kernels ra_align runs for the current geometry and window: 1 = particle-resident fused / tiled search kernel (four
+ * offsets per pass: rings of up to 256 samples and at most 36 - 37 rings, in any box -- beyond ~93 pixels over a crop of the
+ * image that follows the particle's centre), 0 = polar + contraction kernel pair, 2 = size-generic kernels (rings beyond 512
+ * samples, more than 64 rings), 3 = particle-resident search with one or two ring buffers next to the image (search_pair_kernel:
+ * ou = 37 .. 40; search_solo_kernel / search_duo_kernel: rings of 512 samples, ou = 41 .. ~62) */
 int  ra_search_path(const ra_engine *e);
 /* with ra_search_path == 3: search offsets per pass, 2 (search_duo_kernel, the default) or 1 (search_solo_kernel); 0 otherwise */
 int  ra_search_offsets_per_pass(const ra_engine *e);
@@ -199,8 +201,9 @@ int  ra_state_from_params_dev(ra_engine *e, const ra_result *d_result, int n, co
 /* class-resident alignment (the ISAC mode behind ref_free_alignment_2D, cuda/gpu_aln_noref.cu:559-782): every particle
  * against the average of its own class, all classes in one launch.  ra_set_class_references prepares ncls references
  * (d_refs [ncls][nx][nx] device); ra_align_classes aligns particle i to reference d_cls[i] (device, [n]); results and
- * state as ra_align.  Needs RA_MODE_REFFREE with nref = 1 on a geometry the fused search kernel covers
- * (ra_search_path == 1); RA_ERR_STATE otherwise -- loop over the classes with ra_set_references / ra_align then. */
+ * state as ra_align.  Needs RA_MODE_REFFREE with nref = 1 on a geometry the fused search kernel covers with the whole
+ * image in LDS (ra_search_path == 1 and a box of up to ~93 pixels at ou = 36); RA_ERR_STATE otherwise -- loop over the
+ * classes with ra_set_references / ra_align then. */
 int  ra_set_class_references(ra_engine *e, const float *d_refs, int ncls);
 int  ra_align_classes(ra_engine *e, const float *d_particles, int n, float *d_state,
                       ra_result *d_result, const int *d_cls);
