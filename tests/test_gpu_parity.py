@@ -1275,8 +1275,9 @@ def test_transform_kernel_matches_the_reference_tree_bit_for_bit(golden_dir):
         eng.close()
 
 
+@pytest.mark.parametrize("nx,ou", [(64, 25), (128, 30)], ids=["box64", "box128-crop"])
 @pytest.mark.parametrize("fused", ["1", "0"], ids=["one-launch", "class-by-class"])
-def test_class_resident_alignment_isac_surface(fused, monkeypatch):
+def test_class_resident_alignment_isac_surface(fused, nx, ou, monkeypatch):
     """ref_free_alignment_2D* (cuda/gpu_aln_noref.h:94-109): every particle against the average of its own class
     with ormq rules, rot_shift2D, class means rebuilt on the device, tangent filter of the averages; all classes in one
     launch of the fused search kernel (ra_set_class_references / ra_align_classes) and, with the fused kernel switched
@@ -1284,7 +1285,9 @@ def test_class_resident_alignment_isac_surface(fused, monkeypatch):
     default_path_only()
     from oracle import refine_oracle as ro
     monkeypatch.setenv("RALIGN_FUSED", fused)
-    nx, ou, xr, ncls = 64, 25, 2, 5
+    # (box128-crop: an engine of the size-generic class -- the search runs the fused kernel over a crop of the image, or the pair
+    # kernel with the fused kernel switched off; the class-resident launch is not available there and the library walks the classes)
+    xr, ncls = 2, 5
     sizes = [17, 30, 1, 24, 40]
     refs = synth.make_references(ncls, nx, ou)
     parts, cids = [], []
