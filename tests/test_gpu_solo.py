@@ -180,7 +180,7 @@ def test_solo_edge_limited_windows_and_reset_rule(nx, ou):
     eng.close()
 
 
-@pytest.mark.parametrize("nx,ou", [(128, 56), (112, 40)])
+@pytest.mark.parametrize("nx,ou", [(128, 56), (112, 40), (144, 32)])      # duo, pair, fused kernel on a crop
 def test_solo_reference_free_and_nomirror(nx, ou):
     """ormq's rules (no Normalize_ring, one reference) and its nomirror form (Crosrng_ns) at maxrin 512 (duo kernel) and at
     maxrin 256 in a large box (pair kernel)"""
@@ -198,7 +198,7 @@ def test_solo_reference_free_and_nomirror(nx, ou):
         finally:
             orc.set_nomirror(False)
         eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE)
-        assert eng.search_path == SOLO
+        assert eng.search_path == (1 if crop4_expected(ou, 1) else SOLO)
         eng.set_nomirror(nomirror)
         eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
         st, res = eng.new_state(n), eng.new_result(n)
