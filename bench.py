@@ -41,19 +41,19 @@ WORKLOADS = {
     # name: (BASELINE.json config, nx, ou, xr, nref, particles per GPU, default steps, warmup)
     "mref": ("configs[1]", 90, 36, 3.0, 10, 50000, 6, 1),
     "reffree": ("configs[2]", 90, 36, 3.0, 1, 50000, 10, 1),
-    "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 8192, 2, 1),
-    "mref50": ("configs[3], one GPU's share", 90, 36, 3.0, 50, 125000, 3, 1),
+    "largebox": ("configs[4] geometry, one GPU's share", 256, 120, 5.0, 100, 8192, 3, 1),
+    "mref50": ("configs[3], one GPU's share", 90, 36, 3.0, 50, 125000, 4, 1),
     # rings of 512 samples (search_solo_kernel): the reference's own documented run (notebook/00_Multireference_Alignment.ipynb
     # cell 3: 5000 x 130 x 130, nref = 50, ou = 52) and a 128 x 128 box at the largest radius
     # (two warm-up steps: in a process that ran another workload before, one of the first two iterations of these short runs takes
     # 50 - 90 ms longer -- the driver unmapping the gigabytes the previous workload freed --, scripts/dev/two_workloads2.py)
-    "nb00": ("reference notebook/00 cell 3 geometry", 130, 52, 3.0, 50, 5000, 3, 2),
-    "box128": ("128 x 128 box, ou = 60 (maxrin 512)", 128, 60, 3.0, 10, 16384, 3, 2),
+    "nb00": ("reference notebook/00 cell 3 geometry", 130, 52, 3.0, 50, 5000, 6, 2),
+    "box128": ("128 x 128 box, ou = 60 (maxrin 512)", 128, 60, 3.0, 10, 16384, 6, 2),
     # rings of 256 samples in a box too large for four LDS ring buffers (search_pair_kernel)
-    "box100": ("100 x 100 box, ou = 40 (maxrin 256, two ring buffers)", 100, 40, 3.0, 10, 32768, 3, 2),
+    "box100": ("100 x 100 box, ou = 40 (maxrin 256, two ring buffers)", 100, 40, 3.0, 10, 32768, 6, 2),
     # a box far larger than the rings: the LDS image is a crop around the particle's centre (search_pair_kernel), rot_shift2D +
     # class sums by output tiles (transform_sum_tile_kernel)
-    "box256": ("256 x 256 box, ou = 36 (cropped LDS image)", 256, 36, 3.0, 10, 8192, 3, 2),
+    "box256": ("256 x 256 box, ou = 36 (cropped LDS image)", 256, 36, 3.0, 10, 8192, 6, 2),
 }
 
 
