@@ -88,6 +88,7 @@ struct ra_engine {
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
     bool tcrop = false;                 // generic class, but the search runs search_tiled_kernel over a CROP of the image (tcrop_wanted)
     int crop_S = 0;                     // ... whose side was planned for search shifts of up to this many pixels
+    int crop_pst = 0;                   // ... and its row stride in LDS (tcrop_wanted)
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
@@ -194,7 +195,7 @@ static fused_fn select_fused(int maxrin, int nref, int nzr, int sbuf, bool pack 
 // that the whole image does not fit next to four ring buffers, but a crop around the particle's sampling centre does (crop_plan,
 // ralign_solo.h).  Four offsets per pass with every wave in a ring job instead of the pair kernel's two: 1.6 x its rate.
 // RALIGN_TCROP=0: the pair kernel
-static bool tcrop_wanted(const ra_engine *e)
+static bool tcrop_wanted(ra_engine *e)
 {
     const Geometry &g = e->geo;
     // (search_tiled_kernel holds slices of at most 36 rings, search_fused_kernel reads its operand from the ring buffers: up to 64)
@@ -208,8 +209,15 @@ static bool tcrop_wanted(const ra_engine *e)
     // the job tables and the image stride are laid out for this kernel before its plan is made (build_device_geometry), so the
     // answer has to be the plan's: the same plan on an upper estimate of the polar part's LDS (tables of 4 offset slots)
     const int sbuf = (g.lring + 31) / 32 * 32 + 16;
-    const size_t polar = (size_t)t.s_pst * t.s_pst + 4 * (size_t)std::max(sbuf, sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf) + 2 * g.maxrin + 3000;
     FusedPlanHost tmp;
+    // row stride of the crop: 101 words -- the stride of the 90 x 90 headline geometry, which the order of the ring jobs' instances was
+    // tuned on -- when the crop is narrower and the plan still fits, else the narrowest conflict-poor one (crop_plan).  Measured
+    // (search launch per 8192 / 16 384 particles): ou = 36 / 256 x 256: 5.40 ms at 91, 5.35 at 93, 5.39 - 5.41 at 95 - 99, 5.23 at 101;
+    // ou = 30 / 160 x 160: 9.56 ms at 73, 9.28 - 9.54 at 75 - 99, 9.35 at 101
+    const int pst_min = t.s_pst;
+    for (int pst : {pst_min < 101 && !(getenv("RALIGN_CROP_PST101") && atoi(getenv("RALIGN_CROP_PST101")) == 0) ? 101 : pst_min, pst_min}) {
+    e->crop_pst = pst;
+    const size_t polar = (size_t)pst * pst + 4 * (size_t)std::max(sbuf, sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf) + 2 * g.maxrin + 3000;
     // the kernels' division of the reference counts is that of the 90 x 90 engines: search_fused_kernel up to RT_MINREF - 1
     // references, search_tiled_kernel from there on (RALIGN_TILED=1: from 7 on, the fewest its tile sizes are instantiated for)
     const bool force = getenv("RALIGN_TILED") && atoi(getenv("RALIGN_TILED")) != 0, no_tiled = getenv("RALIGN_TILED") && !force;
@@ -217,6 +225,7 @@ static bool tcrop_wanted(const ra_engine *e)
         if (!no_tiled && (e->cfg.nref >= RT_MINREF || force) && build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
         if (e->cfg.nref <= RF_MAXREF && build_fused_plan(g, e->cfg.nref, sb, polar, tmp) && select_fused(g.maxrin, e->cfg.nref, tmp.f.nzr, sb, false, true)) return true;
         if (!no_tiled && build_tiled_plan(g, e->cfg.nref, sb, polar, tmp) && select_tiled(tmp.f.nh, sb)) return true;
+    }
     }
     return false;
 }
@@ -260,9 +269,7 @@ static int build_device_geometry(ra_engine *e)
     // and four such buffers (+ 16 KB of tables and records) still fit the LDS (RALIGN_SBUF_FIXED=0: keep the run-time stride)
     if ((fused_wanted(e) || e->tcrop) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !getenv("RALIGN_SBUF_PAD") &&
         !(getenv("RALIGN_SBUF_FIXED") && atoi(getenv("RALIGN_SBUF_FIXED")) == 0)) {
-        FusedGeom tcr{};
-        if (e->tcrop) crop_plan(g, tcr);
-        const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = e->tcrop ? tcr.s_pst : g.nx + 2 * bd0 + 3;
+        const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = e->tcrop ? e->crop_pst : g.nx + 2 * bd0 + 3;
         if ((size_t)(pst0 * pst0 + 4 * RF_SBUF_FIXED + 3400) * sizeof(float) <= 160 * 1024) sbuf = RF_SBUF_FIXED;
     }
     d.sbuf = sbuf;
@@ -438,9 +445,7 @@ static int build_device_geometry(ra_engine *e)
     d.bd = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2;
     d.pst = g.nx + 2 * d.bd;
     if (e->tcrop) {          // borderless crop (search_tiled_kernel: load_image): rows / columns 0 .. side - 1 + one spare
-        FusedGeom tcr{};
-        crop_plan(g, tcr);
-        d.bd = 0; d.pst = tcr.s_pst;
+        d.bd = 0; d.pst = e->crop_pst;
     }
     // row stride of the padded LDS image: the lanes of a ring job sit along an arc and across consecutive radii, so
     // bilinear taps step through the image by +-1 column, +-1 row (= pst words) or a diagonal (pst +- 1).  A stride
