@@ -60,17 +60,31 @@ inline bool build_pair_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     crop_plan(g, f);
     // references per tile: 2 offsets x RZ spectra in the two ring buffers, which grow past the rings' own length when the LDS has the
     // room (ou 36: 12 spectra need 6552 floats, the rings 5.7 k -- without the slack 96 x 96 / ou 36 fell back to the generic kernels)
+    // row stride of a crop: 101 words (the 90 x 90 headline geometry's, as for the engines that run its kernels over a crop: 35.9 ->
+    // 35.3 ms per 32 768 at 100 x 100 / ou = 40) when the plan fits with it, else the narrowest conflict-poor one
+    const int pst_narrow = f.s_pst;
+    const bool try_wide = f.s_crop && f.s_pst < 101 && !(getenv("RALIGN_CROP_PST101") && atoi(getenv("RALIGN_CROP_PST101")) == 0);
     bool found = false;
-    for (int nhmax = RP_MAXRZ / 2; nhmax >= 1 && !found; nhmax--) {
-        f.ntile = (f.nrp + nhmax - 1) / nhmax;
-        f.nh = (f.nrp + f.ntile - 1) / f.ntile;
-        f.nrpw = (f.nh + 1) / 2;                 // pairs per wave (template parameter): the two waves of a group share a tile's pairs
-        f.nh = 2 * f.nrpw;
-        f.rz = 2 * f.nh; f.nzr = f.ntile;
-        if (f.rz > RP_MAXRZ || f.nrpw > RP_MAXNHW) continue;
-        f.s_sbuf = (std::max(g.lring, f.rz * zstride) + 31) / 32 * 32 + 16;
-        const SoloLds L = pair_lds_plan(g.maxrin, f.s_rows, f.s_pst, f.s_sbuf, n_qtab, n_inst, n_job, g.nring, nref);
-        found = (size_t)L.total * sizeof(float) <= 160 * 1024;
+    auto plan_tiles = [&]() {
+        for (int nhmax = RP_MAXRZ / 2; nhmax >= 1 && !found; nhmax--) {
+
+            f.ntile = (f.nrp + nhmax - 1) / nhmax;
+            f.nh = (f.nrp + f.ntile - 1) / f.ntile;
+            f.nrpw = (f.nh + 1) / 2;                 // pairs per wave (template parameter): the two waves of a group share a tile's pairs
+            f.nh = 2 * f.nrpw;
+            f.rz = 2 * f.nh; f.nzr = f.ntile;
+            if (f.rz > RP_MAXRZ || f.nrpw > RP_MAXNHW) continue;
+            f.s_sbuf = (std::max(g.lring, f.rz * zstride) + 31) / 32 * 32 + 16;
+            const SoloLds L = pair_lds_plan(g.maxrin, f.s_rows, f.s_pst, f.s_sbuf, n_qtab, n_inst, n_job, g.nring, nref);
+            found = (size_t)L.total * sizeof(float) <= 160 * 1024;
+        }
+    };
+    plan_tiles();
+    if (found && try_wide) {          // the wide stride must not cost a tile
+        const int ntile_narrow = f.ntile;
+        f.s_pst = 101; found = false;
+        plan_tiles();
+        if (!found || f.ntile > ntile_narrow) { f.s_pst = pst_narrow; found = false; plan_tiles(); }
     }
     if (!found) return false;
     rf_layout_b(g, nref, f, out.bsrc);
