@@ -1060,6 +1060,19 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     }
     e->generic = !fits_specialised_kernels(e->geo, *cfg);
     e->tcrop = tcrop_wanted(e);
+    if (!e->tcrop && e->generic && e->geo.maxrin == 256 && !(getenv("RALIGN_TIGHT_RINGS") && atoi(getenv("RALIGN_TIGHT_RINGS")) == 0)) {
+        // ou = 37 ... 40: crop + four ring buffers miss the LDS by 4 - 8 KB, of which the 16 padding floats per ring are 10 KB.  With
+        // rings 4 floats apart (the in-place real transform needs 2; 4 keeps every ring 16-byte aligned) the four-offset kernels take
+        // the class from the pair kernel (RALIGN_TIGHT_RINGS=0: the pair kernel)
+        const int pad = getenv("RALIGN_TIGHT_RINGS") ? std::max(2, atoi(getenv("RALIGN_TIGHT_RINGS")) & ~1) : 4;
+        Geometry g16 = e->geo, g4;
+        if (build_rings(g4, cfg->nx, cfg->first_ring, cfg->last_ring, cfg->ring_skip > 0 ? cfg->ring_skip : 1, pad) &&
+            build_shifts(g4, cfg->xrng, cfg->yrng, cfg->step)) {
+            e->geo = g4;
+            e->tcrop = tcrop_wanted(e);
+            if (!e->tcrop) e->geo = g16;
+        }
+    }
     e->crop_S = (int)std::ceil(std::max(e->geo.nkx, e->geo.nky) * e->geo.step - 1e-6);
     if (e->generic && e->geo.maxrin <= 1024 && !(getenv("RALIGN_QUAD_ALIGN") && atoi(getenv("RALIGN_QUAD_ALIGN")) == 0)) align_ring_quads(e->geo);
     if (e->geo.maxrin > 4096) {

@@ -24,7 +24,8 @@ struct Geometry {
     int nbins = 0;                 // maxrin/2 + 1 complex bins of the CCF spectrum
     int LB = 0;                    // sum over rings of (n/2+1): complex entries per particle-shift
     int LBP = 0;                   // same with every bin's ring count padded to a multiple of 4
-    int lring = 0;                 // lcirc + kRingPad*nring floats: ring buffers padded for in-place R2C
+    int ring_pad = kRingPad;       // floats between consecutive rings of a ring buffer (>= 2: the in-place R2C needs the slot of X_{n/2})
+    int lring = 0;                 // lcirc + ring_pad*nring floats: ring buffers padded for in-place R2C
     float nn_weight = 0.f;         // Normalize_ring's float-accumulated sum of weights
     std::vector<int> numr;         // (radius, 1-based offset, length) per ring
     std::vector<float> wr;         // ringwe
@@ -51,8 +52,9 @@ struct Geometry {
 inline int ilog2_floor(int n) { int l = -1; while (n > 0) { n >>= 1; l++; } return l; }
 
 // sp_alignment.Numrinit(first,last,skip,"F") / ringwe(numr,"F")
-inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int skip)
+inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int skip, int ring_pad = kRingPad)
 {
+    g.ring_pad = ring_pad;
     const int MAXFFT = 32768;
     const double dpi = 2.0 * M_PI;
     g.nx = nx; g.first_ring = first_ring; g.last_ring = last_ring; g.skip = skip;
@@ -88,7 +90,7 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
     float nn = 0.f;
     for (int it = 0; it < g.nring; it++) {
         int inr = g.numr[3 * it], kc = g.numr[3 * it + 1] - 1, l = g.numr[3 * it + 2];
-        g.ring_off[it] = kc + kRingPad * it;
+        g.ring_off[it] = kc + g.ring_pad * it;
         int lt = l / 4, nsim = lt - 1;
         double dfi = qpi / (nsim + 1);
         float w = (float)(inr * 2 * M_PI / (float)l);
@@ -106,7 +108,7 @@ inline bool build_rings(Geometry &g, int nx, int first_ring, int last_ring, int 
         for (int j = 0; j < l; j++) nn += w;   // Normalize_ring: float accumulation in ring order
     }
     g.nn_weight = nn;
-    g.lring = g.lcirc + kRingPad * g.nring;
+    g.lring = g.lcirc + g.ring_pad * g.nring;
 
     // bin-major contraction layout
     g.bin_first.assign(g.nbins, 0);

@@ -23,7 +23,8 @@ SOLO = 3        # ra_search_path: particle-resident, one offset per pass
 
 @pytest.mark.parametrize("nx,ou,xr,mode", [(130, 52, 3, api.RA_MODE_MREF), (128, 60, 3, api.RA_MODE_MREF),
                                            (128, 60, 3, api.RA_MODE_REFFREE), (101, 44, 2, api.RA_MODE_MREF),
-                                           (100, 40, 3, api.RA_MODE_MREF), (128, 38, 4, api.RA_MODE_REFFREE)])      # the last two: search_pair_kernel
+                                           (100, 40, 3, api.RA_MODE_MREF), (128, 40, 4, api.RA_MODE_REFFREE)])      # the last two: search_pair_kernel (ou = 40: the
+                                                                                                      # one radius the four-offset kernels do not fit)
 def test_solo_polar_stage_bin_for_bin(nx, ou, xr, mode):
     """Polar2Dm -> (Normalize_ring) -> Frngs of every in-window search offset through the ring jobs of the solo / pair kernels (the
     512-sample job included), element by element against the oracle in EMAN2's packed ring layout"""
@@ -82,7 +83,7 @@ def crop4_expected(ou, nref):
     """engines of the size-generic class whose rings end at 256 samples and fit four ring buffers next to a CROP of the image run the
     kernels of the 90 x 90 boxes (search_fused_kernel up to 14 references, search_tiled_kernel beyond) instead of the pair kernel"""
     off = any(os.environ.get(sw) == "0" for sw in ("RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_CROP")) or (nref >= 15 and os.environ.get("RALIGN_TILED") == "0")
-    return ou <= 37 and not off          # (ou = 37: 37 rings, the fused kernel only -- it fits up to there at xr = 3)
+    return ou <= 39 and not off          # (ou = 37 .. 39: the fused kernel only, 38 and 39 with the rings 4 floats apart)
 
 
 def needs_crop(nx):
@@ -326,13 +327,14 @@ def test_pair_kernel_with_grown_ring_buffers(nx, ou, nref, monkeypatch):
 
 
 @pytest.mark.parametrize("nx,ou,nref,xr,ts", [(256, 36, 10, 3, 1.0), (160, 30, 24, 2, 0.5), (200, 34, 50, 3, 1.0), (141, 36, 7, 3, 1.0),
-                                              (176, 33, 2, 3, 1.0), (256, 30, 14, 2, 0.5)])
+                                              (176, 33, 2, 3, 1.0), (256, 30, 14, 2, 0.5),
+                                              (128, 38, 10, 3, 1.0), (150, 39, 3, 2, 1.0)])      # rings 4 floats apart: ou = 38, 39 fit too
 def test_tiled_kernel_on_a_cropped_image(nx, ou, nref, xr, ts):
     """boxes far larger than rings of 256 samples (engines of the size-generic class): search_fused_kernel (up to 14 references) /
     search_tiled_kernel, four offsets per pass, over a crop of the image that follows the particle's centre WITHOUT being clamped to the box (the kernel samples every offset of the
     window; those search_range excludes read whatever the crop holds there and are never looked at).  Shifts up to and beyond mashi,
     the dense offset stream with partial last passes, a half-pixel grid, 1 - 5 reference tiles"""
-    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP", "RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED")
+    default_path_only("RALIGN_SOLO", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_CROP", "RALIGN_TCROP", "RALIGN_FUSED", "RALIGN_TILED", "RALIGN_TIGHT_RINGS")
     n = 61
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
