@@ -36,6 +36,7 @@ CASES = {
     "box128": (128, 60, 3, 10, None),
     "box100": (100, 40, 3, 10, None),                   # search_pair_kernel
     "box96": (96, 36, 3, 10, None),                     # search_pair_kernel with ring buffers grown to hold a tile's spectra
+    "box128r38": (128, 38, 3, 10, None),                # search_fused_kernel on a crop with the rings 4 floats apart
     "box256": (256, 36, 3, 10, None),                   # search_pair_kernel on a crop of the image around the particle's centre
     "largebox": (256, 120, 5, 100, None),               # BASELINE configs[4] geometry (generic kernels); at most 8192 particles: the oracle needs ~0.5 s of 16 threads each
 }
