@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("RALIGN_LIB") or os.path.join(_HERE, "libralign_hip.so
 
 RA_MODE_MREF = 0
 RA_MODE_REFFREE = 1
+RA_INTERP_BILINEAR = 0      # Util::bilinear in alrl_ms (EMAN2 2.31; default)
+RA_INTERP_QUADRI = 1        # Util::quadri (older releases): size-generic kernels
 
 
 class AlignConfig(ctypes.Structure):
@@ -43,6 +45,11 @@ class RaConfig(ctypes.Structure):
                 ("device", ctypes.c_int), ("chunk", ctypes.c_int)]
 
 
+class RaOptions(ctypes.Structure):
+    # include/ralign.h: ra_options
+    _fields_ = [("interp", ctypes.c_int), ("normalize_ring", ctypes.c_int)]
+
+
 # ra_result as a numpy record (32 bytes)
 RESULT_DTYPE = np.dtype([("alpha", np.float32), ("sx", np.float32), ("sy", np.float32), ("mirror", np.int32),
                          ("ref_id", np.int32), ("peak", np.float32), ("angle_bin", np.int32),
@@ -62,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
     "ra_state_from_params_dev", "ra_class_fsc_fit", "ra_filter_references_dev", "ra_last_refine_count",
+    "ra_create_ex", "ra_set_normalize_ring", "ra_get_options",
 ]
 
 _lib = None
@@ -86,6 +94,9 @@ def load_library(path=None):
     vp = ctypes.c_void_p
     L.ra_last_error.restype = ctypes.c_char_p
     L.ra_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(RaConfig)]
+    L.ra_create_ex.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(RaConfig), ctypes.POINTER(RaOptions)]
+    L.ra_set_normalize_ring.argtypes = [vp, ctypes.c_int]
+    L.ra_get_options.argtypes = [vp, ctypes.POINTER(RaOptions)]
     L.ra_destroy.argtypes = [vp]
     L.ra_destroy.restype = None
     L.ra_set_stream.argtypes = [vp, vp]
@@ -192,14 +203,21 @@ class Engine:
     """Handle-based engine.  All tensor arguments are torch CUDA tensors on `device`."""
 
     def __init__(self, nx, last_ring, xrng, yrng, step, nref, mode=RA_MODE_MREF, first_ring=1, ring_skip=1,
-                 device=0, chunk=0):
+                 device=0, chunk=0, interp=RA_INTERP_BILINEAR, normalize_ring=None):
+        """interp / normalize_ring: the two hedges of include/ralign.h (ra_options) for the choices of the EMAN2 CPU path that the
+        reference tree does not pin -- Util::alrl_ms's interpolation (RA_INTERP_QUADRI: older EMAN2 releases; size-generic kernels)
+        and Normalize_ring on / off independent of the mode (None: by mode)."""
         import torch
         self.torch = torch
         self.lib = load_library()
         self.cfg = RaConfig(int(nx), int(first_ring), int(last_ring), int(ring_skip), float(xrng), float(yrng),
                             float(step), int(nref), int(mode), int(device), int(chunk))
         self.handle = ctypes.c_void_p()
-        _check(self.lib.ra_create(ctypes.byref(self.handle), ctypes.byref(self.cfg)), "ra_create")
+        if interp == RA_INTERP_BILINEAR and normalize_ring is None:
+            _check(self.lib.ra_create(ctypes.byref(self.handle), ctypes.byref(self.cfg)), "ra_create")
+        else:
+            opt = RaOptions(int(interp), -1 if normalize_ring is None else int(bool(normalize_ring)))
+            _check(self.lib.ra_create_ex(ctypes.byref(self.handle), ctypes.byref(self.cfg), ctypes.byref(opt)), "ra_create_ex")
         self.nx, self.nref, self.mode, self.device = int(nx), int(nref), int(mode), int(device)
         self.dev = torch.device("cuda", device)
 
@@ -262,6 +280,17 @@ class Engine:
         """user mask [nx][nx] (CUDA tensor) in place of model_circle(last_ring)"""
         assert mask.shape == (self.nx, self.nx)
         _check(self.lib.ra_set_mask(self.handle, self._ptr(mask, self.torch.float32)), "ra_set_mask")
+
+    def set_normalize_ring(self, flag):
+        """Normalize_ring for subsequent searches: True / False, None = the mode's default (ra_set_normalize_ring)"""
+        _check(self.lib.ra_set_normalize_ring(self.handle, -1 if flag is None else int(bool(flag))), "ra_set_normalize_ring")
+
+    @property
+    def options(self):
+        """(interp, normalize_ring) in force (ra_get_options)"""
+        o = RaOptions()
+        _check(self.lib.ra_get_options(self.handle, ctypes.byref(o)), "ra_get_options")
+        return int(o.interp), int(o.normalize_ring)
 
     def set_nomirror(self, flag):
         """--nomirror: search the straight orientation only (ormq -> Util.Crosrng_ns)"""

@@ -57,7 +57,7 @@ inline bool build_duo_plan(const Geometry &g, int nref, int n_qtab, int n_inst, 
     f.nh = (f.nrp + f.ntile - 1) / f.ntile;
     f.nrpw = f.nh; f.rz = 2 * f.nh; f.nzr = f.ntile;
     f.s_sbuf = std::max(lring_pad, 2 * f.rz * zstride);
-    f.s_r2 = getenv("RALIGN_DUO_R2") ? atoi(getenv("RALIGN_DUO_R2")) & 15 : 0;
+    f.s_r2 = RA_EXP_ENV("RALIGN_DUO_R2") ? ra_atoi(RA_EXP_ENV("RALIGN_DUO_R2")) & 15 : 0;
     // transforms of a tile: slot z = offset * rz + reference, one per wave, dealt from the highest rank down
     for (int w = 0; w < 16; w++) {
         const int c = 15 - f.s_rank[w];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
         for (int i = l0; i < g.nring; i += 64) { a += part[2 * i]; q += part[2 * i + 1]; }
         a = wave_sum_dpp(a); q = wave_sum_dpp(q);
         float avg = 0.f, rsg = 1.f;
-        if (g.mode == RA_MODE_MREF) {
+        if (g.norm_ring) {
             avg = a * g.inv_nn_weight;
             rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
         }

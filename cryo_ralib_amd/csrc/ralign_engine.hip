@@ -27,6 +27,17 @@ using namespace ralign;
 
 static thread_local std::string g_last_error;
 
+// The size-generic kernels for a geometry the LDS-resident ones cover: RALIGN_GENERIC=1 (A/B runs, tests), or an engine whose
+// options only they implement (ra_create_ex: RA_INTERP_QUADRI).  The option is engine state; the flag below carries it into the
+// planning helpers that see a geometry but no engine (fits_specialised_kernels, resident_expected) while that engine is planned.
+static thread_local bool g_force_generic = false;
+static bool generic_forced() { return g_force_generic || (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0); }
+struct ForceGenericScope {
+    bool prev;
+    explicit ForceGenericScope(bool on) : prev(g_force_generic) { g_force_generic = g_force_generic || on; }
+    ~ForceGenericScope() { g_force_generic = prev; }
+};
+
 #define RA_HIP(call)                                                                          \
     do {                                                                                      \
         hipError_t err__ = (call);                                                            \
@@ -85,7 +96,9 @@ struct ra_engine {
     int *d_ring_off = nullptr, *d_numr = nullptr;
     float *d_wr = nullptr;
     size_t lds_polar = 0, lds_ref = 0, lds_ccf = 0, lds_xf = 0;
+    bool force_generic = false;         // options that only the size-generic kernels implement (ra_create_ex)
     bool generic = false;               // size-generic kernels (ralign_generic.h): large boxes, maxrin > 256, > 48 rings
+    bool no_tcrop = false;              // the crop plan did not fit the real tables once: planned without it (create_engine)
     bool tcrop = false;                 // generic class, but the search runs search_tiled_kernel over a CROP of the image (tcrop_wanted)
     int crop_S = 0;                     // ... whose side was planned for search shifts of up to this many pixels
     int crop_pst = 0;                   // ... and its row stride in LDS (tcrop_wanted)
@@ -153,6 +166,15 @@ static bool fft_plan(int h, int &R1, int &R2)
     }
 }
 
+// polar stage of the size-generic class: alrl_ms with Util::bilinear (default) or Util::quadri (ra_create_ex)
+typedef void (*gpolar_fn)(DevGeom, const float *, const float *, int, float *, float2 *);
+static gpolar_fn gpolar_kernel(const ra_engine *e, bool refs)
+{
+    const bool q = e->dg.interp == RA_INTERP_QUADRI;
+    return refs ? (q ? (gpolar_fn)polar_generic_kernel<true, true> : (gpolar_fn)polar_generic_kernel<true, false>)
+                : (q ? (gpolar_fn)polar_generic_kernel<false, true> : (gpolar_fn)polar_generic_kernel<false, false>);
+}
+
 // the particle-resident kernel is planned for this engine (decided before the LDS layout, which differs slightly)
 static bool tiled_wanted(const ra_engine *e)
 {
@@ -176,7 +198,7 @@ static bool solo_wanted(const ra_engine *e)
 static bool pair_wanted(const ra_engine *e)
 {
     if (!e->generic || e->geo.maxrin != 256 || e->geo.nring > 4 * RP_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
-    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;      // the switch that forces the generic kernels
+    if (generic_forced()) return false;      // the switch that forces the generic kernels
     return !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0);
 }
 
@@ -200,8 +222,8 @@ static bool tcrop_wanted(ra_engine *e)
     const Geometry &g = e->geo;
     // (search_tiled_kernel holds slices of at most 36 rings, search_fused_kernel reads its operand from the ring buffers: up to 64)
     if (!e->generic || g.maxrin != 256 || g.nring > 64 || g.numr[2] < 8 || e->cfg.nref > 127) return false;
-    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) return false;
-    if (getenv("RALIGN_TCROP") && atoi(getenv("RALIGN_TCROP")) == 0) return false;
+    if (generic_forced()) return false;
+    if (e->no_tcrop || (getenv("RALIGN_TCROP") && atoi(getenv("RALIGN_TCROP")) == 0)) return false;
     if (getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0) return false;
     FusedGeom t{};
     crop_plan(g, t);
@@ -215,7 +237,7 @@ static bool tcrop_wanted(ra_engine *e)
     // (search launch per 8192 / 16 384 particles): ou = 36 / 256 x 256: 5.40 ms at 91, 5.35 at 93, 5.39 - 5.41 at 95 - 99, 5.23 at 101;
     // ou = 30 / 160 x 160: 9.56 ms at 73, 9.28 - 9.54 at 75 - 99, 9.35 at 101
     const int pst_min = t.s_pst;
-    for (int pst : {pst_min < 101 && !(getenv("RALIGN_CROP_PST101") && atoi(getenv("RALIGN_CROP_PST101")) == 0) ? 101 : pst_min, pst_min}) {
+    for (int pst : {pst_min < 101 && !(RA_EXP_ENV("RALIGN_CROP_PST101") && ra_atoi(RA_EXP_ENV("RALIGN_CROP_PST101")) == 0) ? 101 : pst_min, pst_min}) {
     e->crop_pst = pst;
     const size_t polar = (size_t)pst * pst + 4 * (size_t)std::max(sbuf, sbuf <= RF_SBUF_FIXED ? RF_SBUF_FIXED : sbuf) + 2 * g.maxrin + 3000;
     // the kernels' division of the reference counts is that of the 90 x 90 engines: search_fused_kernel up to RT_MINREF - 1
@@ -248,11 +270,11 @@ static int build_device_geometry(ra_engine *e)
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
-    d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.quad_aligned = g.quad_aligned ? 1 : 0;
+    d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.norm_ring = e->cfg.mode == RA_MODE_MREF ? 1 : 0; d.interp = RA_INTERP_BILINEAR; d.quad_aligned = g.quad_aligned ? 1 : 0;
 #ifdef RALIGN_PROFILE_SWITCHES
-    d.dbg = getenv("RALIGN_DEBUG") ? atoi(getenv("RALIGN_DEBUG")) : 0;
+    d.dbg = RA_EXP_ENV("RALIGN_DEBUG") ? ra_atoi(RA_EXP_ENV("RALIGN_DEBUG")) : 0;
     d.timeline = nullptr;
-    if (getenv("RALIGN_TIMELINE")) {          // 64 passes x 16 waves x 16 stamps, written by workgroup 0 for its first particle
+    if (RA_EXP_ENV("RALIGN_TIMELINE")) {          // 64 passes x 16 waves x 16 stamps, written by workgroup 0 for its first particle
         if (!e->d_timeline && hipMalloc(&e->d_timeline, 64 * 16 * 16 * sizeof(unsigned long long)) != hipSuccess) e->d_timeline = nullptr;
         if (e->d_timeline) (void)hipMemset(e->d_timeline, 0, 64 * 16 * 16 * sizeof(unsigned long long));
         d.timeline = e->d_timeline;
@@ -264,11 +286,11 @@ static int build_device_geometry(ra_engine *e)
     // ring-buffer stride.  Kernel pair: == 8 (mod 32), the 4 offsets of an entry hit disjoint banks in the write-out gather.
     // Fused kernel: == 16 (mod 32), the two offsets a 4x4x1 MFMA A operand reads (16 bins x Re/Im each) sit in disjoint
     // halves of the 32 banks (RALIGN_SBUF_PAD overrides: experiments)
-    int sbuf = (g.lring + 31) / 32 * 32 + (getenv("RALIGN_SBUF_PAD") ? atoi(getenv("RALIGN_SBUF_PAD")) : ((fused_wanted(e) || e->tcrop) ? 16 : 8));
+    int sbuf = (g.lring + 31) / 32 * 32 + (RA_EXP_ENV("RALIGN_SBUF_PAD") ? ra_atoi(RA_EXP_ENV("RALIGN_SBUF_PAD")) : ((fused_wanted(e) || e->tcrop) ? 16 : 8));
     // fused kernel at maxrin 256: pad the stride to the compile-time value of its fixed-stride instantiations when the image
     // and four such buffers (+ 16 KB of tables and records) still fit the LDS (RALIGN_SBUF_FIXED=0: keep the run-time stride)
-    if ((fused_wanted(e) || e->tcrop) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !getenv("RALIGN_SBUF_PAD") &&
-        !(getenv("RALIGN_SBUF_FIXED") && atoi(getenv("RALIGN_SBUF_FIXED")) == 0)) {
+    if ((fused_wanted(e) || e->tcrop) && g.maxrin == 256 && sbuf <= RF_SBUF_FIXED && !RA_EXP_ENV("RALIGN_SBUF_PAD") &&
+        !(RA_EXP_ENV("RALIGN_SBUF_FIXED") && ra_atoi(RA_EXP_ENV("RALIGN_SBUF_FIXED")) == 0)) {
         const int bd0 = (int)std::ceil(std::max(e->cfg.xrng, e->cfg.yrng)) + 2, pst0 = e->tcrop ? e->crop_pst : g.nx + 2 * bd0 + 3;
         if ((size_t)(pst0 * pst0 + 4 * RF_SBUF_FIXED + 3400) * sizeof(float) <= 160 * 1024) sbuf = RF_SBUF_FIXED;
     }
@@ -374,7 +396,7 @@ static int build_device_geometry(ra_engine *e)
             // rings of 8 .. 32 samples share jobs of code 9 (ring_job_mix: n / 8 lanes per ring, one table entry per lane)
             // (RALIGN_MIX_JOBS=0, one job per ring length, is an experiment switch of the kernel pair: the fused kernel carries
             // the job variants of codes 1, 6, 7 and 9 only)
-            const bool mixed = solo || pairj || (nslot == 4 && (fused_wanted(e) || e->tcrop || !(getenv("RALIGN_MIX_JOBS") && atoi(getenv("RALIGN_MIX_JOBS")) == 0)));
+            const bool mixed = solo || pairj || (nslot == 4 && (fused_wanted(e) || e->tcrop || !(RA_EXP_ENV("RALIGN_MIX_JOBS") && ra_atoi(RA_EXP_ENV("RALIGN_MIX_JOBS")) == 0)));
             for (int lg = solo ? 9 : 8; lg >= (mixed ? 6 : 3); lg--) {
                 const int n = 1 << lg;
                 const int code = lightjobs && n == 512 ? 11 : lightjobs && n == 256 ? 0 :
@@ -428,7 +450,7 @@ static int build_device_geometry(ra_engine *e)
             if (duo_wanted(e) && !light_only) { make_jobs(1, jobs, inst, instw, true); d.n_job_b = (int)jobs.size() - na; }
         } else if (e->tcrop) make_jobs(4, jobs, inst, instw, false);
         else if (pair_wanted(e)) make_jobs(2, jobs, inst, instw, false);
-        if (const char *po = getenv("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
+        if (const char *po = RA_EXP_ENV("RALIGN_JOB_ORDER")) {       // experiments: wave w of a pass runs job order[w] ("3,2,1,0,...")
             std::vector<int4> perm;
             for (const char *c = po; *c;) {
                 const int k = atoi(c);
@@ -451,7 +473,7 @@ static int build_device_geometry(ra_engine *e)
     // bilinear taps step through the image by +-1 column, +-1 row (= pst words) or a diagonal (pst +- 1).  A stride
     // that is a multiple of 32 (96 at nx = 90) puts every vertical neighbour into the same LDS bank; pick the next
     // stride whose residues pst, pst - 1, pst + 1 share at most a factor 4 with the 32 banks.
-    if (!(getenv("RALIGN_PST_RAW") && atoi(getenv("RALIGN_PST_RAW")) != 0))
+    if (!(RA_EXP_ENV("RALIGN_PST_RAW") && ra_atoi(RA_EXP_ENV("RALIGN_PST_RAW")) != 0))
         while (!((d.pst & 1) && ((d.pst - 1) & 7) && ((d.pst + 1) & 7))) d.pst++;
 
     std::vector<float2> tw(g.maxrin);
@@ -546,7 +568,7 @@ static bool resident_expected(const Geometry &g, const ra_config &cfg, bool gene
         // search_pair_kernel: rings of 256 samples, image and two ring buffers
         const bool c512 = g.maxrin == 512 && g.nring <= 4 * RS_NQ && !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
         const bool c256 = g.maxrin == 256 && g.nring <= 4 * RP_NQ && !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0) &&
-                          !(getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0);
+                          !generic_forced();
         if (!(c512 || c256) || g.numr[2] < 8 || cfg.nref > 127) return false;
         // the LDS image is a crop around the particle's centre when the box is larger than the rings need (crop_plan)
         const int S = (int)std::ceil(std::max(g.nkx, g.nky) * g.step - 1e-6), side = 2 * (S + g.last_ring) + 5;
@@ -843,7 +865,7 @@ static int plan_nqmax(const FusedGeom &f)
 static solo_fn select_duo(int maxrin, int nh, int nqmax)
 {
     if (maxrin != 512) return nullptr;
-    const bool q14 = nqmax <= 14 && !(getenv("RALIGN_DUO_NQT") && atoi(getenv("RALIGN_DUO_NQT")) == 16);
+    const bool q14 = nqmax <= 14 && !(RA_EXP_ENV("RALIGN_DUO_NQT") && ra_atoi(RA_EXP_ENV("RALIGN_DUO_NQT")) == 16);
     return q14 ? select_duo_t<14>(nh) : select_duo_t<16>(nh);
 }
 
@@ -914,7 +936,7 @@ static int setup_refine(ra_engine *e)
     e->refine_ok = false;
     if (getenv("RALIGN_REFINE")) e->refine_thr = (float)atof(getenv("RALIGN_REFINE"));
     // ring buffers (2 lcirc floats) + the twiddles and samples of the f64 CCF (RA_EXACT_TABLE_BYTES)
-    e->lds_refine = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float) + RA_EXACT_TABLE_BYTES(g.maxrin);
+    e->lds_refine = (size_t)((std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) + 3) & ~3) * sizeof(float) + RA_EXACT_TABLE_BYTES(g.maxrin);
     if (g.lcirc & 1) return RA_OK;
     // large boxes: one offset's rings exceed the LDS (271 KB at 256 x 256 / ou = 120) -- the same kernels with the ring buffers
     // in global scratch
@@ -940,6 +962,9 @@ static int setup_refine(ra_engine *e)
         (rc = dev_alloc(e, &e->d_rcount, 1, true))) return rc;
     if (e->refine_gm) {
         if ((rc = dev_alloc(e, &e->d_rscratch, (size_t)std::max(e->refine_grid, e->cfg.nref) * 2 * g.lcirc, false))) return rc;
+        // the f64 twiddles and samples stay in LDS (24 maxrin bytes: 96 KB at maxrin 4096, beyond the 64 KB a kernel gets unasked)
+        hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
+        if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(refine, global ring buffers): ") + hipGetErrorString(he); return RA_ERR_HIP; }
     } else {
         hipError_t he = hipFuncSetAttribute((const void *)refine_winner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)refspec_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_refine);
@@ -1025,11 +1050,24 @@ static bool fits_specialised_kernels(const Geometry &g0, const ra_config &cfg)
         if (ns != prev) { ncls++; prev = ns; }
     }
     if (ncls > 8) fast = false;
-    if (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0) fast = false;
+    if (generic_forced()) fast = false;
     return fast;
 }
 
-extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
+static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options *opt, bool allow_tcrop);
+extern "C" int ra_create(ra_engine **out, const ra_config *cfg) { return ra_create_ex(out, cfg, nullptr); }
+extern "C" int ra_create_ex(ra_engine **out, const ra_config *cfg, const ra_options *opt)
+{
+    if (opt && (opt->interp != RA_INTERP_BILINEAR && opt->interp != RA_INTERP_QUADRI)) { g_last_error = "bad interpolation"; return RA_ERR_ARG; }
+    if (opt && (opt->normalize_ring < -1 || opt->normalize_ring > 1)) { g_last_error = "normalize_ring is -1 (by mode), 0 or 1"; return RA_ERR_ARG; }
+    ForceGenericScope scope(opt && opt->interp == RA_INTERP_QUADRI);
+    int rc = create_engine(out, cfg, opt, true);
+    // the plan of the four-offset kernels over a crop of the image is promised by tcrop_wanted on an estimate of the tables; should
+    // the real tables miss it, the engine is planned again without that path (pair or generic kernels) instead of failing
+    if (rc == RA_ERR_STATE) rc = create_engine(out, cfg, opt, false);
+    return rc;
+}
+static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options *opt, bool allow_tcrop)
 {
     if (!out || !cfg) { g_last_error = "null argument"; return RA_ERR_ARG; }
     *out = nullptr;
@@ -1058,13 +1096,18 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         delete e;
         return RA_ERR_ARG;
     }
+    e->force_generic = g_force_generic;
+    e->no_tcrop = !allow_tcrop;
     e->generic = !fits_specialised_kernels(e->geo, *cfg);
     e->tcrop = tcrop_wanted(e);
-    if (!e->tcrop && e->generic && e->geo.maxrin == 256 && !(getenv("RALIGN_TIGHT_RINGS") && atoi(getenv("RALIGN_TIGHT_RINGS")) == 0)) {
+    if (!e->tcrop && allow_tcrop && e->generic && e->geo.maxrin == 256 && !(getenv("RALIGN_TIGHT_RINGS") && atoi(getenv("RALIGN_TIGHT_RINGS")) == 0)) {
         // ou = 37 ... 40: crop + four ring buffers miss the LDS by 4 - 8 KB, of which the 16 padding floats per ring are 10 KB.  With
         // rings 4 floats apart (the in-place real transform needs 2; 4 keeps every ring 16-byte aligned) the four-offset kernels take
         // the class from the pair kernel (RALIGN_TIGHT_RINGS=0: the pair kernel)
-        const int pad = getenv("RALIGN_TIGHT_RINGS") ? std::max(2, atoi(getenv("RALIGN_TIGHT_RINGS")) & ~1) : 4;
+        // (RALIGN_TIGHT_RINGS is on / off like every other switch; the distance itself is an experiment of profiling builds,
+        // RALIGN_RING_PAD: multiples of 4 only -- 2 would leave the rings 8-byte aligned, a layout no test covers)
+        int pad = 4;
+        if (const char *rp = RA_EXP_ENV("RALIGN_RING_PAD")) { const int v = atoi(rp); if (v >= 4 && v % 4 == 0 && v < kRingPad) pad = v; }
         Geometry g16 = e->geo, g4;
         if (build_rings(g4, cfg->nx, cfg->first_ring, cfg->last_ring, cfg->ring_skip > 0 ? cfg->ring_skip : 1, pad) &&
             build_shifts(g4, cfg->xrng, cfg->yrng, cfg->step)) {
@@ -1074,7 +1117,7 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         }
     }
     e->crop_S = (int)std::ceil(std::max(e->geo.nkx, e->geo.nky) * e->geo.step - 1e-6);
-    if (e->generic && e->geo.maxrin <= 1024 && !(getenv("RALIGN_QUAD_ALIGN") && atoi(getenv("RALIGN_QUAD_ALIGN")) == 0)) align_ring_quads(e->geo);
+    if (e->generic && e->geo.maxrin <= 1024 && !(RA_EXP_ENV("RALIGN_QUAD_ALIGN") && ra_atoi(RA_EXP_ENV("RALIGN_QUAD_ALIGN")) == 0)) align_ring_quads(e->geo);
     if (e->geo.maxrin > 4096) {
         g_last_error = "rings longer than 4096 samples are not supported";
         delete e;
@@ -1084,6 +1127,10 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
     e->dg.rpt = (cfg->nref + e->nrtile - 1) / e->nrtile;      // balanced reference tiles (10 -> 5 + 5)
     int rc = build_device_geometry(e);
     if (rc) { ra_destroy(e); return rc; }
+    if (opt) {
+        e->dg.interp = opt->interp;
+        if (opt->normalize_ring >= 0) e->dg.norm_ring = opt->normalize_ring;
+    }
 
     e->shift_cap = e->geo.nshift; e->pad_cap = e->geo.nshift_pad;
     const Geometry &g = e->geo;
@@ -1111,8 +1158,8 @@ extern "C" int ra_create(ra_engine **out, const ra_config *cfg)
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ref_polar_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ref);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)select_ccf(g.maxrin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_ccf);
     } else {
-        he = hipFuncSetAttribute((const void *)polar_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
-        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)polar_generic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
+        he = hipFuncSetAttribute((const void *)gpolar_kernel(e, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
+        if (he == hipSuccess) he = hipFuncSetAttribute((const void *)gpolar_kernel(e, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gpolar);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
         if (he == hipSuccess) he = hipFuncSetAttribute((const void *)ccf_generic_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_gccf);
@@ -1160,11 +1207,11 @@ extern "C" void ra_destroy(ra_engine *e)
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
 #ifdef RALIGN_PROFILE_SWITCHES
-    if (e->d_timeline && getenv("RALIGN_TIMELINE")) {      // profiling builds: dump the wave timeline of the last launch
+    if (e->d_timeline && RA_EXP_ENV("RALIGN_TIMELINE")) {      // profiling builds: dump the wave timeline of the last launch
         std::vector<unsigned long long> h(64 * 16 * 16);
         (void)hipDeviceSynchronize();
         if (hipMemcpy(h.data(), e->d_timeline, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *fp = fopen(getenv("RALIGN_TIMELINE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
+            if (FILE *fp = fopen(RA_EXP_ENV("RALIGN_TIMELINE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
         }
         (void)hipFree(e->d_timeline);
     }
@@ -1189,6 +1236,19 @@ extern "C" int ra_set_mask(ra_engine *e, const float *d_mask)
 {
     if (!e || !d_mask) { g_last_error = "null argument"; return RA_ERR_ARG; }
     RA_HIP(hipMemcpyAsync((void *)e->dg.mask, d_mask, (size_t)e->geo.nx * e->geo.nx * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return RA_OK;
+}
+
+extern "C" int ra_set_normalize_ring(ra_engine *e, int flag)
+{
+    if (!e) return RA_ERR_ARG;
+    e->dg.norm_ring = flag < 0 ? (e->cfg.mode == RA_MODE_MREF ? 1 : 0) : flag ? 1 : 0;
+    return RA_OK;
+}
+extern "C" int ra_get_options(const ra_engine *e, ra_options *opt)
+{
+    if (!e || !opt) return RA_ERR_ARG;
+    opt->interp = e->dg.interp; opt->normalize_ring = e->dg.norm_ring;
     return RA_OK;
 }
 
@@ -1225,6 +1285,7 @@ extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_A
 extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
 {
     if (!e) return RA_ERR_ARG;
+    ForceGenericScope scope(e->force_generic);
     Geometry g2 = e->geo;
     if (!build_shifts(g2, xrng, yrng, step)) { g_last_error = "bad shift window"; return RA_ERR_ARG; }
     // the reference asserts the offset count does not change (gpu_aln_noref.cu:135); we only
@@ -1259,7 +1320,8 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     int rc = setup_fused(e);
     // the solo / duo / pair kernels keep a crop of the image whose side follows the search range: plan again (a wider range at a
     // constant offset count, e.g. xr = 1, ts = 0.5 -> xr = 4, ts = 2, would otherwise let taps leave the crop)
-    if (!rc && e->generic && e->solo) rc = setup_solo(e);
+    // (also when the previous window made the plan fall back to the generic kernels: the new one may fit again)
+    if (!rc && e->generic && !e->fused && (e->solo || solo_wanted(e) || pair_wanted(e))) rc = setup_solo(e);
     return rc;
 }
 
@@ -1268,7 +1330,7 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
     if (!e || !d_refs) { g_last_error = "null argument"; return RA_ERR_ARG; }
     const Geometry &g = e->geo;
     if (e->generic)
-        hipLaunchKernelGGL(polar_generic_kernel<true>, dim3(e->cfg.nref), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
+        hipLaunchKernelGGL(gpolar_kernel(e, true), dim3(e->cfg.nref), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
                            d_refs, (const float *)nullptr, e->cfg.nref, e->d_refspec, (float2 *)nullptr);
     else
         hipLaunchKernelGGL(ref_polar_fft_kernel, dim3(e->cfg.nref), dim3(256), e->lds_ref, e->stream, e->dg, d_refs,
@@ -1571,7 +1633,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         }
         if (evp) RA_HIP(hipEventRecord(evp->first, sp));
         if (e->generic)
-            hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
+            hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
                                part, (const float *)st, cn, Abuf, e->d_gstats);
         else
             hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
@@ -1603,7 +1665,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             };
             for (int task0 = 0; task0 < ntask; task0 += nblk) {
                 const int nt = std::min(nblk, ntask - task0);
-                const int grid2 = std::min(nt * TMv * TRv * 8, (getenv("RALIGN_IFFT_WGS") ? atoi(getenv("RALIGN_IFFT_WGS")) : 2) * e->n_cu);
+                const int grid2 = std::min(nt * TMv * TRv * 8, (RA_EXP_ENV("RALIGN_IFFT_WGS") ? ra_atoi(RA_EXP_ENV("RALIGN_IFFT_WGS")) : 2) * e->n_cu);
                 if (wide && TMv == 4) launch(ccf_generic_kernel<4, 7, true>, gccf_ifft_kernel<4, 7>, task0, nt, grid2);
                 else if (wide && TMv == 2) launch(ccf_generic_kernel<2, 7, true>, gccf_ifft_kernel<2, 7>, task0, nt, grid2);
                 else if (wide) launch(ccf_generic_kernel<1, 7, true>, gccf_ifft_kernel<1, 7>, task0, nt, grid2);
@@ -1663,7 +1725,7 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
         if (rcw) return rcw;
     }
     if (e->generic)
-        hipLaunchKernelGGL(polar_generic_kernel<false>, dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
+        hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
                            e->dg, d_particles, d_state, n, e->d_A, e->d_gstats);
     else
         hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refspec_exact_kernel(DevGeom
     else { circ = lds; work = lds + g.lcirc; }
     const float *img = refs + (size_t)r * g.nx * g.nx;
     const float c = (float)g.cnx;
-    for (int i = lane; i < g.lcirc; i += RA_EXACT_THREADS) circ[i] = bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
+    for (int i = lane; i < g.lcirc; i += RA_EXACT_THREADS) circ[i] = g.interp ? quadri_1b(img, g.nx, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c) : bilinear_1b(img, g.nx, g.samp_dx[i] + c, g.samp_dy[i] + c);
     exact_lds_sync<GM>();
     exact_frngs<GM>(circ, work, g, numr, tw, twoff, lane, wr);          // Frngs, then Applyws on the way out of the split step
     exact_lds_sync<GM>();
@@ -201,7 +201,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = min(i0 + T * u, g.lcirc - 1);
-            v[u] = bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
+            v[u] = g.interp ? quadri_1b(img, g.nx, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy) : bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
             w[u] = g.samp_w[i];
         }
 #pragma unroll
@@ -211,7 +211,7 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
                 av += (double)(v[u] * w[u]); sq += (double)(v[u] * v[u] * w[u]);
             }
     }
-    if (g.mode == RA_MODE_MREF) {
+    if (g.norm_ring) {
         av = block_sum_f64(av, red); sq = block_sum_f64(sq, red);
         const float nn = g.nn_weight, avf = (float)av, sqf = (float)sq;
         const float avg = avf / nn;
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     else { circ = lds; work = lds + g.lcirc; }
     // behind the ring buffers (GM: at the start of the dynamic LDS): [maxrin] (cos, sin)(2 pi j / maxrin) and the maxrin samples of
     // a candidate's CCF, both in double (RA_EXACT_TABLE_BYTES)
-    double2 *twd = reinterpret_cast<double2 *>(GM ? lds : lds + 2 * g.lcirc);
+    // (the spectrum of a candidate -- maxrin doubles at `work` -- ends at lcirc + 2 maxrin floats, beyond 2 lcirc for very short ring
+    // sets: the tables start behind whichever is larger, as setup_refine sizes the allocation)
+    double2 *twd = reinterpret_cast<double2 *>(GM ? lds : lds + (((2 * g.lcirc > g.lcirc + 2 * g.maxrin ? 2 * g.lcirc : g.lcirc + 2 * g.maxrin) + 3) & ~3));
     double *xs = reinterpret_cast<double *>(twd + g.maxrin);
     for (int j = lane; j < g.maxrin; j += RA_EXACT_THREADS) {
         double sn, cs;

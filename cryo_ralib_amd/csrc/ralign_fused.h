@@ -160,7 +160,7 @@ inline bool build_fused_plan(const Geometry &g, int nref, int sbuf, size_t lds_p
         int light[4] = {0, 1, 2, 3};
         // (counting the inverse-FFT calls of a SIMD's waves into its load before the deal -- 8 .. 19 units per call -- measured
         // within noise, more than that slower)
-        f.ifft_full = (getenv("RALIGN_IFFT_FULL") && atoi(getenv("RALIGN_IFFT_FULL")) == 0) ? 0 : 1;
+        f.ifft_full = (RA_EXP_ENV("RALIGN_IFFT_FULL") && ra_atoi(RA_EXP_ENV("RALIGN_IFFT_FULL")) == 0) ? 0 : 1;
         for (const Item &it : items) {
             int c = -1;
             for (int q = 0; q < 4; q++)
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_fused_kernel(DevGeom g_in, 
             for (int i = lane; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum_dpp(a); q = wave_sum_dpp(q);
             float avg = 0.f, rsg = 1.f;
-            if (g.mode == RA_MODE_MREF) {
+            if (g.norm_ring) {
                 // avg = av / nn, 1 / sigma = 1 / sqrt((sq - av^2 / nn) / nn) with the host's 1 / nn and v_rsq_f32 (1 ulp):
                 // four IEEE divisions and a square root are ~100 instructions on the wave that ends the phase
                 avg = a * g.inv_nn_weight;

@@ -280,7 +280,7 @@ __device__ __forceinline__ float2 ring_pos(const float2 *qt, int lt, int lgl, fl
 // Normalize_ring is linear, and at these sizes a second sampling pass for its statistics costs as much as the
 // transform itself: the particle spectra are written RAW, the statistics {avg, 1/sigma} of every (particle, offset) go to
 // `stats`, and the contraction applies them (DC bin: a -= avg * sum_r n_r C_r(0); peak records: * 1/sigma).
-template <bool REFS>
+template <bool REFS, bool QUADRI = false>
 __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeom g, const float *__restrict__ images,
                                                                       const float *__restrict__ state, int n,
                                                                       float *__restrict__ out, float2 *__restrict__ stats)
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
             float *xr = reinterpret_cast<float *>(bx);
             for (int j = lane; j < nlen; j += 64) {
                 const float2 d = ring_pos(qt_s + ri.w, lt, lgl, fr, j);
-                xr[j] = bilinear_1b(img, g.nx, d.x + c, d.y + c);
+                xr[j] = polar_sample_1b<QUADRI>(img, g.nx, d.x + c, d.y + c);
             }
             wave_lds_sync();
             const float2 *Z = (h >= 2) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
                         for (int u = 0; u < 4; u++) {
                             const int j = min(j0 + 64 * u, nlen - 1);
                             const float2 d = ring_pos(qt, lt, lgl, fr, j);
-                            sv[u] = RA_DBG(g, 512) ? (float)j : bilinear_1b(img, g.nx, d.x + cx, d.y + cy);
+                            sv[u] = RA_DBG(g, 512) ? (float)j : polar_sample_1b<QUADRI>(img, g.nx, d.x + cx, d.y + cy);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++)
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
         float a = 0.f, q = 0.f;
         for (int j = lane; j < nlen; j += 64) {
             const float2 d = ring_pos(qt_s + ri.w, lt, lgl, fr, j);
-            const float sv = bilinear_1b(img, g.nx, d.x + cx, d.y + cy);
+            const float sv = polar_sample_1b<QUADRI>(img, g.nx, d.x + cx, d.y + cy);
             xr[j] = sv;
             a += sv * wt; q += sv * sv * wt;
         }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
     av = wave_sum_dpp(av); sq = wave_sum_dpp(sq);      // fixed order: reproducible
     if (lane == 0) {
         float avg = 0.f, rsg = 1.f;
-        if (g.mode == RA_MODE_MREF) {
+        if (g.norm_ring) {
             const float nn = g.nn_weight;
             avg = av / nn;
             rsg = 1.0f / sqrtf((sq - av * av / nn) / nn);
@@ -459,7 +459,7 @@ inline bool gccf_wide_blocks(int nrtile) { return nrtile >= 6 && (nrtile + 6) / 
 // fewer launches and tails: 27.9 / 27.6 / 27.1 ms per chunk at 1 / 2 / 5 blocks); RALIGN_GCCF_BPW = 1 .. 8 overrides
 inline int gccf_blocks_per_wg()
 {
-    const char *ev = getenv("RALIGN_GCCF_BPW");
+    const char *ev = RA_EXP_ENV("RALIGN_GCCF_BPW");
     const int v = ev ? atoi(ev) : 0;
     return v >= 1 && v <= 8 ? v : 2;
 }

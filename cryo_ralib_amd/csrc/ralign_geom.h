@@ -9,7 +9,20 @@
 #include <cstdint>
 #include <vector>
 
+// Environment switches.  The ones a user or a test may set (kernel-path selection, RALIGN_INFO, RALIGN_REFINE; README "Environment")
+// are read with getenv in every build.  EXPERIMENT switches -- layout strides, job orders, block shapes that were measured once and
+// whose built-in value is the fastest -- exist only in profiling builds (-DRALIGN_PROFILE_SWITCHES): in the shipped library
+// RA_EXP_ENV is a null constant, so neither the lookup nor the name is in the binary.
+#include <cstdlib>
+#ifdef RALIGN_PROFILE_SWITCHES
+#define RA_EXP_ENV(name) getenv(name)
+#else
+#define RA_EXP_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace ralign {
+
+inline int ra_atoi(const char *v) { return v ? atoi(v) : 0; }
 
 // floats between consecutive rings in the padded ring buffer, beyond the ring's n samples: 2 would do for the
 // in-place real FFT (slot of X_{n/2}); 16 makes every ring stride (24, 32, 48, 80, 144, 272 floats) an odd multiple of 8

@@ -51,6 +51,8 @@ struct DevGeom {
     int lg_maxrin;                 // log2(maxrin): twiddle strides are shifts (v_mul_lo_u32 is quarter rate)
     int mode;                     // RA_MODE_*
     int nomirror;                 // ormq(..., nomirror): the mirrored half of Crosrng_ms is not considered
+    int norm_ring;                // Normalize_ring between Polar2Dm and Frngs (default: RA_MODE_MREF on, RA_MODE_REFFREE off; ra_set_normalize_ring)
+    int interp;                   // RA_INTERP_*: alrl_ms's interpolation (bilinear; quadri: size-generic kernels only, ra_create_ex)
     int quad_aligned;             // generic kernels: ring quads aligned across bins (ralign_geom.h: align_ring_quads)
     int dbg;                      // phase-skip mask of profiling builds (-DRALIGN_PROFILE_SWITCHES); unused otherwise
     unsigned long long *timeline; // profiling builds: [pass][wave][stamp] clock values of workgroup 0's first particle, or null
@@ -146,6 +148,45 @@ __device__ __forceinline__ float bilinear_1b(const float *img, int nx, float xol
     auto tap = [&](unsigned idx) { return *reinterpret_cast<const float *>(ib + 4u * idx); };      // 32-bit byte offset (images < 4 GB)
     float f00 = tap(r0 + (unsigned)x0), f10 = tap(r0 + (unsigned)x1), f01 = tap(r1 + (unsigned)x0), f11 = tap(r1 + (unsigned)x1);
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+}
+
+// Util::quadri (the interpolation of alrl_ms in older EMAN2 releases; RA_INTERP_QUADRI): 1-based coordinates, periodic in both
+// directions, the operations and their order as in quadri_background_1b below (no contraction)
+__device__ __forceinline__ float quadri_1b(const float *fdata, int nx, int ny, float xx, float yy)
+{
+#pragma clang fp contract(off)
+    float x = xx, y = yy;
+    while (x < 1.0f) x += nx;
+    while (x >= (float)(nx + 1)) x -= nx;
+    while (y < 1.0f) y += ny;
+    while (y >= (float)(ny + 1)) y -= ny;
+    int i = (int)x, j = (int)y;
+    float dx0 = x - i, dy0 = y - j;
+    int ip1 = i + 1, im1 = i - 1, jp1 = j + 1, jm1 = j - 1;
+    if (ip1 > nx) ip1 -= nx;
+    if (im1 < 1) im1 += nx;
+    if (jp1 > ny) jp1 -= ny;
+    if (jm1 < 1) jm1 += ny;
+#define RA_FDQ(i_, j_) fdata[((j_) - 1) * nx + ((i_) - 1)]
+    float f0 = RA_FDQ(i, j);
+    float c1 = RA_FDQ(ip1, j) - f0;
+    float c2 = (c1 - f0 + RA_FDQ(im1, j)) * 0.5f;
+    float c3 = RA_FDQ(i, jp1) - f0;
+    float c4 = (c3 - f0 + RA_FDQ(i, jm1)) * 0.5f;
+    float dxb = dx0 - 1, dyb = dy0 - 1;
+    int hxc = (dx0 >= 0) ? 1 : -1, hyc = (dy0 >= 0) ? 1 : -1;
+    int ic = i + hxc, jc = j + hyc;
+    if (ic > nx) ic -= nx; else if (ic < 1) ic += nx;
+    if (jc > ny) jc -= ny; else if (jc < 1) jc += ny;
+    float c5 = ((RA_FDQ(ic, jc) - f0 - hxc * c1 - (hxc * (hxc - 1.0f)) * c2 - hyc * c3 - (hyc * (hyc - 1.0f)) * c4) * (hxc * hyc));
+#undef RA_FDQ
+    return f0 + dx0 * (c1 + dxb * c2 + dy0 * c5) + dy0 * (c3 + dyb * c4);
+}
+// alrl_ms's sample at (x, y): Util::bilinear (EMAN2 2.31; the default) or Util::quadri
+template <bool QUADRI> __device__ __forceinline__ float polar_sample_1b(const float *img, int nx, float x, float y)
+{
+    if constexpr (QUADRI) return quadri_1b(img, nx, nx, x, y);
+    else return bilinear_1b(img, nx, x, y);
 }
 
 // the same interpolation on an LDS image with a zero border of `bd` pixels (row stride `st`):
@@ -839,7 +880,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             a = wave_sum(a); q = wave_sum(q);
             if (lane == 0) {
                 float avg = 0.f, rsg = 1.f;
-                if (g.mode == RA_MODE_MREF) {
+                if (g.norm_ring) {
                     const float nn = g.nn_weight;
                     avg = a / nn;
                     rsg = 1.0f / sqrtf((q - a * a / nn) / nn);
@@ -848,7 +889,7 @@ __global__ __launch_bounds__(RA_POLAR_THREADS) void polar_fft_kernel(DevGeom g, 
             }
         }
         __syncthreads();
-        if (g.mode == RA_MODE_MREF && tid < 4 * g.nring) {
+        if (g.norm_ring && tid < 4 * g.nring) {
             const int s = tid / g.nring, i = tid - s * g.nring;
             const int4 ri = g.ringinfo[i];
             bufs[s * g.sbuf + ri.x] -= red[8 + s] * (float)ri.z;

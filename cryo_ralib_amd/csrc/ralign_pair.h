@@ -63,7 +63,7 @@ inline bool build_pair_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     // row stride of a crop: 101 words (the 90 x 90 headline geometry's, as for the engines that run its kernels over a crop: 35.9 ->
     // 35.3 ms per 32 768 at 100 x 100 / ou = 40) when the plan fits with it, else the narrowest conflict-poor one
     const int pst_narrow = f.s_pst;
-    const bool try_wide = f.s_crop && f.s_pst < 101 && !(getenv("RALIGN_CROP_PST101") && atoi(getenv("RALIGN_CROP_PST101")) == 0);
+    const bool try_wide = f.s_crop && f.s_pst < 101 && !(RA_EXP_ENV("RALIGN_CROP_PST101") && ra_atoi(RA_EXP_ENV("RALIGN_CROP_PST101")) == 0);
     bool found = false;
     auto plan_tiles = [&]() {
         for (int nhmax = RP_MAXRZ / 2; nhmax >= 1 && !found; nhmax--) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_pair_kernel(DevGeom g_in, F
                 for (int i = ln; i < g.nring; i += 64) { a += red[24 + 2 * (o * g.nring + i)]; q += red[25 + 2 * (o * g.nring + i)]; }
                 a = wave_sum_dpp(a); q = wave_sum_dpp(q);
                 float avg = 0.f, rsg = 1.f;
-                if (g.mode == RA_MODE_MREF) {
+                if (g.norm_ring) {
                     avg = a * g.inv_nn_weight;
                     rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
                 }

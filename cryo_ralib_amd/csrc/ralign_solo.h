@@ -109,7 +109,7 @@ inline bool build_solo_plan(const Geometry &g, int nref, int n_qtab, int n_inst,
     // ring jobs: longest first, wave w runs jobs rank[w], rank[w] + 16, ..; the waves with the highest ranks have no job in a
     // geometry with fewer than 16 jobs; the transforms of a tile (one per wave) go to the highest ranks.  RALIGN_SOLO_ORDER=1 gives
     // the jobs to the youngest waves and the transforms to the oldest (the SIMDs issue oldest-first).
-    const bool rev = getenv("RALIGN_SOLO_ORDER") && atoi(getenv("RALIGN_SOLO_ORDER")) == 1;
+    const bool rev = RA_EXP_ENV("RALIGN_SOLO_ORDER") && ra_atoi(RA_EXP_ENV("RALIGN_SOLO_ORDER")) == 1;
     for (int w = 0; w < 16; w++) {
         f.s_rank[w] = rev ? 15 - w : w;
         const int c = 15 - f.s_rank[w];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_solo_kernel(DevGeom g_in, F
                 for (int i = ln; i < g.nring; i += 64) { a += red[24 + 2 * i]; q += red[25 + 2 * i]; }
                 a = wave_sum_dpp(a); q = wave_sum_dpp(q);
                 float avg = 0.f, rsg = 1.f;
-                if (g.mode == RA_MODE_MREF) {
+                if (g.norm_ring) {
                     avg = a * g.inv_nn_weight;
                     rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
                 }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
             for (int i = sl0; i < g.nring; i += 64) { a += red[24 + 2 * (os * g.nring + i)]; q += red[25 + 2 * (os * g.nring + i)]; }
             a = wave_sum_dpp(a); q = wave_sum_dpp(q);
             float avg = 0.f, rsg = 1.f;
-            if (g.mode == RA_MODE_MREF) {
+            if (g.norm_ring) {
                 avg = a * g.inv_nn_weight;
                 rsg = __builtin_amdgcn_rsqf((q - a * avg) * g.inv_nn_weight);
             }

@@ -132,8 +132,30 @@ typedef struct ra_result {
     int   shift_idx;      /* index of the winning search offset (y outer, x inner) */
 } ra_result;
 
+/* Hedges for the two choices of the EMAN2 CPU path that the reference tree does not pin (its arithmetic lives in EMAN2 2.31, which
+ * is not part of the reference: SURVEY.md Appendix A.3 / A.4; call sites test_mref_gpu_align.py:1015, 1043-1044):
+ *   interp          Util::alrl_ms's interpolation.  RA_INTERP_BILINEAR (Util::bilinear, EMAN2 2.31; default) or RA_INTERP_QUADRI
+ *                   (Util::quadri, older releases).  Quadri runs through the size-generic kernels (ra_search_path == 2) whatever
+ *                   the geometry -- the particle-resident kernels sample bilinearly only --, and the exact re-evaluation of
+ *                   ra_set_refine follows the option.
+ *   normalize_ring  Util::Normalize_ring between Polar2Dm and Frngs: -1 = by mode (RA_MODE_MREF on, as inside
+ *                   Util.multiref_polar_ali_2d; RA_MODE_REFFREE off, as sp_alignment.ormq), 0 = off, 1 = on.  Every kernel family
+ *                   honours it; the search window rule (reset vs clamp) stays the mode's. */
+#define RA_INTERP_BILINEAR 0
+#define RA_INTERP_QUADRI   1
+typedef struct ra_options {
+    int interp;           /* RA_INTERP_*                      */
+    int normalize_ring;   /* -1 by mode (default), 0 off, 1 on */
+} ra_options;
+
 const char *ra_last_error(void);
 int  ra_create(ra_engine **out, const ra_config *cfg);
+/* ra_create with options (NULL: the defaults = ra_create) */
+int  ra_create_ex(ra_engine **out, const ra_config *cfg, const ra_options *opt);
+/* switch Normalize_ring for subsequent ra_align calls (flag < 0: back to the mode's default); any time, any kernel path */
+int  ra_set_normalize_ring(ra_engine *e, int flag);
+/* the options in force (normalize_ring resolved to 0 / 1) */
+int  ra_get_options(const ra_engine *e, ra_options *opt);
 void ra_destroy(ra_engine *e);
 /* use `hip_stream` (a hipStream_t) for all subsequent work; NULL = default stream */
 int  ra_set_stream(ra_engine *e, void *hip_stream);
