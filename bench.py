@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+N_SIMD = 256 * 4            # MI355X: 256 CUs x 4 SIMDs (matrix-pipe utilisation from SQ_VALU_MFMA_BUSY_CYCLES)
 
 SEARCH_PATHS = {0: "kernel pair", 1: "fused", 2: "generic", 3: "solo / duo / pair (particle-resident, one or two ring buffers next to the image)"}
 
@@ -222,7 +223,9 @@ def parity_block(refs_np, nx, ou, xr, nref, reffree, dev, n=4096):
     from cryo_ralib_amd import api
     from oracle import oracle as orc
     if nx > 130:
-        n = 8
+        # large boxes: 32 per set where the rings reach 1024 samples (configs[4]: the 16-thread oracle takes ~10 s for them), 256
+        # where they stay short (256 x 256 / ou = 36)
+        n = 32 if ou > 64 else 256
     elif nx > 90:
         n = 512           # maxrin 512: ~1 k particles/s on 16 threads at nref = 10
     elif nref > 16:
@@ -275,7 +278,7 @@ def committed_traffic(kernel_substr, workload, geometry=None):
     import glob
     import re
     if geometry is not None and tuple(geometry) != tuple(WORKLOADS[workload][1:5]):
-        return None, None          # the summaries were profiled at the workload's default (nx, ou, xr, nref) only
+        return None, None, None    # the summaries were profiled at the workload's default (nx, ou, xr, nref) only
     natural = lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))]      # r02_v10 after r02_v9
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=natural, reverse=True):
         try:
@@ -293,10 +296,17 @@ def committed_traffic(kernel_substr, workload, geometry=None):
             tot = sum(v["hbm_bytes_per_dispatch_corrected"] * v.get("dispatches", 1) for k, v in pm["kernels"].items()
                       if any(nm in k for nm in names) and "pack" not in k and "hbm_bytes_per_dispatch_corrected" in v)
             if tot > 0:
-                return tot / 14000.0, os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
+                # matrix-pipe utilisation of the dominant kernel from the same passes: SQ_VALU_MFMA_BUSY_CYCLES (summed over the
+                # SIMDs) / (kernel cycles x SIMDs); GRBM_GUI_ACTIVE counts the kernel's cycles once per XCD (8)
+                busy = None
+                ks = [v for k, v in pm["kernels"].items() if kernel_substr in k and "pack" not in k and v.get("GRBM_GUI_ACTIVE")]
+                if ks:
+                    cyc = sum(v["GRBM_GUI_ACTIVE"] * v.get("dispatches", 1) for v in ks) / 8.0
+                    busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * v.get("dispatches", 1) for v in ks) / (cyc * N_SIMD)
+                return tot / 14000.0, os.path.relpath(path, ROOT), busy
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
-    return None, None
+    return None, None, None
 
 
 def run_workload(args, rank, local, world, dev):
@@ -389,12 +399,20 @@ def run_workload(args, rank, local, world, dev):
             k["frac"] = k["achieved_tflops"] / PEAK_F32_TFLOPS
         dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         kern_ms = sum(k["avg_launch_ms"] * k["launches"] for k in kernels.values())
-        traffic_pp, traffic_src = committed_traffic(dom.split("<")[0], args.workload, (nx, ou, xr, nref))
+        traffic_pp, traffic_src, mfma_busy = committed_traffic(dom.split("<")[0], args.workload, (nx, ou, xr, nref))
         whole = (polar_f + ccf_f) * total / world / dt / 1e12
-        # measured HBM rate of the dominant kernel (committed PMC bytes per particle / live launch time) beside its flop rate:
-        # whichever fraction of its peak is larger names the bound (the large-box contraction streams operand panels)
-        hbm_gbps = traffic_pp * per_launch / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9 if traffic_pp is not None else None
+        # Roofline of the dominant kernel, both roofs on ALGORITHMIC work: flops per particle against the f32
+        # matrix peak, bytes per particle (image read for the search + read for rot_shift2D + 24 B of parameters) against HBM; the
+        # larger fraction names the bound.  What the kernel really moves through the L2 <-> fabric boundary (committed PMC bytes,
+        # Infinity Cache hits included) is reported beside it as `traffic` and `hbm_bus_frac` -- a bus utilisation, not a fraction
+        # of useful work: the large-box kernels move ~690 x their algorithmic bytes.
+        alg_bytes = 2 * nx * nx * 4 + 24
+        launch_s = kernels[dom]["avg_launch_ms"] * 1e-3
+        hbm_alg_gbps = alg_bytes * per_launch / launch_s / 1e9 if launch_s > 0 else 0.0
+        hbm_alg_frac = hbm_alg_gbps / PEAK_HBM_GBPS
+        hbm_gbps = traffic_pp * per_launch / launch_s / 1e9 if traffic_pp is not None and launch_s > 0 else None
         hbm_frac = hbm_gbps / PEAK_HBM_GBPS if hbm_gbps is not None else None
+        hbm_bound = hbm_alg_frac > kernels[dom]["frac"]
         what = ("%s: %d synthetic %dx%d particles per GPU, %s, xr=yr=%g, ts=1, ou=%d; step = one %s iteration (search + rot_shift2D + "
                 "class sums + all-reduce + reference update with --function=%s)") % (
                    "BASELINE " + args.config_name if (args.nx, args.ou, args.xr, args.nref) == WORKLOADS[args.workload][1:5] else "custom",
@@ -407,16 +425,22 @@ def run_workload(args, rank, local, world, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "particles_per_gpu": n, "nref": nref, "shifts": S, "live_shift_fraction": live_frac, "parallelism": "dp%d" % world,
                        "search_path": SEARCH_PATHS[path]},
-            "roofline": {"bound": "hbm" if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else "mfma",
-                         "achieved": hbm_gbps if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else kernels[dom]["achieved_tflops"],
-                         "peak": PEAK_HBM_GBPS if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else PEAK_F32_TFLOPS,
-                         "unit": "GB/s" if hbm_frac is not None and hbm_frac > kernels[dom]["frac"] else "TFLOP/s",
-                         "frac": max(kernels[dom]["frac"], hbm_frac or 0.0),
-                         "mfma_frac": kernels[dom]["frac"], "hbm_gbps": hbm_gbps, "hbm_frac": hbm_frac,
+            "roofline": {"bound": "hbm" if hbm_bound else "mfma",
+                         "achieved": hbm_alg_gbps if hbm_bound else kernels[dom]["achieved_tflops"],
+                         "peak": PEAK_HBM_GBPS if hbm_bound else PEAK_F32_TFLOPS,
+                         "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                         "frac": hbm_alg_frac if hbm_bound else kernels[dom]["frac"],
+                         "mfma_frac": kernels[dom]["frac"], "hbm_algorithmic_gbps": hbm_alg_gbps, "hbm_algorithmic_frac": hbm_alg_frac,
+                         "mfma_busy_frac": mfma_busy,
+                         "mfma_busy_what": "matrix-pipe utilisation of this kernel in the committed PMC passes: SQ_VALU_MFMA_BUSY_CYCLES / "
+                                           "(kernel cycles x 1024 SIMDs)",
+                         "hbm_bus_gbps": hbm_gbps, "hbm_bus_frac": hbm_frac,
+                         "hbm_bus_what": "measured bytes through the L2 <-> fabric boundary (traffic) / live launch time / 8 TB/s: bus "
+                                         "utilisation, not a roofline fraction of useful work",
                          "traffic": traffic_pp * per_launch if traffic_pp is not None else None,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE per particle x particles per launch)",
                          "traffic_per_particle": traffic_pp, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_particle": 2 * nx * nx * 4 + 24,
+                         "algorithmic_bytes_per_particle": alg_bytes,
                          "kernel": dom, "flops_per_particle": kernels[dom]["flops_per_particle"],
                          "particles_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_launch_ms"],
                          "launches": kernels[dom]["launches"], "kernels": kernels,
@@ -459,6 +483,15 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        # one line per rank on stderr: which device this rank bound and over what backend, so that the first run on a whole node
+        # diagnoses itself (two ranks on one ordinal, a rank without a GPU, gloo instead of RCCL)
+        import torch.distributed as tdist
+        props = torch.cuda.get_device_properties(local)
+        print("bench.py rank %d/%d: LOCAL_RANK %s -> cuda:%d %s (%d CUs, %.0f GiB), %d device(s) visible, backend %s" % (
+            rank, world, os.environ.get("LOCAL_RANK", "?"), local, torch.cuda.get_device_name(local), props.multi_processor_count,
+            props.total_memory / 2.0 ** 30, torch.cuda.device_count(), tdist.get_backend() if tdist.is_initialized() else "none"),
+            file=sys.stderr, flush=True)
     line = run_workload(args, rank, local, world, dev)
     if world == 1 and args.workload == "mref" and not args.no_others and not args.custom_geometry:
         # the other workloads, measured in the same process right after the headline (short runs, their own parity block, no

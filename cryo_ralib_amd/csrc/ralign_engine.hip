@@ -190,6 +190,7 @@ static bool tiled_wanted(const ra_engine *e)
 static bool solo_wanted(const ra_engine *e)
 {
     if (!e->generic || e->geo.maxrin != 512 || e->geo.nring > 4 * RS_NQ || e->geo.numr[2] < 8 || e->cfg.nref > 127) return false;
+    if (g_force_generic) return false;      // engine options that only the size-generic kernels implement (RALIGN_GENERIC=1 leaves this class alone, as before)
     return !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
 }
 
@@ -566,7 +567,7 @@ static bool resident_expected(const Geometry &g, const ra_config &cfg, bool gene
     if (generic) {
         // search_solo_kernel / search_duo_kernel (setup_solo): rings of 512 samples, image and one ring buffer in the LDS;
         // search_pair_kernel: rings of 256 samples, image and two ring buffers
-        const bool c512 = g.maxrin == 512 && g.nring <= 4 * RS_NQ && !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
+        const bool c512 = g.maxrin == 512 && g.nring <= 4 * RS_NQ && !g_force_generic && !(getenv("RALIGN_SOLO") && atoi(getenv("RALIGN_SOLO")) == 0);
         const bool c256 = g.maxrin == 256 && g.nring <= 4 * RP_NQ && !(getenv("RALIGN_PAIR") && atoi(getenv("RALIGN_PAIR")) == 0) &&
                           !generic_forced();
         if (!(c512 || c256) || g.numr[2] < 8 || cfg.nref > 127) return false;
@@ -2272,7 +2273,7 @@ void run_search(int start, int stop, int mode)
         fprintf(stderr, "libralign_hip: bad index range [%d,%d)\n", start, stop);
         exit(EXIT_FAILURE);
     }
-    L.eng->cfg.mode = mode; L.eng->dg.mode = mode;
+    L.eng->cfg.mode = mode; L.eng->dg.mode = mode; L.eng->dg.norm_ring = mode == RA_MODE_MREF ? 1 : 0;      // (Normalize_ring follows the entry point: multiref_polar_ali_2d | ormq)
     for (int i = 0; i < n; i++) { L.h_state[2 * i] = L.h_param[start + i].shift_x; L.h_state[2 * i + 1] = L.h_param[start + i].shift_y; }
     hip_or_die(hipMemcpy(L.d_state, L.h_state, sizeof(float) * 2 * n, hipMemcpyHostToDevice), "state upload");
     if (ra_align(L.eng, L.d_sbj, n, L.d_state, L.d_res, nullptr)) die("ra_align");

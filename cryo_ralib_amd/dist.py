@@ -68,6 +68,7 @@ class ClassSumBuffer:
         self.extra_f = self.flat[self.nsum + nref:]
         self.counts_i = torch.zeros(nref, dtype=torch.int32, device=device)
         self._gather = None
+        self.last_path = None       # which collective the last all_reduce ran: "ordered" | "all_reduce" | None (one rank, nothing to do)
 
     def zero_(self):
         self.flat.zero_()
@@ -84,6 +85,7 @@ class ClassSumBuffer:
         the same bits on every rank of a run, but the association of the float additions follows RCCL's algorithm, so
         runs on different rank counts / topologies agree to rounding only.  RALIGN_ORDERED_REDUCE=1 / 0 forces either."""
         self.counts_f.copy_(self.counts_i.to(torch.float32))
+        self.last_path = None
         if _collective_needed():
             world = dist.get_world_size()
             # gloo rehearsal of several ranks on one GPU (RALIGN_DIST_BACKEND=gloo): the collective runs on a host copy
@@ -98,8 +100,10 @@ class ClassSumBuffer:
                 work.copy_(self._gather[0])
                 for r in range(1, world):
                     work.add_(self._gather[r])
+                self.last_path = "ordered"
             else:
                 dist.all_reduce(work, op=dist.ReduceOp.SUM)
+                self.last_path = "all_reduce"
             if staged:
                 self.flat.copy_(work)
         self.counts_i.copy_(self.counts_f.round().to(torch.int32))

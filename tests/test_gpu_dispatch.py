@@ -1,0 +1,118 @@
+"""The dispatch boundaries of ra_create, pinned: ra_align picks among seven kernel families by the LDS plan of the geometry
+(include/ralign.h: ra_search_path), and a plan that is off by one ring, one reference or one pixel column lands in another family.
+A FIXED, seeded list -- one case on each side of every boundary (outer radius 36 | 37, 39 | 40, 40 | 41, 62 | 63; references
+14 | 15 and 16 | 17; boxes 93 | 94 and 140 | 141; half-pixel steps, inner radius 3, ring skip 2, both modes) -- asserts WHICH family
+runs and, against the CPU oracle, zero disagreements of the integer assignments, CCF peaks within 1e-4 and the class sums of
+rot_shift2D (whose own kernels change at ~100 and ~140 pixels).  (the random sweeps of scripts/dev/random_sweep.py
+stay a development tool.)
+
+`python tests/test_gpu_dispatch.py` on a GPU box prints the family every case takes (how the table below was filled).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))       # (run as a script: see the last lines)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cryo_ralib_amd import api, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+M, F = api.RA_MODE_MREF, api.RA_MODE_REFFREE
+# search families: (ra_search_path, ra_search_tiled, ra_search_offsets_per_pass)
+FUSED, TILED, PAIRK, SOLO2, PAIR2, GENERIC = (1, 0, 0), (1, 1, 0), (0, 0, 0), (3, 0, 2), (3, 0, 2), (2, 0, 0)
+
+CASES = [
+    # name,                       nx,  ou, ir, rs, xr, yr, ts,  nref, n, mode, family
+    ("box93-ou36",                93,  36, 1, 1, 3, 3, 1.0, 10, 16, M, FUSED),       # whole image next to four ring buffers
+    ("box94-ou36",                94,  36, 1, 1, 3, 3, 1.0, 10, 16, M, FUSED),       # ... a crop of it (tcrop)
+    ("box128-ou36",               128, 36, 1, 1, 3, 3, 1.0, 10, 12, M, FUSED),
+    ("box128-ou37-tight",         128, 37, 1, 1, 3, 3, 1.0, 10, 12, M, FUSED),       # rings 4 floats apart
+    ("box128-ou37-R20",           128, 37, 1, 1, 3, 3, 1.0, 20, 8, M, PAIR2),        # ... which the tiled plan does not fit: pair kernel
+    ("box128-ou39-R8",            128, 39, 1, 1, 3, 3, 1.0, 8, 12, M, FUSED),
+    ("box128-ou40-R8",            128, 40, 1, 1, 3, 3, 1.0, 8, 12, M, PAIR2),        # ou = 40: the one 256-sample radius without four buffers
+    ("box100-ou40-reffree",       100, 40, 1, 1, 3, 3, 1.0, 1, 16, F, PAIR2),
+    ("box100-ou41",               100, 41, 1, 1, 2, 2, 1.0, 4, 10, M, SOLO2),        # first radius with 512-sample rings: duo kernel
+    ("box140-ou62",               140, 62, 1, 1, 2, 2, 1.0, 3, 6, M, SOLO2),         # last radius whose image + ring buffer fit
+    ("box140-ou63",               140, 63, 1, 1, 2, 2, 1.0, 3, 6, M, GENERIC),
+    ("box160-ou70",               160, 70, 1, 1, 2, 2, 1.0, 2, 4, M, GENERIC),       # more than 64 rings
+    ("R14",                       90,  36, 1, 1, 3, 3, 1.0, 14, 16, M, FUSED),
+    ("R15",                       90,  36, 1, 1, 3, 3, 1.0, 15, 16, M, TILED),
+    ("R16-maxrin128",             48,  20, 1, 1, 2, 2, 1.0, 16, 16, M, FUSED),       # no tiled kernel at maxrin 128: fused up to 16,
+    ("R17-maxrin128",             48,  20, 1, 1, 2, 2, 1.0, 17, 16, M, PAIRK),       # ... the kernel pair beyond
+    ("R16-crop",                  128, 36, 1, 1, 3, 3, 1.0, 16, 8, M, TILED),
+    ("R17-crop",                  128, 36, 1, 1, 3, 3, 1.0, 17, 8, M, TILED),
+    ("half-pixel-steps",          90,  36, 1, 1, 1, 1, 0.5, 5, 16, M, FUSED),
+    ("half-pixel-steps-crop",     112, 34, 1, 1, 1, 2, 0.5, 3, 12, M, FUSED),
+    ("half-pixel-steps-duo",      120, 50, 1, 1, 1, 1, 0.5, 2, 6, M, SOLO2),
+    ("inner-radius-3",            90,  36, 3, 1, 3, 3, 1.0, 6, 16, M, FUSED),
+    ("inner-radius-3-pair",       104, 40, 3, 1, 2, 3, 1.0, 3, 10, M, PAIR2),
+    ("ring-skip-2",               90,  36, 1, 2, 3, 2, 1.0, 4, 16, M, FUSED),
+    ("ring-skip-2-reffree",       76,  30, 2, 2, 2, 2, 1.0, 1, 16, F, FUSED),
+    ("ring-skip-2-big",           150, 70, 1, 2, 2, 2, 1.0, 2, 4, M, GENERIC),
+    ("reffree-90-36",             90,  36, 1, 1, 3, 3, 1.0, 1, 24, F, FUSED),
+    ("reffree-crop-128-36",       128, 36, 1, 1, 3, 3, 1.0, 1, 16, F, FUSED),
+    ("reffree-duo-128-60",        128, 60, 1, 1, 2, 2, 1.0, 1, 8, F, SOLO2),
+    ("tiny-rings",                40,  9,  3, 2, 3, 1, 1.0, 1, 12, F, PAIRK),        # rings below 8 samples' worth of the fused jobs
+    ("box140-sums",               140, 36, 1, 1, 3, 3, 1.0, 3, 8, M, FUSED),         # transform_sum_kernel in row bands
+    ("box141-sums",               141, 36, 1, 1, 3, 3, 1.0, 3, 8, M, FUSED),         # transform_sum_tile_kernel
+]
+IDS = [c[0] for c in CASES]
+
+
+def _run(case, check=True):
+    name, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, family = case
+    refs = synth.make_references(nref, nx, ou, seed=1000 + IDS.index(name))
+    parts, _ = synth.make_particles(refs, n, xr, yr, 0.5, shard=IDS.index(name), ou=ou)          # seeded: 2000 + shard
+    eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs)
+    got_family = (eng.search_path, int(eng.search_tiled), eng.search_offsets_per_pass)
+    if not check:
+        eng.close()
+        return got_family
+    rg = orc.rings(ir, ou, rs)
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask, rg)
+    d = np.zeros((n, 2), np.float32)
+    if mode == M:
+        params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8)
+    else:
+        p0 = np.zeros((n, 6), np.float32)
+        params, infos, sums, counts = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, p0, nthreads=8)
+    eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    tp = torch.from_numpy(parts).to(eng.dev)
+    st, res = eng.new_state(n), eng.new_result(n)
+    eng.align(tp, st, res)
+    gs = torch.zeros((nref, 2, nx, nx), device=eng.dev)
+    gc = torch.zeros(nref, dtype=torch.int32, device=eng.dev)
+    eng.transform_accumulate(tp, res, 0, None, gs, gc)
+    eng.sync()
+    r = api.Engine.result_to_numpy(res)
+    out = (got_family, r, st.cpu().numpy(), params, infos, d, gs.cpu().numpy(), gc.cpu().numpy(), sums, counts, mask)
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_dispatch_boundary(case):
+    from test_gpu_parity import compare_search, assert_images_close, default_path_only, _log_flips
+    default_path_only("RALIGN_FUSED", "RALIGN_TILED", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_SOLO", "RALIGN_DUO", "RALIGN_TCROP",
+                      "RALIGN_CROP", "RALIGN_TIGHT_RINGS")
+    got_family, r, st, params, infos, d, gs, gc, sums, counts, mask = _run(case)
+    assert got_family == case[-1], "%s: kernel family %s, expected %s" % (case[0], got_family, case[-1])
+    flips = compare_search(r, st, params, infos, d)
+    assert flips == 0
+    _log_flips("dispatch boundary " + case[0], case[9], flips)
+    assert (gc == np.asarray(counts).reshape(-1)).all()
+    assert_images_close(gs, np.asarray(sums).reshape(gs.shape), mask, 2e-3)
+
+
+if __name__ == "__main__":
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    for c in CASES:
+        fam = _run(c, check=False)
+        print("%-26s family %s %s" % (c[0], fam, "" if fam == c[-1] else "   <-- table says %s" % (c[-1],)), flush=True)

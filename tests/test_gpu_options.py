@@ -62,18 +62,19 @@ def test_normalize_ring_off_in_multireference_mode(nx, ou, xr, nref, n, env, wan
     eng = api.Engine(nx, ou, xr, xr, 1.0, nref, api.RA_MODE_MREF, normalize_ring=False)
     assert (eng.search_path, eng.search_tiled) == want, (eng.search_path, eng.search_tiled)
     assert eng.options == (api.RA_INTERP_BILINEAR, 0)
-    want_off = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d.copy(), nthreads=8, normalize=False)
-    want_on = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d.copy(), nthreads=8, normalize=True)
+    d_off, d_on = d.copy(), d.copy()          # the oracle's loops advance the state in place
+    want_off = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d_off, nthreads=8, normalize=False)
+    want_on = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d_on, nthreads=8, normalize=True)
     # the option matters on this input: without the normalisation the peaks carry the particle's own scale
     assert np.abs(want_off[0][:, 5] - want_on[0][:, 5]).max() > 1e-3 * np.abs(want_on[0][:, 5]).max()
     r, st = _search(eng, parts, refs_n, d)
-    flips = compare_search(r, st, want_off[0], want_off[1], d)
+    flips = compare_search(r, st, want_off[0], want_off[1], d_off)
     _log_flips("normalize_ring off / mref / %d-%d-%d %s" % (nx, ou, nref, env or ""), n, flips)
     # ... and back to the mode's default at run time (ra_set_normalize_ring(-1)): the plain multi-reference search
     eng.set_normalize_ring(None)
     assert eng.options[1] == 1
     r, st = _search(eng, parts, refs_n, d)
-    compare_search(r, st, want_on[0], want_on[1], d)
+    compare_search(r, st, want_on[0], want_on[1], d_on)
     eng.close()
 
 
@@ -97,16 +98,18 @@ def test_normalize_ring_on_in_reference_free_mode(nx, ou, xr, env, want, monkeyp
     eng = api.Engine(nx, ou, xr, xr, 1.0, 1, api.RA_MODE_REFFREE, normalize_ring=True)
     assert eng.search_path == want
     assert eng.options == (api.RA_INTERP_BILINEAR, 1)
-    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d.copy(), nthreads=8, normalize=True)
+    d1 = d.copy()
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d1, nthreads=8, normalize=True)
     r, st = _search(eng, parts, refs_n)
-    flips = compare_search(r, st, params, infos, d)
+    flips = compare_search(r, st, params, infos, d1)
     _log_flips("normalize_ring on / reffree / %d-%d %s" % (nx, ou, env or ""), n, flips)
     # switched off at run time: plain ormq
     eng.set_normalize_ring(False)
     p0 = np.zeros((n, 6), np.float32)
-    params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d.copy(), p0, nthreads=8)
+    d2 = d.copy()
+    params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d2, p0, nthreads=8)
     r, st = _search(eng, parts, refs_n)
-    compare_search(r, st, params, infos, d)
+    compare_search(r, st, params, infos, d2)
     eng.close()
 
 
@@ -127,11 +130,12 @@ def test_quadri_interpolation_against_the_oracle(nx, ou, xr, nref, mode):
     assert np.abs(cref - cref_bil).max() > 1e-4 * np.abs(cref).max()       # the option matters on this input
     d = np.zeros((n, 2), np.float32)
     d[2] = (-1, 1)
+    d_out = d.copy()
     if mode == api.RA_MODE_MREF:
-        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d.copy(), nthreads=8, interp=orc.INTERP_QUADRI)
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d_out, nthreads=8, interp=orc.INTERP_QUADRI)
     else:
         p0 = np.zeros((n, 6), np.float32)
-        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d.copy(), p0, nthreads=8,
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d_out, p0, nthreads=8,
                                                     interp=orc.INTERP_QUADRI)
     eng = api.Engine(nx, ou, xr, xr, 1.0, nref, mode, interp=api.RA_INTERP_QUADRI)
     assert eng.search_path == 2, "quadri runs through the size-generic kernels"
@@ -141,7 +145,7 @@ def test_quadri_interpolation_against_the_oracle(nx, ou, xr, nref, mode):
     got = eng.prepared_references()
     assert np.abs(got - cref).max() < 1e-6 * np.abs(cref).max()
     r, st = _search(eng, parts, refs_n, d)
-    flips = compare_search(r, st, params, infos, d)
+    flips = compare_search(r, st, params, infos, d_out)
     assert_alpha_equal_to_the_ulp(r["alpha"], params[:, 0])
     _log_flips("quadri / %s / %d-%d-%d" % ("mref" if mode == api.RA_MODE_MREF else "reffree", nx, ou, nref), n, flips)
     eng.close()

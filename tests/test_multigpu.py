@@ -225,6 +225,29 @@ t = al.refs.clone()
 rdist.broadcast(t, src=0)
 torch.cuda.synchronize()
 assert torch.equal(t, al.refs)
+# the exchange buffers of BASELINE configs[1] (R = 10, 90 x 90: 648 KB -> rank-ordered all-gather + sum) and configs[4] (R = 100,
+# 256 x 256: 52.4 MB -> the plain all-reduce) with the DEFAULT size rule, device tensors, bit for bit; and the broadcast of the
+# configs[4] reference stack (26 MB)
+os.environ.pop("RALIGN_ORDERED_REDUCE", None)
+dev = torch.device("cuda", 0)
+for nref_b, nx_b, want in ((10, 90, "ordered"), (100, 256, "all_reduce")):
+    buf = rdist.ClassSumBuffer(nref_b, nx_b, dev, extra=2)
+    g = torch.Generator(device=dev); g.manual_seed(5 + nref_b)
+    buf.sums.normal_(generator=g)
+    buf.counts_i.copy_(torch.randint(0, 5000, (nref_b,), generator=g, device=dev, dtype=torch.int32))
+    buf.extra_f.copy_(torch.tensor([1.25, -3.5], device=dev))
+    assert buf.flat.is_cuda and buf.flat.numel() * 4 == (nref_b * 2 * nx_b * nx_b + nref_b + 2) * 4
+    ref_s, ref_c, ref_e = buf.sums.clone(), buf.counts_i.clone(), buf.extra_f.clone()
+    buf.all_reduce()
+    torch.cuda.synchronize()
+    assert buf.last_path == want, (nref_b, nx_b, buf.last_path)
+    assert torch.equal(buf.sums, ref_s) and torch.equal(buf.counts_i, ref_c) and torch.equal(buf.extra_f, ref_e), (nref_b, nx_b)
+    stack = buf.sums[:, 0].contiguous()
+    keep = stack.clone()
+    rdist.broadcast(stack, src=0)
+    torch.cuda.synchronize()
+    assert stack.is_cuda and torch.equal(stack, keep)
+    del buf, stack, keep, ref_s
 x = torch.arange(1024, dtype=torch.float32, device="cuda")
 dist.all_reduce(x)
 assert float(x[1000]) == 1000.0
