@@ -15,6 +15,7 @@
 #include "ralign_geom.h"
 #include "ralign_kernels.h"
 #include "ralign_generic.h"
+#include "ralign_zone.h"
 #include "ralign_fused.h"
 #include "ralign_tiled.h"
 #include "ralign_solo.h"
@@ -104,6 +105,13 @@ struct ra_engine {
     int crop_pst = 0;                   // ... and its row stride in LDS (tcrop_wanted)
     bool xf_generic = false;            // image does not fit LDS in transform_kernel
     float2 *d_zscr = nullptr;           // [g_nblk][maxrin][64 TM TR] CCF spectra scratch of ccf_generic_kernel
+    // polar stage with the image in LDS, ring zone by ring zone (ralign_zone.h); the global-tap kernel stays underneath
+    ZonePlanHost zplan;
+    ZonePlanDev zdev{};
+    bool zones = false;
+    float2 *d_stats_part = nullptr;     // [chunk * nshift_pad + 8][nquad_total] Normalize_ring partial sums of every (entry, ring quad)
+    size_t zone_cap_rows = 0, zone_cap_pix = 0, zone_cap_zones = 0, stats_part_cap = 0;
+    int2 *d_zone_rows = nullptr; int *d_zone_pix = nullptr; ZoneDesc *d_zone_desc = nullptr;
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
     unsigned long long *d_timeline = nullptr;      // profiling builds only (RALIGN_TIMELINE)
     float *d_cls_refspec = nullptr, *d_cls_Bf = nullptr;      // class-resident mode: [cls_cap][lring], [cls_cap][b_floats]
@@ -269,7 +277,7 @@ static int build_device_geometry(ra_engine *e)
     d.nx = g.nx; d.cnx = g.nx / 2 + 1;
     d.nring = g.nring; d.maxrin = g.maxrin; d.lcirc = g.lcirc; d.lring = g.lring; d.nbins = g.nbins;
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
-    d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky;
+    d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky; d.ent_stride = g.nshift_pad;
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
     d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.norm_ring = e->cfg.mode == RA_MODE_MREF ? 1 : 0; d.interp = RA_INTERP_BILINEAR; d.quad_aligned = g.quad_aligned ? 1 : 0;
 #ifdef RALIGN_PROFILE_SWITCHES
@@ -929,6 +937,59 @@ static int setup_solo(ra_engine *e)
     return RA_OK;
 }
 
+// plan and tables of polar_zone_kernel (ralign_zone.h) for an engine that runs the size-generic polar stage: ring zones whose
+// annulus (for every search offset of the window) fits the LDS.  RALIGN_ZONES=0: the global-tap kernel.  Quadri sampling (six
+// taps, periodic) stays with the global-tap kernel.
+static int setup_zones(ra_engine *e)
+{
+    e->zones = false;
+    if (!e->generic || e->fused || e->solo || e->dg.interp != RA_INTERP_BILINEAR) return RA_OK;
+    if (getenv("RALIGN_ZONES") && atoi(getenv("RALIGN_ZONES")) == 0) return RA_OK;
+    const Geometry &g = e->geo;
+    const int S = (int)std::ceil(std::max(g.nkx, g.nky) * g.step - 1e-6);
+    if (!build_zone_plan(g, S, RA_ZONE_NW, e->dg.n_qtab, e->zplan)) return RA_OK;
+    ZonePlanHost &zp = e->zplan;
+    if (const char *ev = RA_EXP_ENV("RALIGN_ZONE_CHUNKS")) { const int v = ra_atoi(ev); if (v >= 1 && v <= 64) zp.nchunk = v; }
+    zp.nchunk = std::min(zp.nchunk, std::max(1, g.nshift));
+    int rc;
+    if ((rc = grow_upload(e, &e->d_zone_rows, &e->zone_cap_rows, zp.rowtab)) || (rc = grow_upload(e, &e->d_zone_pix, &e->zone_cap_pix, zp.pixtab)) ||
+        (rc = grow_upload(e, &e->d_zone_desc, &e->zone_cap_zones, zp.zones))) return rc;
+    const size_t need = ((size_t)e->chunk * e->pad_cap + 8) * zp.nquad_total;
+    if (need > e->stats_part_cap) {
+        if ((rc = dev_grow(e, &e->d_stats_part, need, true))) return rc;
+        e->stats_part_cap = need;
+    }
+    hipError_t he = hipFuncSetAttribute((const void *)polar_zone_kernel<RA_ZONE_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zp.lds_bytes);
+    if (he != hipSuccess) { g_last_error = std::string("hipFuncSetAttribute(zones): ") + hipGetErrorString(he); return RA_ERR_HIP; }
+    e->zdev.zones = e->d_zone_desc; e->zdev.rowtab = e->d_zone_rows; e->zdev.pixtab = e->d_zone_pix;
+    e->zdev.nzone = (int)zp.zones.size(); e->zdev.nchunk = zp.nchunk; e->zdev.nquad_total = zp.nquad_total; e->zdev.max_rows = zp.max_rows;
+    if (getenv("RALIGN_INFO")) {
+        fprintf(stderr, "libralign_hip: zone plan: %d zones, %zu bytes of LDS, %d offset chunks, S = %d:", e->zdev.nzone, zp.lds_bytes, zp.nchunk, S);
+        for (const ZoneDesc &z : zp.zones) fprintf(stderr, " [rings %d..%d: %d px, %d rows]", z.ring0, std::min(z.ring0 + 4 * z.nquad, g.nring) - 1, z.npix, z.nrow);
+        fprintf(stderr, "\n");
+    }
+    e->zones = true;
+    return RA_OK;
+}
+
+// Polar2Dm + Normalize_ring statistics + Frngs of `cn` particles into the A blocks / d_gstats of the size-generic path
+static int launch_generic_polar(ra_engine *e, const float *part, const float *st, int cn, float *Abuf)
+{
+    const Geometry &g = e->geo;
+    if (e->zones) {
+        hipLaunchKernelGGL(polar_zone_kernel<RA_ZONE_NW>, dim3((unsigned)cn * e->zdev.nzone * e->zdev.nchunk), dim3(64 * RA_ZONE_NW), e->zplan.lds_bytes, e->stream,
+                           e->dg, e->zdev, part, st, cn, Abuf, e->d_stats_part);
+        RA_HIP(hipGetLastError());
+        const int nent = cn * g.nshift_pad;
+        hipLaunchKernelGGL(polar_stats_kernel, dim3((nent + 255) / 256), dim3(256), 0, e->stream, e->dg, (const float2 *)e->d_stats_part, nent,
+                           e->zdev.nquad_total, e->d_gstats);
+    } else
+        hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)cn * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
+                           part, st, cn, Abuf, e->d_gstats);
+    RA_HIP(hipGetLastError());
+    return RA_OK;
+}
+
 // tables and buffers of the sub-bin angle refinement (ralign_exact.h): twiddles (float) of the double-precision cos / sin for
 // every power-of-two length, as fftr_q's tables; exact reference spectra; the list of flagged particles of a chunk
 static int setup_refine(ra_engine *e)
@@ -1196,6 +1257,7 @@ static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options
     }
     if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_solo(e))) { ra_destroy(e); return rc; }
+    if ((rc = setup_zones(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_refine(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
@@ -1316,13 +1378,14 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     e->geo.shift_x = g2.shift_x; e->geo.shift_y = g2.shift_y;
     e->geo.nshift_pad = g2.nshift_pad;
     e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
-    e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad;
+    e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad; e->dg.ent_stride = g2.nshift_pad;
     e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
     int rc = setup_fused(e);
     // the solo / duo / pair kernels keep a crop of the image whose side follows the search range: plan again (a wider range at a
     // constant offset count, e.g. xr = 1, ts = 0.5 -> xr = 4, ts = 2, would otherwise let taps leave the crop)
     // (also when the previous window made the plan fall back to the generic kernels: the new one may fit again)
     if (!rc && e->generic && !e->fused && (e->solo || solo_wanted(e) || pair_wanted(e))) rc = setup_solo(e);
+    if (!rc) rc = setup_zones(e);          // the zones' annuli follow the search range
     return rc;
 }
 
@@ -1633,10 +1696,10 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             evc = next_events(e->ev_ccf, e->ev_used_ccf);
         }
         if (evp) RA_HIP(hipEventRecord(evp->first, sp));
-        if (e->generic)
-            hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)cn * ngroup), dim3(RA_GEN_THREADS), e->lds_gpolar, sp, e->dg,
-                               part, (const float *)st, cn, Abuf, e->d_gstats);
-        else
+        if (e->generic) {
+            int rcp = launch_generic_polar(e, part, st, cn, Abuf);
+            if (rcp) return rcp;
+        } else
             hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
@@ -1725,10 +1788,10 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
         int rcw = ensure_unfused_ws(e);
         if (rcw) return rcw;
     }
-    if (e->generic)
-        hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)n * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream,
-                           e->dg, d_particles, d_state, n, e->d_A, e->d_gstats);
-    else
+    if (e->generic) {
+        int rcp = launch_generic_polar(e, d_particles, d_state, n, e->d_A);
+        if (rcp) return rcp;
+    } else
         hipLaunchKernelGGL(polar_fft_kernel, dim3(n), dim3(RA_POLAR_THREADS), e->lds_polar, e->stream, e->dg, d_particles, d_state, n, e->d_A);
     RA_HIP(hipGetLastError());
     float *d_out = nullptr;

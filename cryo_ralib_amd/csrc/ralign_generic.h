@@ -17,6 +17,8 @@
 //   transform_generic_kernel     rot_shift2D reading the image from global memory.
 #pragma once
 
+#include <type_traits>
+
 #include "ralign_kernels.h"
 
 namespace ralign {
@@ -515,18 +517,23 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
                     Ab[ai] = A + (size_t)(2 * min(TM * mt2 + ai, n_mtile - 1) + (r16 >> 3)) * g.a_blk;
 #pragma unroll
                 for (int bi = 0; bi < TR; bi++) Bb[bi] = B + (size_t)min(TR * rt2 + bi, nrtile - 1) * g.LBP * 16;
+                // the last block of reference tiles may hold TR - 1 of them (13 tiles at 100 references = 7 + 6): its own instantiation of
+                // the bin loop, so that the missing tile costs neither operand requests, matrix instructions nor scratch stores (it used to
+                // repeat the tile before it: 1 / 14 of the contraction at configs[4])
+                auto bin_loop = [&](auto tre_c) {
+                constexpr int TRE = decltype(tre_c)::value;
                 for (int k = wave; k < g.nbins; k += NW) {
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
                     const float *pa[TM], *pb[TR];
 #pragma unroll
                     for (int ai = 0; ai < TM; ai++) pa[ai] = Ab[ai] + (size_t)e0 * 8;
 #pragma unroll
-                    for (int bi = 0; bi < TR; bi++) pb[bi] = Bb[bi] + (size_t)e0 * 16;
+                    for (int bi = 0; bi < TRE; bi++) pb[bi] = Bb[bi] + (size_t)e0 * 16;
                     f32x4 acc[TM][TR];
 #pragma unroll
                     for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                        for (int bi = 0; bi < TR; bi++) acc[ai][bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int bi = 0; bi < TRE; bi++) acc[ai][bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     int oa = 0, ob = 0;
                     const int nq = ns >> 2;
                     if (nq > 0) {      // chunks of 4 ring steps, the next chunk's operands in flight while this one multiplies
@@ -534,24 +541,24 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
 #pragma unroll
                         for (int ai = 0; ai < TM; ai++) va[ai] = *reinterpret_cast<const float4 *>(pa[ai] + la * 4);
 #pragma unroll
-                        for (int bi = 0; bi < TR; bi++) vb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + lb * 4);
+                        for (int bi = 0; bi < TRE; bi++) vb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + lb * 4);
                         for (int q = 0; q < nq; q++) {
                             const int step = q + 1 < nq ? 1 : 0;       // the last chunk re-requests itself (discarded)
 #pragma unroll
                             for (int ai = 0; ai < TM; ai++) na[ai] = *reinterpret_cast<const float4 *>(pa[ai] + oa + step * 128 + la * 4);
 #pragma unroll
-                            for (int bi = 0; bi < TR; bi++) nb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + ob + step * 256 + lb * 4);
+                            for (int bi = 0; bi < TRE; bi++) nb[bi] = *reinterpret_cast<const float4 *>(pb[bi] + ob + step * 256 + lb * 4);
 #pragma unroll
                             for (int c = 0; c < 4; c++)
 #pragma unroll
                                 for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                                    for (int bi = 0; bi < TR; bi++)
+                                    for (int bi = 0; bi < TRE; bi++)
                                         acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf4(va[ai], c), rf4(vb[bi], c), acc[ai][bi], 0, 0, 0);
 #pragma unroll
                             for (int ai = 0; ai < TM; ai++) va[ai] = na[ai];
 #pragma unroll
-                            for (int bi = 0; bi < TR; bi++) vb[bi] = nb[bi];
+                            for (int bi = 0; bi < TRE; bi++) vb[bi] = nb[bi];
                             oa += 128; ob += 256;
                         }
                     }
@@ -560,11 +567,11 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
 #pragma unroll
                         for (int ai = 0; ai < TM; ai++) wa[ai] = *reinterpret_cast<const float2 *>(pa[ai] + oa + la * 2);
 #pragma unroll
-                        for (int bi = 0; bi < TR; bi++) wb[bi] = *reinterpret_cast<const float2 *>(pb[bi] + ob + lb * 2);
+                        for (int bi = 0; bi < TRE; bi++) wb[bi] = *reinterpret_cast<const float2 *>(pb[bi] + ob + lb * 2);
 #pragma unroll
                         for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                            for (int bi = 0; bi < TR; bi++) {
+                            for (int bi = 0; bi < TRE; bi++) {
                                 acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ai].x, wb[bi].x, acc[ai][bi], 0, 0, 0);
                                 acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ai].y, wb[bi].y, acc[ai][bi], 0, 0, 0);
                             }
@@ -575,18 +582,18 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
 #pragma unroll
                         for (int ai = 0; ai < TM; ai++) sa[ai] = pa[ai][oa + la];
 #pragma unroll
-                        for (int bi = 0; bi < TR; bi++) sb[bi] = pb[bi][ob + lb];
+                        for (int bi = 0; bi < TRE; bi++) sb[bi] = pb[bi][ob + lb];
 #pragma unroll
                         for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                            for (int bi = 0; bi < TR; bi++)
+                            for (int bi = 0; bi < TRE; bi++)
                                 acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ai], sb[bi], acc[ai][bi], 0, 0, 0);
                     }
                     // a=c1d1 b=c1d2 c=c2d1 d=c2d2 after the 2x2 exchange between the Re/Im column lanes
 #pragma unroll
                     for (int ai = 0; ai < TM; ai++)
 #pragma unroll
-                        for (int bi = 0; bi < TR; bi++) {
+                        for (int bi = 0; bi < TRE; bi++) {
                             const f32x4 c4 = acc[ai][bi];
                             const float s0 = odd ? c4[0] : c4[2], s1 = odd ? c4[1] : c4[3];
                             const float r0 = swap_lane_pair(s0), r1 = swap_lane_pair(s1);
@@ -610,6 +617,9 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
                             }
                         }
                 }
+                };
+                if (TR > 1 && nrtile - TR * rt2 == TR - 1) bin_loop(std::integral_constant<int, (TR > 1 ? TR - 1 : 1)>{});
+                else bin_loop(std::integral_constant<int, TR>{});
             }
             if constexpr (SPLIT) continue;
             __syncthreads();

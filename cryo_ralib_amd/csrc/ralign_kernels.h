@@ -45,6 +45,7 @@ struct DevGeom {
     int nring, maxrin, lcirc, lring, nbins, LB, LBP;
     int last_ring;
     int nshift, nshift_pad, nkx, nky;
+    int ent_stride;               // entries (particle-offsets) per particle in the A blocks, statistics and candidate records: nshift_pad
     float step, xrng, yrng;
     float nn_weight;
     float inv_nn_weight;           // 1 / nn_weight, rounded once on the host

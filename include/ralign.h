@@ -167,7 +167,7 @@ int  ra_lcirc(const ra_engine *e);
  * offsets per pass: rings of up to 256 samples, ou <= 36 -- <= 39 with at most 16 references --, in any box: beyond ~93 pixels over a crop of the
  * image that follows the particle's centre), 0 = polar + contraction kernel pair, 2 = size-generic kernels (rings beyond 512
  * samples, more than 64 rings), 3 = particle-resident search with one or two ring buffers next to the image (search_pair_kernel:
- * ou = 40, and 37 .. 39 with more than 16 references; search_solo_kernel / search_duo_kernel: rings of 512 samples, ou = 41 .. ~62) */
+ * ou = 40, and 37 .. 39 with more than 16 references; search_solo_kernel / search_duo_kernel: rings of 512 samples, ou = 41 .. 60) */
 int  ra_search_path(const ra_engine *e);
 /* with ra_search_path == 3: search offsets per pass, 2 (search_duo_kernel, the default) or 1 (search_solo_kernel); 0 otherwise */
 int  ra_search_offsets_per_pass(const ra_engine *e);

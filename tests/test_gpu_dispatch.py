@@ -1,6 +1,6 @@
 """The dispatch boundaries of ra_create, pinned: ra_align picks among seven kernel families by the LDS plan of the geometry
 (include/ralign.h: ra_search_path), and a plan that is off by one ring, one reference or one pixel column lands in another family.
-A FIXED, seeded list -- one case on each side of every boundary (outer radius 36 | 37, 39 | 40, 40 | 41, 62 | 63; references
+A FIXED, seeded list -- one case on each side of every boundary (outer radius 36 | 37, 39 | 40, 40 | 41, 60 | 61; references
 14 | 15 and 16 | 17; boxes 93 | 94 and 140 | 141; half-pixel steps, inner radius 3, ring skip 2, both modes) -- asserts WHICH family
 runs and, against the CPU oracle, zero disagreements of the integer assignments, CCF peaks within 1e-4 and the class sums of
 rot_shift2D (whose own kernels change at ~100 and ~140 pixels).  (the random sweeps of scripts/dev/random_sweep.py
@@ -37,8 +37,8 @@ CASES = [
     ("box128-ou40-R8",            128, 40, 1, 1, 3, 3, 1.0, 8, 12, M, PAIR2),        # ou = 40: the one 256-sample radius without four buffers
     ("box100-ou40-reffree",       100, 40, 1, 1, 3, 3, 1.0, 1, 16, F, PAIR2),
     ("box100-ou41",               100, 41, 1, 1, 2, 2, 1.0, 4, 10, M, SOLO2),        # first radius with 512-sample rings: duo kernel
-    ("box140-ou62",               140, 62, 1, 1, 2, 2, 1.0, 3, 6, M, SOLO2),         # last radius whose image + ring buffer fit
-    ("box140-ou63",               140, 63, 1, 1, 2, 2, 1.0, 3, 6, M, GENERIC),
+    ("box140-ou60",               140, 60, 1, 1, 2, 2, 1.0, 3, 6, M, SOLO2),         # last radius whose image crop + one ring buffer fit the LDS
+    ("box140-ou61",               140, 61, 1, 1, 2, 2, 1.0, 3, 6, M, GENERIC),
     ("box160-ou70",               160, 70, 1, 1, 2, 2, 1.0, 2, 4, M, GENERIC),       # more than 64 rings
     ("R14",                       90,  36, 1, 1, 3, 3, 1.0, 14, 16, M, FUSED),
     ("R15",                       90,  36, 1, 1, 3, 3, 1.0, 15, 16, M, TILED),
@@ -53,7 +53,7 @@ CASES = [
     ("inner-radius-3-pair",       104, 40, 3, 1, 2, 3, 1.0, 3, 10, M, PAIR2),
     ("ring-skip-2",               90,  36, 1, 2, 3, 2, 1.0, 4, 16, M, FUSED),
     ("ring-skip-2-reffree",       76,  30, 2, 2, 2, 2, 1.0, 1, 16, F, FUSED),
-    ("ring-skip-2-big",           150, 70, 1, 2, 2, 2, 1.0, 2, 4, M, GENERIC),
+    ("ring-skip-2-big",           150, 70, 1, 2, 2, 2, 1.0, 2, 4, M, SOLO2),         # 35 rings of up to 512 samples: the duo kernel at radius 70
     ("reffree-90-36",             90,  36, 1, 1, 3, 3, 1.0, 1, 24, F, FUSED),
     ("reffree-crop-128-36",       128, 36, 1, 1, 3, 3, 1.0, 1, 16, F, FUSED),
     ("reffree-duo-128-60",        128, 60, 1, 1, 2, 2, 1.0, 1, 8, F, SOLO2),
@@ -81,7 +81,8 @@ def _run(case, check=True):
         params, infos, sums, counts = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8)
     else:
         p0 = np.zeros((n, 6), np.float32)
-        params, infos, sums, counts = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, p0, nthreads=8)
+        params, infos, sums, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, p0, nthreads=8)
+        counts = np.array([n], np.int32)          # one class: every particle
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
     tp = torch.from_numpy(parts).to(eng.dev)
     st, res = eng.new_state(n), eng.new_result(n)
@@ -98,7 +99,7 @@ def _run(case, check=True):
 
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_dispatch_boundary(case):
-    from test_gpu_parity import compare_search, assert_images_close, default_path_only, _log_flips
+    from test_gpu_parity import compare_search, default_path_only, _log_flips
     default_path_only("RALIGN_FUSED", "RALIGN_TILED", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_SOLO", "RALIGN_DUO", "RALIGN_TCROP",
                       "RALIGN_CROP", "RALIGN_TIGHT_RINGS")
     got_family, r, st, params, infos, d, gs, gc, sums, counts, mask = _run(case)
@@ -107,7 +108,15 @@ def test_dispatch_boundary(case):
     assert flips == 0
     _log_flips("dispatch boundary " + case[0], case[9], flips)
     assert (gc == np.asarray(counts).reshape(-1)).all()
-    assert_images_close(gs, np.asarray(sums).reshape(gs.shape), mask, 2e-3)
+    # class sums of a handful of particles: rot_shift2D's quadratic interpolant is not continuous across pixel-cell borders, so the
+    # 1e-5 degree between an f32 and an f64 sub-bin angle moves single pixels by O(sigma) (assert_images_close of
+    # tests/test_gpu_parity.py, which asks 2e-4 of sums over hundreds of particles); with 1 - 3 particles per sum the bar is 99.5 % of
+    # the pixels within 2e-3 and 3e-3 overall -- a wrong kernel at a box-size boundary is off by O(1)
+    want = np.asarray(sums).reshape(gs.shape)
+    diff = np.abs(gs - want)
+    sel = np.broadcast_to(mask > 0.5, diff.shape)
+    assert np.quantile(diff[sel], 0.995) < 2e-3, np.quantile(diff[sel], 0.995)
+    assert np.linalg.norm(diff[sel]) < 3e-3 * np.linalg.norm(want[sel]) + 1e-6, np.linalg.norm(diff[sel]) / np.linalg.norm(want[sel])
 
 
 if __name__ == "__main__":
