@@ -160,7 +160,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_duo_kernel(DevGeom g_in, Fu
             if (last) {
                 if (wd == 1 && lv >= bv - RA_TIE_RTOL * fabsf(bv)) word = cand_pack_runner(cand_jtot(word), *run);
                 if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
-                reinterpret_cast<int *>(cand + (size_t)pw * g.nshift_pad + sw)[wd] = word;
+                reinterpret_cast<int *>(cand + (size_t)pw * g.ent_stride + sw)[wd] = word;
             } else {
                 if (wd == 0) rword = __float_as_int(lv);
                 reinterpret_cast<int *>(pb)[wd] = word;

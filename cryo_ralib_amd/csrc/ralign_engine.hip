@@ -277,7 +277,7 @@ static int build_device_geometry(ra_engine *e)
     d.nx = g.nx; d.cnx = g.nx / 2 + 1;
     d.nring = g.nring; d.maxrin = g.maxrin; d.lcirc = g.lcirc; d.lring = g.lring; d.nbins = g.nbins;
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
-    d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky; d.ent_stride = g.nshift_pad;
+    d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky; d.ent_stride = e->generic ? g.nshift : g.nshift_pad;      // generic class: dense entries
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
     d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.norm_ring = e->cfg.mode == RA_MODE_MREF ? 1 : 0; d.interp = RA_INTERP_BILINEAR; d.quad_aligned = g.quad_aligned ? 1 : 0;
 #ifdef RALIGN_PROFILE_SWITCHES
@@ -644,7 +644,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
         int best = chunk;
         double best_pps = 0.0;
         for (int cn = chunk; cn >= std::max(2, chunk - 64); cn -= 2) {
-            const long long n_mtile = ((long long)cn * g.nshift_pad + 7) / 8;
+            const long long n_mtile = ((long long)cn * (generic ? g.nshift : g.nshift_pad) + 7) / 8;      // (the generic class packs its entries densely)
             const long long ntask = ((n_mtile + tm - 1) / tm) * ((nrtile + tr - 1) / tr), slices = (ntask + nblk - 1) / nblk;
             const double pps = (double)cn / (double)slices;
             if (pps > best_pps) { best_pps = pps; best = cn; }
@@ -980,11 +980,11 @@ static int launch_generic_polar(ra_engine *e, const float *part, const float *st
         hipLaunchKernelGGL(polar_zone_kernel<RA_ZONE_NW>, dim3((unsigned)cn * e->zdev.nzone * e->zdev.nchunk), dim3(64 * RA_ZONE_NW), e->zplan.lds_bytes, e->stream,
                            e->dg, e->zdev, part, st, cn, Abuf, e->d_stats_part);
         RA_HIP(hipGetLastError());
-        const int nent = cn * g.nshift_pad;
+        const int nent = cn * e->dg.ent_stride;
         hipLaunchKernelGGL(polar_stats_kernel, dim3((nent + 255) / 256), dim3(256), 0, e->stream, e->dg, (const float2 *)e->d_stats_part, nent,
                            e->zdev.nquad_total, e->d_gstats);
     } else
-        hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)cn * (g.nshift_pad / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
+        hipLaunchKernelGGL(gpolar_kernel(e, false), dim3((unsigned)(((long long)cn * e->dg.ent_stride + 3) / 4)), dim3(RA_GEN_THREADS), e->lds_gpolar, e->stream, e->dg,
                            part, st, cn, Abuf, e->d_gstats);
     RA_HIP(hipGetLastError());
     return RA_OK;
@@ -1378,7 +1378,7 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     e->geo.shift_x = g2.shift_x; e->geo.shift_y = g2.shift_y;
     e->geo.nshift_pad = g2.nshift_pad;
     e->cfg.xrng = xrng; e->cfg.yrng = yrng; e->cfg.step = step;
-    e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad; e->dg.ent_stride = g2.nshift_pad;
+    e->dg.nkx = g2.nkx; e->dg.nky = g2.nky; e->dg.nshift = g2.nshift; e->dg.nshift_pad = g2.nshift_pad; e->dg.ent_stride = e->generic ? g2.nshift : g2.nshift_pad;
     e->dg.step = step; e->dg.xrng = xrng; e->dg.yrng = yrng;
     int rc = setup_fused(e);
     // the solo / duo / pair kernels keep a crop of the image whose side follows the search range: plan again (a wider range at a
@@ -1703,7 +1703,7 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             hipLaunchKernelGGL(polar_fft_kernel, dim3(cn), dim3(RA_POLAR_THREADS), e->lds_polar, sp, e->dg, part, st, cn, Abuf);
         RA_HIP(hipGetLastError());
         if (evp) RA_HIP(hipEventRecord(evp->second, sp));
-        const int n_mtile = (cn * g.nshift_pad + 7) / 8;
+        const int n_mtile = (cn * e->dg.ent_stride + 7) / 8;
         if (evc) RA_HIP(hipEventRecord(evc->first, sp));
         // blocks of TM x 7 tiles when the reference tiles come in sevens (gccf_tm): the B stream is read once per 8 TM particle-offsets
         const bool split = e->generic && g.maxrin == 1024 && !(getenv("RALIGN_GCCF_SPLIT") && atoi(getenv("RALIGN_GCCF_SPLIT")) == 0);

@@ -324,17 +324,19 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
         return;
     }
 
-    const int ngroup = g.nshift_pad / 4;
-    const int p = blockIdx.x / ngroup, grp = blockIdx.x - p * ngroup;
-    if (p >= n) return;
+    // entry of this wave: block blockIdx.x holds entries 4 blockIdx.x .. + 3, entry e = particle e / ent_stride, offset e % ent_stride
+    // (ent_stride = nshift: dense, a block may hold offsets of two particles; an offset index beyond nshift -- padded stride, or the
+    // tail of the chunk -- repeats the last offset)
+    const long long ent = (long long)blockIdx.x * 4 + wave;
+    const int p = (int)min((long long)n - 1, ent / g.ent_stride), slot = wave;
+    const int si = min((int)(ent - (long long)p * g.ent_stride), g.nshift - 1);
     const float *img = images + (size_t)p * npix;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    const int slot = wave, si = min(grp * 4 + slot, g.nshift - 1);
     const float cx = ((float)g.cnx + w.sxi) + g.shift_x[si], cy = ((float)g.cnx + w.syi) + g.shift_y[si];
 
     // one sampling pass: ring FFTs and, in multi-reference mode, the Normalize_ring partial sums (added in ring order)
     float av = 0.f, sq = 0.f;
-    float *blk = out + ((size_t)p * ngroup + grp) * g.a_blk;
+    float *blk = out + (size_t)blockIdx.x * g.a_blk;
     if (g.quad_aligned) {
         // Panels with ring quads aligned across bins (maxrin <= 1024): the spectra of rings 4c .. 4c+3 stay in registers
         // (bin k = lane + 64 t, t < 9) and leave as whole float4 panel pieces, Re row and Im row of this offset slot --
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
             avg = av / nn;
             rsg = 1.0f / sqrtf((sq - av * av / nn) / nn);
         }
-        stats[((size_t)p * ngroup + grp) * 4 + slot] = make_float2(avg, rsg);
+        stats[(size_t)blockIdx.x * 4 + slot] = make_float2(avg, rsg);
     }
 }
 

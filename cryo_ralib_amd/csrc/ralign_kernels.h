@@ -45,7 +45,8 @@ struct DevGeom {
     int nring, maxrin, lcirc, lring, nbins, LB, LBP;
     int last_ring;
     int nshift, nshift_pad, nkx, nky;
-    int ent_stride;               // entries (particle-offsets) per particle in the A blocks, statistics and candidate records: nshift_pad
+    int ent_stride;               // entries (particle-offsets) per particle in the A blocks, statistics and candidate records: nshift_pad; the
+                                  // size-generic path packs them densely (nshift: 121 instead of 124 at configs[4], no padding offsets in the contraction)
     float step, xrng, yrng;
     float nn_weight;
     float inv_nn_weight;           // 1 / nn_weight, rounded once on the host
@@ -988,9 +989,10 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
     const int m = blockIdx.x;                  // particle * nshift + shift
     const int p = m / g.nshift, sft = m - p * g.nshift;
     if (p >= n) return;
-    const float *blk = A + ((size_t)p * (g.nshift_pad / 4) + (sft >> 2)) * g.a_blk;
+    const size_t ent = (size_t)p * g.ent_stride + sft;          // entry of this particle-offset: block ent >> 2, slot ent & 3
+    const float *blk = A + (ent >> 2) * g.a_blk;
     float *dst = out + (size_t)m * g.lcirc;
-    const int row0 = (sft & 3) * 2;
+    const int row0 = (int)(ent & 3) * 2;
     for (int i = 0; i < g.nring; i++) {
         const int nlen = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
         for (int j = threadIdx.x; j < nlen; j += blockDim.x) {
@@ -1000,7 +1002,7 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
             const int2 ap = g.ent_apos[e];
             float v = blk[ap.x + (row0 + comp) * ap.y];
             if (stats) {
-                const float2 st = stats[(size_t)p * g.nshift_pad + sft];
+                const float2 st = stats[(size_t)p * g.ent_stride + sft];
                 if (j == 0) v -= st.x * (float)nlen;
                 v *= st.y;
             }
@@ -1491,7 +1493,7 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__r
                 rec.bs2 = bs; rec.ref2 = runner - 1; rec.mirror2 = (jword >> 21) & 1; rec.jtot2 = (jword >> 22) & 0x3ff;
                 rec.rt2 = (brt << 16) | brt;
             } else if (tie_rec) {
-                const CandT *c = cand + ((size_t)p * g.nshift_pad + s2) * nrtile + rt2;
+                const CandT *c = cand + ((size_t)p * g.ent_stride + s2) * nrtile + rt2;
                 rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = cand_jtot(c->jtot);
                 rec.rt2 = (rt2 << 16) | brt;          // scan order of the two records: (offset, reference tile)
             }
@@ -1516,7 +1518,7 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
         if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
         for (int rt = 0; rt < nrtile; rt++) {
-            const CandT *c = cand + ((size_t)p * g.nshift_pad + s) * nrtile + rt;
+            const CandT *c = cand + ((size_t)p * g.ent_stride + s) * nrtile + rt;
             const float v = c->val;
             if (v >= peak) { second = peak; s2 = bs; rt2 = brt; peak = v; best = *c; bs = s; brt = rt; }
             else if (v >= second) { second = v; s2 = s; rt2 = rt; }
@@ -1543,7 +1545,7 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
         const int s = li / nrtile;
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
         if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
-        const float v = cand[(size_t)p * g.nshift_pad * nrtile + li].val;
+        const float v = cand[(size_t)p * g.ent_stride * nrtile + li].val;
         if (v >= bv) { sv = bv; si = bi; bv = v; bi = li; }
         else if (v >= sv) { sv = v; si = li; }
     }
@@ -1562,7 +1564,7 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
     CandT best; best.val = -1.0e23f; best.jtot = 1; best.refmir = 0;
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
     int bs = 0, brt = 0;
-    if (bi >= 0) { best = cand[(size_t)p * g.nshift_pad * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
+    if (bi >= 0) { best = cand[(size_t)p * g.ent_stride * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
     const int s2 = si >= 0 ? si / nrtile : -1, rt2 = si >= 0 ? si - s2 * nrtile : 0;
     finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr);
 }

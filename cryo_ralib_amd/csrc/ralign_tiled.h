@@ -278,7 +278,7 @@ __global__ __launch_bounds__(RF_THREADS) void search_tiled_kernel(DevGeom g_in, 
                 if (wd == 0 || wd >= 3) word = __float_as_int(__int_as_float(word) * red[12 + o]);     // val, t7[]
                 int io = i0r, so = s0r + o;
                 if (so >= SPP) { so -= SPP; io++; }
-                reinterpret_cast<int *>(cand + (size_t)particle_of(io) * g.nshift_pad + so)[wd] = word;
+                reinterpret_cast<int *>(cand + (size_t)particle_of(io) * g.ent_stride + so)[wd] = word;
             } else {
                 reinterpret_cast<int *>(pbest + o)[wd] = word;
             }

@@ -50,12 +50,7 @@ struct ZonePlanHost {
     bool ok = false;
 };
 
-// LDS of polar_zone_kernel: [nw][maxrin] float2 transform buffers | [maxrin] twiddles | [n_qtab] (sin, cos) tables |
-// [max_rows + 2] row table | image
-inline size_t zone_lds_overhead(int nw, int maxrin, int n_qtab, int max_rows)
-{
-    return ((size_t)nw * maxrin + maxrin + n_qtab + (max_rows + 2)) * sizeof(float2);
-}
+inline size_t zone_lds_overhead(int nw, int maxrin, int n_qtab, int max_rows);
 
 // Cuts the rings into zones (from the outside in) whose pixel sets fit `budget` floats.  The pixel set of a group of rings is
 // found by stamping: sample (dx, dy) of a ring under a sampling centre c + (ox, oy), |ox|, |oy| <= S, c within [0, 1) of the
@@ -65,7 +60,7 @@ inline bool build_zone_plan(const Geometry &g, int S, int nw, int n_qtab, ZonePl
 {
     zp = ZonePlanHost();
     zp.S = S; zp.nw = nw;
-    if (!g.quad_aligned || g.nring < 4 || g.maxrin > 2048) return false;
+    if (!g.quad_aligned || g.nring < 4 || g.maxrin > 1024 || g.maxrin < 64) return false;
     const int Hmax = g.last_ring + S + 6, W = 2 * Hmax + 1;
     const int nquad = (g.nring + 3) / 4;
     const size_t lds_total = 160 * 1024 - 1024;
@@ -169,26 +164,136 @@ inline bool build_zone_plan(const Geometry &g, int S, int nw, int n_qtab, ZonePl
     return zp.ok;
 }
 
+// waves per workgroup.  8: 256 registers per wave, no spills, 3 zones at configs[4] -- measured 9.8 ms per chunk of 330 particles against
+// 13.3 ms with 12 waves (170 registers: 27 spilled) and 14.2 ms with 16 (scripts/dev/zone_nw.sh; the global-tap kernel: 13.25 ms)
+#ifndef RA_ZONE_NW
 #define RA_ZONE_NW 8
+#endif
+#define RA_ZONE_WB 544        // float2 per wave: the 512 padded slots of the register transforms (slot sl at sl + (sl >> 4))
+
+// LDS of polar_zone_kernel: [nw][RA_ZONE_WB] float2 wave buffers | [maxrin] twiddles | [n_qtab] (sin, cos) tables | [64] W_64^{n1 k0} |
+// [max_rows + 2] row table | [2 nbins + 2] ints bin_offp, bin_first | image
+inline size_t zone_lds_overhead(int nw, int maxrin, int n_qtab, int max_rows)
+{
+    return ((size_t)nw * RA_ZONE_WB + maxrin + n_qtab + 64 + (max_rows + 2) + (maxrin / 2 + 2)) * sizeof(float2);
+}
+
+// Util::bilinear at 1-based (xo, yo) with the four taps out of a zone's LDS image: bilinear_1b's operations in its order (no
+// contraction; v_fract_f32 is x - (float)(int)x for the positive coordinates here, exactly), so the sample equals
+// polar_generic_kernel's bit for bit wherever that kernel's taps lie inside the image
+// (the row table holds BYTE offsets into the image: tap address = (column left of the centre ? offL : offR) + 4 column)
+__device__ __forceinline__ float zone_bilinear(const float *img_s, const int2 *rt_s, int cxi, int cyi_mH, float xo, float yo)
+{
+#pragma clang fp contract(off)
+    const int ix = (int)xo, iy = (int)yo;
+    const float ydif = __builtin_amdgcn_fractf(yo), xdif = __builtin_amdgcn_fractf(xo);
+    const int rx = ix - cxi;
+    const int2 *rp = rt_s + (iy - cyi_mH);
+    const int2 t0 = rp[0], t1 = rp[1];
+    const bool left = rx < 0;
+    const char *ib = reinterpret_cast<const char *>(img_s) + 4 * rx;
+    const float *q0 = reinterpret_cast<const float *>(ib + (left ? t0.x : t0.y)), *q1 = reinterpret_cast<const float *>(ib + (left ? t1.x : t1.y));
+    const float f00 = q0[0], f10 = q0[1], f01 = q1[0], f11 = q1[1];          // (4-byte aligned pairs: ds_read2_b32)
+    return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+}
+
+__device__ __forceinline__ float2 *zone_slot(float2 *wb, int sl) { return wb + sl + (sl >> 4); }
+
+// One ring of NR = 128 R1 samples (1024 | 512) by one wave, everything between the taps and the spectrum in registers:
+//   samples      lane l holds z[l + 64 k2] = (x[2 (l + 64 k2)], x[2 (l + 64 k2) + 1]), k2 < R1 -- the four quadrants of a table
+//                position share its (sin, cos) read and radius multiply (alrl_ms's mirroring, as ring_pos)
+//   transform    H = 64 R1 points as R1 x 8 x 8: DFT-R1 over k2 in registers, twiddle W_H^{n0 l}; the 64-point transforms of
+//                the R1 rows as two DFT-8 with a transpose through the wave's LDS buffer each (k = 64 k2 + 8 k1 + k0,
+//                n = n0 + R1 n1 + 8 R1 n2); lane 8 n0 + n1 ends with Z[m + 8 R1 n2], n2 < 8, m = n0 + R1 n1 (lanes < 8 R1)
+//   split step   X_k from (Z_k, Z_{H-k}): the partner values sit in lane(8 R1 - m) at register 7 - n2 (ds_bpermute); lane 0 (m = 0)
+//                pairs inside itself and also holds the Nyquist term X_H
+// X[t] = X_{m + 8 R1 t}; nyq = X_H (lane 0).  av / sq += the ring's Normalize_ring sums (weighted once per ring).
+template <int R1>
+__device__ __forceinline__ void zone_ring_fast(const DevGeom &g, const float *img_s, const int2 *rt_s, const float2 *tw_s, const float2 *qt,
+                                               const float2 *twb_s, float2 *wb, int lane, int cxi, int cyi_mH, float cx, float cy, float fr,
+                                               float wt, float &av, float &sq, float2 (&X)[8], float &nyq, bool no_taps)
+{
+    constexpr int H = 64 * R1, NB = R1 == 8 ? 2 : 1;        // table positions per lane and sample parity: 2 l + u (+ 128)
+    static_assert(R1 == 8 || R1 == 4, "rings of 1024 or 512 samples");
+    float2 v[R1];
+    float a = 0.f, qq = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float2 sc = qt[2 * lane + u + 128 * b];
+            const float x = __fmul_rn(sc.x, fr), y = __fmul_rn(sc.y, fr);
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int k2 = R1 == 8 ? 2 * qd + b : qd;
+                const float px = qd == 0 ? x : qd == 1 ? y : qd == 2 ? -x : -y;
+                const float py = qd == 0 ? y : qd == 1 ? -x : qd == 2 ? -y : x;
+                const float sv = no_taps ? px : zone_bilinear(img_s, rt_s, cxi, cyi_mH, __fadd_rn(px, cx), __fadd_rn(py, cy));
+                if (u == 0) v[k2].x = sv; else v[k2].y = sv;
+                a += sv; qq += sv * sv;
+            }
+        }
+    av += a * wt; sq += qq * wt;
+    // ---- stage 1: DFT-R1 over k2, twiddle W_H^{n0 lane}
+    Dft<-1, R1>::run(v);
+    const int sh = g.lg_maxrin - (R1 == 8 ? 9 : 8);
+#pragma unroll
+    for (int n0 = 1; n0 < R1; n0++) v[n0] = cmul(v[n0], tw_s[(n0 * lane) << sh]);
+#pragma unroll
+    for (int n0 = 0; n0 < R1; n0++) *zone_slot(wb, 64 * n0 + lane) = v[n0];
+    wave_lds_sync();
+    float2 z[8];
+    const bool act = lane < 8 * R1;
+    const int lc = act ? lane : 0;
+    // ---- stage 2: lane = 8 n0 + k0: DFT-8 over k1, twiddle W_64^{n1 k0}, back into the slots it read
+    {
+        const int n0 = lc >> 3, k0 = lc & 7;
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++) z[k1] = *zone_slot(wb, 64 * n0 + 8 * k1 + k0);
+        Dft<-1, 8>::run(z);
+#pragma unroll
+        for (int n1 = 1; n1 < 8; n1++) z[n1] = cmul(z[n1], twb_s[n1 * 8 + k0]);
+        if (act) {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) *zone_slot(wb, 64 * n0 + 8 * n1 + k0) = z[n1];
+        }
+    }
+    wave_lds_sync();
+    // ---- stage 3: lane = 8 n0 + n1: DFT-8 over k0 (8 consecutive slots) -> Z[m + 8 R1 n2]
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = *zone_slot(wb, 8 * lc + k0);
+    Dft<-1, 8>::run(z);
+    wave_lds_sync();                         // the buffer is free for the next ring (or the re-mapping of this one)
+    // ---- split step
+    const int m = (lc >> 3) + R1 * (lc & 7);
+    const int mp = (8 * R1 - m) & (8 * R1 - 1);                     // partner residue; m = 0 pairs with itself
+    const int pl = 8 * (mp & (R1 - 1)) + mp / R1;
+    const int lsh = g.lg_maxrin - (R1 == 8 ? 10 : 9);              // twiddle e^{-2 pi i k / NR} = tw[k << lsh]
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        // Z_{H-k}, k = m + 8 R1 t: register 7 - t of the partner lane; lane 0: its own register 8 - t (t = 0: Z_H = Z_0)
+        float2 zm;
+        zm.x = __shfl(z[7 - t].x, pl); zm.y = __shfl(z[7 - t].y, pl);
+        if (m == 0) zm = z[(8 - t) & 7];
+        const int k = m + 8 * R1 * t;
+        v2f xk, xm;
+        vsplit_pair(to_v(z[t]), to_v(zm), to_v(tw_s[k << lsh]), xk, xm);
+        X[t] = to_f2(xk);
+    }
+    nyq = z[0].x - z[0].y;
+    if (m == 0) X[0] = make_float2(z[0].x + z[0].y, 0.f);
+    (void)H;
+}
 
 // Polar2Dm (bilinear) + Normalize_ring partial sums + Frngs of the particles of a chunk, image taps from LDS.
 //   grid = n * nzone * nchunk workgroups of NW waves: block -> (particle, zone, chunk of search offsets)
 //   out: the A blocks of polar_generic_kernel (entry e = p * ent_stride + s lives in block e >> 2, slot e & 3)
 //   stats_part [n * ent_stride][nquad_total] {sum w v, sum w v^2} of every (entry, ring quad)
-// Util::bilinear at 1-based (xo, yo) with the four taps out of a zone's LDS image: bilinear_1b's operations in its order (no
-// contraction), so the sample equals polar_generic_kernel's bit for bit wherever that kernel's taps lie inside the image
-__device__ __forceinline__ float zone_bilinear(const float *img_s, const int2 *rt_s, int cxi, int cyi_mH, float xo, float yo)
-{
-#pragma clang fp contract(off)
-    const int ix = (int)xo, iy = (int)yo;
-    const float ydif = yo - iy, xdif = xo - ix;
-    const int rx = ix - cxi, ry = iy - cyi_mH;
-    const int2 t0 = rt_s[ry], t1 = rt_s[ry + 1];
-    const int a0 = (rx < 0 ? t0.x : t0.y) + rx, a1 = (rx < 0 ? t1.x : t1.y) + rx;
-    const float f00 = img_s[a0], f10 = img_s[a0 + 1], f01 = img_s[a1], f11 = img_s[a1 + 1];
-    return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
-}
-
+// Work item of a wave = (search offset, ring quad).  Rings of 1024 / 512 samples go through zone_ring_fast; shorter ones are
+// sampled into the wave's buffer and transformed there (wave_fft, split_bin).  The lanes of a quad store the bins of ITS longest
+// ring's register layout (bins m + 8 R1 t of lane 8 n0 + n1; natural order, lane + 64 t, when the quad's rings have at most 256
+// samples); a ring of another length inside the quad (one quad at configs[4]: rings 80 .. 83) passes its spectrum through the
+// wave's buffer in natural order.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlanDev zp, const float *__restrict__ images,
                                                              const float *__restrict__ state, int n, float *__restrict__ out,
@@ -196,12 +301,14 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
 {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *bx = reinterpret_cast<float2 *>(lds) + (size_t)wave * g.maxrin;     // two buffers of maxrin/2 complex
-    float2 *by = bx + g.maxrin / 2;
-    float2 *tw_s = reinterpret_cast<float2 *>(lds) + (size_t)NW * g.maxrin;
+    float2 *wb = reinterpret_cast<float2 *>(lds) + (size_t)wave * RA_ZONE_WB;
+    float2 *tw_s = reinterpret_cast<float2 *>(lds) + (size_t)NW * RA_ZONE_WB;
     float2 *qt_s = tw_s + g.maxrin;
-    int2 *rt_s = reinterpret_cast<int2 *>(qt_s + g.n_qtab);
-    float *img_s = reinterpret_cast<float *>(rt_s + zp.max_rows + 2);
+    float2 *twb_s = qt_s + g.n_qtab;
+    int2 *rt_s = reinterpret_cast<int2 *>(twb_s + 64);
+    int *bo_s = reinterpret_cast<int *>(rt_s + zp.max_rows + 2);          // bin_offp [nbins + 1]
+    int *bf_s = bo_s + g.nbins + 1;                                        // bin_first [nbins]
+    float *img_s = reinterpret_cast<float *>(reinterpret_cast<float2 *>(bo_s) + (g.maxrin / 2 + 2));
 
     const int per_p = zp.nzone * zp.nchunk;
     const int p = blockIdx.x / per_p, rem = blockIdx.x - p * per_p, zi = rem / zp.nchunk, ch = rem - zi * zp.nchunk;
@@ -213,8 +320,11 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
 
     for (int i = tid; i < g.maxrin; i += 64 * NW) tw_s[i] = g.tw[i];
     for (int i = tid; i < g.n_qtab; i += 64 * NW) qt_s[i] = g.qtab[i];
-    for (int i = tid; i <= zd.nrow; i += 64 * NW) rt_s[i] = zp.rowtab[zd.row_off + i];
-    {
+    for (int i = tid; i < 64; i += 64 * NW) twb_s[i] = g.tw[((i >> 3) * (i & 7) * (g.maxrin >> 6)) & (g.maxrin - 1)];      // W_64^{n1 k0}
+    for (int i = tid; i <= zd.nrow; i += 64 * NW) { const int2 t = zp.rowtab[zd.row_off + i]; rt_s[i] = make_int2(4 * t.x, 4 * t.y); }
+    for (int i = tid; i <= g.nbins; i += 64 * NW) bo_s[i] = g.bin_offp[i];
+    for (int i = tid; i < g.nbins; i += 64 * NW) bf_s[i] = g.bin_first[i];
+    if (!RA_DBG(g, 4096)) {
         const float *img = images + (size_t)p * g.nx * g.nx;
         const int *pt = zp.pixtab + zd.pix_off;
         // eight pixels per thread in flight; out-of-image sources (only offsets outside the particle's window read them) are clamped
@@ -235,23 +345,11 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
     }
     __syncthreads();
 
-    // panel addressing of the lane's bins k = lane + 64 t (polar_generic_kernel, quad_aligned branch)
-    constexpr int T = 9;
-    int base0[T], i0al[T], nsk[T];
-    float rns[T];
-#pragma unroll
-    for (int t = 0; t < T; t++) {
-        const int k = min(lane + 64 * t, g.nbins - 1);
-        nsk[t] = (g.bin_offp[k + 1] - g.bin_offp[k]) >> 2;
-        rns[t] = 1.0f / (float)nsk[t];
-        base0[t] = g.bin_offp[k] * 8;
-        i0al[t] = g.bin_first[k] & ~3;
-    }
-
     const int per = (g.nshift + zp.nchunk - 1) / zp.nchunk;
     const int s_lo = ch * per, s_hi = min(g.nshift, s_lo + per);
     const int nitem = max(0, s_hi - s_lo) * zd.nquad;
-    float *xr = reinterpret_cast<float *>(bx);
+    const int cyi_mH = cyi - zd.H;
+    const bool no_taps = RA_DBG(g, 512);
     for (int it = wave; it < nitem; it += NW) {
         const int sl = it / zd.nquad, q = it - sl * zd.nquad;
         const int s = s_lo + sl, c4 = zd.ring0 + 4 * q;
@@ -259,56 +357,104 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
         float *blk = out + (e >> 2) * g.a_blk;
         const int slot = (int)(e & 3);
         const float cx = cxf + g.shift_x[s], cy = cyf + g.shift_y[s];
+        // bins of the lane: the register layout of the quad's longest ring
+        const int Lq = g.ringinfo[min(c4 + 3, g.nring - 1)].z, hq = Lq >> 1;
+        const int R1q = Lq >> 7;                                             // 8 | 4 for the register layouts
+        const bool regmap = Lq >= 512;
+        const int mq = (lane >> 3) + R1q * (lane & 7);
+        const bool lane_on = !regmap || lane < 8 * R1q;
+        auto bin_of = [&](int t) { return regmap ? mq + 8 * R1q * t : lane + 64 * t; };      // t < 8
         float av = 0.f, sq = 0.f;
-        float2 xq[4][T];
+        float2 xq[4][8];
+        float nyq[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = c4 + r;
-            if (i < g.nring) {        // uniform
-                const int4 ri = g.ringinfo[i];
-                const int nlen = ri.z, h = nlen >> 1, lt = nlen >> 2, lgl = 31 - __clz(lt);
-                const float wt = g.ringw[i], fr = (float)ri.y;
-                const float2 *qt = qt_s + ri.w;
+            nyq[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; t++) xq[r][t] = make_float2(0.f, 0.f);
+            if (i >= g.nring) continue;        // uniform
+            const int4 ri = g.ringinfo[i];
+            const int nlen = ri.z, h = nlen >> 1;
+            const float wt = g.ringw[i], fr = (float)ri.y;
+            const float2 *qt = qt_s + ri.w;
+            if (nlen == 1024 || nlen == 512) {
+                float2 X[8];
+                float ny;
+                if (nlen == 1024) zone_ring_fast<8>(g, img_s, rt_s, tw_s, qt, twb_s, wb, lane, cxi, cyi_mH, cx, cy, fr, wt, av, sq, X, ny, no_taps);
+                else zone_ring_fast<4>(g, img_s, rt_s, tw_s, qt, twb_s, wb, lane, cxi, cyi_mH, cx, cy, fr, wt, av, sq, X, ny, no_taps);
+                if (nlen == Lq) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) xq[r][t] = X[t];
+                    nyq[r] = ny;
+                } else {
+                    // a shorter ring inside the quad: spectrum to the wave's buffer in natural order, read back in the quad's layout
+                    const int R1r = nlen >> 7, mr = (lane >> 3) + R1r * (lane & 7);
+                    if (lane < 8 * R1r) {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) wb[mr + 8 * R1r * t] = X[t];
+                        if (lane == 0) wb[h] = make_float2(ny, 0.f);
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const int k = bin_of(t);
+                        xq[r][t] = (lane_on && k <= h) ? wb[min(k, h)] : make_float2(0.f, 0.f);
+                    }
+                    wave_lds_sync();
+                }
+            } else {
+                // rings of up to 256 samples: samples -> wave buffer, Stockham transform between its two halves, split step by index
+                float *xr = reinterpret_cast<float *>(wb);
                 float a = 0.f, qq = 0.f;
                 for (int j0 = lane; j0 < nlen; j0 += 256) {
                     float sv[4];
+                    const int lt = nlen >> 2, lgl = 31 - __clz(lt);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int j = min(j0 + 64 * u, nlen - 1);
                         const float2 d = ring_pos(qt, lt, lgl, fr, j);
-                        sv[u] = RA_DBG(g, 512) ? d.x : zone_bilinear(img_s, rt_s, cxi, cyi - zd.H, d.x + cx, d.y + cy);      // bilinear_1b(img, nx, d.x + cx, d.y + cy)
+                        sv[u] = no_taps ? d.x : zone_bilinear(img_s, rt_s, cxi, cyi_mH, d.x + cx, d.y + cy);      // bilinear_1b(img, nx, d.x + cx, d.y + cy)
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++)
                         if (j0 + 64 * u < nlen) {
                             xr[j0 + 64 * u] = sv[u];
-                            a += sv[u] * wt; qq += sv[u] * sv[u] * wt;
+                            a += sv[u]; qq += sv[u] * sv[u];
                         }
                 }
-                av += a; sq += qq;
+                av += a * wt; sq += qq * wt;
                 wave_lds_sync();
-                const float2 *Z = (h >= 2 && !RA_DBG(g, 256)) ? wave_fft<-1>(bx, by, h, tw_s, g.maxrin, lane) : bx;
+                const float2 *Z = (h >= 2) ? wave_fft<-1>(wb, wb + 128, h, tw_s, g.maxrin, lane) : wb;
 #pragma unroll
-                for (int t = 0; t < T; t++) {
-                    const int k = lane + 64 * t;
-                    xq[r][t] = RA_DBG(g, 2048) ? Z[k & 255] : k <= h ? split_bin(Z, k, h, tw_s[k * (g.maxrin / nlen)]) : make_float2(0.f, 0.f);
+                for (int t = 0; t < 8; t++) {
+                    const int k = bin_of(t);
+                    xq[r][t] = (lane_on && k <= h) ? split_bin(Z, min(k, h), h, tw_s[min(k, h) * (g.maxrin / nlen)]) : make_float2(0.f, 0.f);
                 }
+                if (regmap) nyq[r] = 0.f;          // (a ring of <= 256 samples has no bin hq >= 256 ... except h == hq, excluded: Lq >= 512 > nlen)
                 wave_lds_sync();
-            } else {
-#pragma unroll
-                for (int t = 0; t < T; t++) xq[r][t] = make_float2(0.f, 0.f);
             }
         }
+        // panel pieces: 16 bytes of four rings per (bin, Re | Im)
+        if (!RA_DBG(g, 1024)) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const int k = lane + 64 * t;
-            if (k < g.nbins && c4 >= i0al[t]) {
-                const int j0 = c4 - i0al[t];
-                const int kk = (int)(((float)j0 + 0.5f) * rns[t]), s4 = j0 - kk * nsk[t];      // j0 / ns, exact (see align_ring_quads)
-                float *dst = blk + base0[t] + 8 * slot + (s4 >> 2) * 128 + kk * 32;
-                if (RA_DBG(g, 1024) && xq[0][t].x != 1.2345f) continue;          // profiling: no panel stores
-                *reinterpret_cast<float4 *>(dst) = make_float4(xq[0][t].x, xq[1][t].x, xq[2][t].x, xq[3][t].x);
-                *reinterpret_cast<float4 *>(dst + 4) = make_float4(xq[0][t].y, xq[1][t].y, xq[2][t].y, xq[3][t].y);
+            for (int t = 0; t < 9; t++) {
+                // t = 8: the Nyquist bin hq of the register layouts (lane 0); natural layout: bin lane + 64 t of t < 8 covers everything
+                const int k = t < 8 ? bin_of(t) : hq;
+                const bool on = t < 8 ? (lane_on && k < g.nbins && (regmap ? k < hq : k <= hq)) : (regmap && lane == 0);
+                if (!on) continue;
+                const int bo = bo_s[k], nsk = (bo_s[k + 1] - bo) >> 2, i0al = bf_s[k] & ~3;
+                if (c4 < i0al) continue;
+                const int j0 = c4 - i0al;
+                const int kk = j0 / nsk, s4 = j0 - kk * nsk;
+                float *dst = blk + bo * 8 + 8 * slot + (s4 >> 2) * 128 + kk * 32;
+                if (t < 8) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(xq[0][t & 7].x, xq[1][t & 7].x, xq[2][t & 7].x, xq[3][t & 7].x);
+                    *reinterpret_cast<float4 *>(dst + 4) = make_float4(xq[0][t & 7].y, xq[1][t & 7].y, xq[2][t & 7].y, xq[3][t & 7].y);
+                } else {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(nyq[0], nyq[1], nyq[2], nyq[3]);
+                    *reinterpret_cast<float4 *>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         av = wave_sum_dpp(av); sq = wave_sum_dpp(sq);      // fixed order: reproducible
