@@ -1036,20 +1036,27 @@ static int setup_refine(ra_engine *e)
     return RA_OK;
 }
 
-// finalize + (flagged particles) refine of one chunk: `cand` records with `nrtile` per particle-offset
+// finalize + (flagged particles) refine of one chunk: `cand` records with `nrtile` per particle-offset.
+// Chunked paths (kernel pair, size-generic kernels) call it with deferred = 1 for every chunk -- the flagged particles of the whole
+// call collect in ONE list, indexed from the call's first particle (p_base = the chunk's offset; st / res / part are the chunk's) --
+// and once more with deferred = 2 behind the last chunk (st / res / part the call's, cn its particle count): refine_winner_kernel
+// handles one image per workgroup and a chunk flags ~10 of its 330 particles at configs[4], so a launch per chunk left the GPU to ten
+// workgroups for 0.94 ms, 2.6 % of the iteration; one launch per call fills it.
 static int finalize_and_refine(ra_engine *e, const CandT *cand, int nrtile, int cn, float *st, ra_result *res, const float *part,
-                               const float *refx, const int *cls)
+                               const float *refx, const int *cls, int deferred = 0, int p_base = 0)
 {
     const bool refine = e->refine_ok && e->refine_thr != 0.f && refx;
-    if (refine) RA_HIP(hipMemsetAsync(e->d_rcount, 0, sizeof(int), e->stream));
+    if (refine && deferred == 0) RA_HIP(hipMemsetAsync(e->d_rcount, 0, sizeof(int), e->stream));
+    if (deferred != 2) {
     if ((size_t)e->geo.nshift * nrtile >= 256)          // many records per particle: one wave each
         hipLaunchKernelGGL(finalize_wave_kernel, dim3(cn), dim3(64), 0, e->stream, e->dg, cand, nrtile, cn, st, res,
-                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
+                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr, p_base);
     else
         hipLaunchKernelGGL(finalize_kernel, dim3((cn + 127) / 128), dim3(128), 0, e->stream, e->dg, cand, nrtile, cn, st, res, (const float *)e->d_cs,
-                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr);
+                           refine ? e->d_rlist : (RefineRec *)nullptr, e->d_rcount, e->refine_thr, p_base);
     RA_HIP(hipGetLastError());
-    if (refine) {
+    }
+    if (refine && deferred != 1) {
         const int grid = std::min(cn, e->refine_grid);
         if (e->refine_gm)
             hipLaunchKernelGGL(refine_winner_kernel<true>, dim3(grid), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
@@ -1684,6 +1691,16 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
         int rcw = ensure_unfused_ws(e);
         if (rcw) return rcw;
     }
+    // the flagged particles of every chunk collect in one list; one refine launch behind the last chunk (finalize_and_refine)
+    const bool refine_once = e->refine_ok && e->refine_thr != 0.f && e->d_refx && n > e->chunk;
+    if (refine_once) {
+        if (n > e->rlist_cap) {
+            int rcg = dev_grow(e, &e->d_rlist, (size_t)n, false);
+            if (rcg) return rcg;
+            e->rlist_cap = n;
+        }
+        RA_HIP(hipMemsetAsync(e->d_rcount, 0, sizeof(int), e->stream));
+    }
     for (int start = 0; start < n; start += e->chunk) {
         const int cn = std::min(e->chunk, n - start);
         float *Abuf = e->d_A;
@@ -1750,7 +1767,11 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
                                e->nrtile, e->cfg.nref, Cbuf);
         RA_HIP(hipGetLastError());
         if (evc) RA_HIP(hipEventRecord(evc->second, sp));
-        int rcf = finalize_and_refine(e, Cbuf, e->nrtile, cn, st, d_result + start, part, e->d_refx, nullptr);
+        int rcf = finalize_and_refine(e, Cbuf, e->nrtile, cn, st, d_result + start, part, e->d_refx, nullptr, refine_once ? 1 : 0, start);
+        if (rcf) return rcf;
+    }
+    if (refine_once) {
+        int rcf = finalize_and_refine(e, nullptr, e->nrtile, n, d_state, d_result, d_particles, e->d_refx, nullptr, 2, 0);
         if (rcf) return rcf;
     }
     (void)ngroup;

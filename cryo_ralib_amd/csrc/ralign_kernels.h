@@ -1447,7 +1447,7 @@ struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirro
 __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__restrict__ cand, int nrtile, int p, const Window &w,
                                               CandT best, int bs, int brt, float second, int s2, int rt2, float *__restrict__ state,
                                               ra_result *__restrict__ res, RefineRec *__restrict__ rlist, int *__restrict__ rcount,
-                                              float rthr)
+                                              float rthr, int p_base = 0)
 {
     const float peak = best.val;
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
@@ -1487,7 +1487,8 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__r
         const int runner = (jword >> 13) & 0xff;          // another reference of the winning offset within the tolerance
         if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner) {
             RefineRec rec;
-            rec.p = p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi;
+            // (p_base: index of the chunk's first particle when the list spans a whole call)
+            rec.p = p_base + p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi;
             rec.bs2 = -1; rec.ref2 = 0; rec.mirror2 = 0; rec.jtot2 = 1; rec.rt2 = brt;
             if (runner) {
                 rec.bs2 = bs; rec.ref2 = runner - 1; rec.mirror2 = (jword >> 21) & 1; rec.jtot2 = (jword >> 22) & 0x3ff;
@@ -1504,7 +1505,7 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__r
 
 __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
                                 float *__restrict__ state, ra_result *__restrict__ res,
-                                const float *__restrict__ cs, RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
+                                const float *__restrict__ cs, RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr, int p_base = 0)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -1524,7 +1525,7 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
             else if (v >= second) { second = v; s2 = s; rt2 = rt; }
         }
     }
-    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr);
+    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr, p_base);
 }
 
 // the same with one WAVE per particle, for paths that leave many records per particle (the generic kernels: 121 offsets x 13
@@ -1533,7 +1534,7 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
 // sequential ">=" scan -- of equal peaks the later record wins -- and lane 0 finishes the particle
 __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const CandT *__restrict__ cand, int nrtile, int n,
                                                            float *__restrict__ state, ra_result *__restrict__ res,
-                                                           RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr)
+                                                           RefineRec *__restrict__ rlist, int *__restrict__ rcount, float rthr, int p_base = 0)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
     int bs = 0, brt = 0;
     if (bi >= 0) { best = cand[(size_t)p * g.ent_stride * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
     const int s2 = si >= 0 ? si / nrtile : -1, rt2 = si >= 0 ? si - s2 * nrtile : 0;
-    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr);
+    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr, p_base);
 }
 
 // ------------------------------------------------------------------------------------------
