@@ -178,7 +178,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=7.0):
+def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=10.0):
     """the CPU restatement of the EMAN2 path (oracle/, kind "port") timed on this host's cores on a bounded sample
     of the same workload: all cores (OpenMP over particles), and one thread (what one EMAN2 MPI rank does)."""
     import numpy as np

@@ -72,6 +72,21 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
 
 
+def test_shipped_library_reads_only_the_documented_switches():
+    """experiment switches (LDS strides, job orders, block shapes) exist only in builds with
+    -DRALIGN_PROFILE_SWITCHES; the shipped binary holds exactly the RALIGN_* names README.md documents as user-facing"""
+    with open(api.LIB_PATH, "rb") as f:
+        blob = f.read()
+    names = sorted(set(m.decode() for m in re.findall(rb"RALIGN_[A-Z0-9_]+", blob)))
+    documented = ["RALIGN_ATOMIC_SUMS", "RALIGN_CROP", "RALIGN_DUO", "RALIGN_FUSED", "RALIGN_GCCF_SPLIT", "RALIGN_GCCF_TM",
+                  "RALIGN_GENERIC", "RALIGN_GRID", "RALIGN_INFO", "RALIGN_PACK", "RALIGN_PAIR", "RALIGN_REFINE", "RALIGN_SOLO",
+                  "RALIGN_SOLO_JOBS", "RALIGN_TCROP", "RALIGN_TIGHT_RINGS", "RALIGN_TILED", "RALIGN_XSUM", "RALIGN_XTILE", "RALIGN_ZONES"]
+    assert names == documented, sorted(set(names) ^ set(documented))
+    readme = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "README.md")).read()
+    for n in documented:
+        assert "`%s" % n in readme, n
+
+
 def test_struct_layouts_match_reference_abi():
     # cuda/gpu_aln_common.h:62-83: 8 x 4 B and 24 B
     assert ctypes.sizeof(api.AlignConfig) == 32
