@@ -110,6 +110,7 @@ def _worker_threshold(rank, world, port, out_dir):
         del calls[:]
         buf.all_reduce()
         res[name] = (list(calls), float(buf.flat[0]), int(buf.counts_i[0]))
+        assert buf.last_path == ("ordered" if name == "small" else "all_reduce"), (name, buf.last_path)       # what the RCCL test reads
     np.save(os.path.join(out_dir, "t%d.npy" % rank), np.array([res["small"][1], res["small"][2], res["large"][1], res["large"][2],
                                                                  res["small"][0] == ["gather"], res["large"][0] == ["reduce"]], float))
     torch.distributed.destroy_process_group()

@@ -58,6 +58,9 @@ CASES = [
     ("reffree-crop-128-36",       128, 36, 1, 1, 3, 3, 1.0, 1, 16, F, FUSED),
     ("reffree-duo-128-60",        128, 60, 1, 1, 2, 2, 1.0, 1, 8, F, SOLO2),
     ("tiny-rings",                40,  9,  3, 2, 3, 1, 1.0, 1, 12, F, PAIRK),        # rings below 8 samples' worth of the fused jobs
+    ("generic-ir3-rs2",           176, 80, 3, 2, 2, 2, 1.0, 2, 4, M, GENERIC),       # ring zones over every second ring from radius 3 (polar_zone_kernel)
+    ("generic-half-pixel",        150, 66, 1, 1, 1, 1, 0.5, 2, 4, M, GENERIC),       # ... fractional sampling centres
+    ("generic-reffree",           160, 70, 1, 1, 2, 2, 1.0, 1, 4, F, GENERIC),       # ... without Normalize_ring
     ("box140-sums",               140, 36, 1, 1, 3, 3, 1.0, 3, 8, M, FUSED),         # transform_sum_kernel in row bands
     ("box141-sums",               141, 36, 1, 1, 3, 3, 1.0, 3, 8, M, FUSED),         # transform_sum_tile_kernel
 ]
@@ -117,6 +120,31 @@ def test_dispatch_boundary(case):
     sel = np.broadcast_to(mask > 0.5, diff.shape)
     assert np.quantile(diff[sel], 0.995) < 2e-3, np.quantile(diff[sel], 0.995)
     assert np.linalg.norm(diff[sel]) < 3e-3 * np.linalg.norm(want[sel]) + 1e-6, np.linalg.norm(diff[sel]) / np.linalg.norm(want[sel])
+
+
+def test_reset_shifts_replans_the_ring_zones():
+    """the annuli of polar_zone_kernel follow the search range: an engine of the size-generic class created for xr = 3 searches a
+    window of xr = 1 after reset_shifts (zones planned again for the narrower range) and agrees with the oracle there"""
+    from test_gpu_parity import compare_search, default_path_only
+    default_path_only("RALIGN_GENERIC", "RALIGN_SOLO", "RALIGN_ZONES")
+    nx, ou, nref, n = 150, 66, 2, 5
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 1, 1, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask, rg)
+    eng = api.Engine(nx, ou, 3, 3, 1.0, nref, M)
+    assert eng.search_path == 2
+    eng.reset_shifts(1, 1, 1.0)
+    assert eng.num_shifts == 9
+    d = np.zeros((n, 2), np.float32)
+    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, 1, 1, 1.0, d, nthreads=8)
+    eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    st, res = eng.new_state(n), eng.new_result(n)
+    eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+    eng.sync()
+    assert compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d) == 0
+    eng.close()
 
 
 if __name__ == "__main__":
