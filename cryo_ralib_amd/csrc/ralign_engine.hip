@@ -1739,8 +1739,9 @@ extern "C" int ra_align(ra_engine *e, const float *d_particles, int n, float *d_
             const int nwg = TMv >= 4 ? e->g_nblk / 2 : e->g_nblk;           // 4 x 7 blocks: one workgroup per CU (256 registers)
             const int nblk = nwg * gccf_blocks_per_wg();                    // blocks per slice (the scratch holds them)
             auto launch = [&](auto ccfk, auto ifftk, int task0, int nt, int grid2) {
-                hipLaunchKernelGGL(ccfk, dim3(std::min(nt, nwg)), dim3(RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
+                hipLaunchKernelGGL(ccfk, dim3(std::min(nt, nwg)), dim3(RA_EXP_ENV("RALIGN_GCCF_WAVES") ? 64 * std::max(1, std::min(8, ra_atoi(RA_EXP_ENV("RALIGN_GCCF_WAVES")))) : RA_GCCF_THREADS), 0, sp, e->dg, Abuf, e->d_B, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
                                    e->d_zscr, e->g_P, (const float2 *)e->d_gstats, (const float *)e->d_gcdc, task0, nt);
+                if (!(e->dg.dbg & 1))          // (profiling builds, RALIGN_DEBUG=1: the contraction alone)
                 hipLaunchKernelGGL(ifftk, dim3(grid2), dim3(RA_GCCF_THREADS), lds2, sp, e->dg, n_mtile, e->nrtile, e->cfg.nref, Cbuf,
                                    (const float2 *)e->d_zscr, (const float2 *)e->d_gstats, task0, nt);
             };

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
                 // repeat the tile before it: 1 / 14 of the contraction at configs[4])
                 auto bin_loop = [&](auto tre_c) {
                 constexpr int TRE = decltype(tre_c)::value;
-                for (int k = wave; k < g.nbins; k += NW) {
+                for (int k = wave; k < g.nbins; k += (SPLIT ? (int)(blockDim.x >> 6) : NW)) {      // (SPLIT: profiling builds may launch fewer waves, scripts/dev/gccf_waves.sh)
                     const int e0 = g.bin_offp[k], ns = (g.bin_offp[k + 1] - e0) >> 2;
                     const float *pa[TM], *pb[TR];
 #pragma unroll
