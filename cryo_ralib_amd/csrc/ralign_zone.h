@@ -194,7 +194,15 @@ __device__ __forceinline__ float zone_bilinear(const float *img_s, const int2 *r
     const char *ib = reinterpret_cast<const char *>(img_s) + 4 * rx;
     const float *q0 = reinterpret_cast<const float *>(ib + (left ? t0.x : t0.y)), *q1 = reinterpret_cast<const float *>(ib + (left ? t1.x : t1.y));
     const float f00 = q0[0], f10 = q0[1], f01 = q1[0], f11 = q1[1];          // (4-byte aligned pairs: ds_read2_b32)
+#ifdef RA_ZONE_LERP
+    // the interpolant as two fused lerps, row pair first (bilinear_pad of the particle-resident kernels: 4 instructions instead of 9,
+    // within 1 ulp of the taps of Util::bilinear's own operation order)
+    const v2f r0 = {f00, f10}, r1 = {f01, f11};
+    const v2f gg = __builtin_elementwise_fma((v2f){ydif, ydif}, r1 - r0, r0);
+    return __builtin_fmaf(xdif, gg.y - gg.x, gg.x);
+#else
     return f00 + ydif * (f01 - f00) + xdif * (f10 - f00 + ydif * (f11 - f10 - f01 + f00));
+#endif
 }
 
 __device__ __forceinline__ float2 *zone_slot(float2 *wb, int sl) { return wb + sl + (sl >> 4); }

@@ -16,17 +16,18 @@ from test_gpu_parity import compare_search     # noqa: E402
 
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-big = len(sys.argv) > 3 and sys.argv[3] == "big"
+big = len(sys.argv) > 3 and sys.argv[3] in ("big", "huge")
+huge = len(sys.argv) > 3 and sys.argv[3] == "huge"      # boxes of 140 .. 230 pixels, ou 61 .. 100: the size-generic class (polar_zone_kernel)
 for case in range(ncase):
     xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
-    nx = int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
+    nx = int(rng.integers(140, 231)) if huge else int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
     oumax = (nx - 1) // 2 - max(xr, yr) - 1
-    ou = int(rng.integers(24, min(78, oumax) + 1)) if big else int(rng.integers(8, min(40, oumax) + 1))
+    ou = int(rng.integers(61, min(100, oumax) + 1)) if huge else int(rng.integers(24, min(78, oumax) + 1)) if big else int(rng.integers(8, min(40, oumax) + 1))
     ir = int(rng.integers(1, 4)); rs = int(rng.integers(1, 3))
     ts = float(rng.choice([1.0, 1.0, 0.5]))
     mode = api.RA_MODE_MREF if rng.random() < 0.7 else api.RA_MODE_REFFREE
-    nref = (int(rng.integers(1, 61)) if big else int(rng.integers(1, 17))) if mode == api.RA_MODE_MREF else 1
-    n = int(rng.integers(3, 9)) if big else int(rng.integers(3, 20))
+    nref = (int(rng.integers(1, 21)) if huge else int(rng.integers(1, 61)) if big else int(rng.integers(1, 17))) if mode == api.RA_MODE_MREF else 1
+    n = int(rng.integers(2, 6)) if huge else int(rng.integers(3, 9)) if big else int(rng.integers(3, 20))
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, yr, 0.25, ou=ou)
     rg = orc.rings(ir, ou, rs)
