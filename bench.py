@@ -201,7 +201,7 @@ def cpu_baseline(refs_np, nx, ou, xr, yr, nref, reffree, target_seconds=10.0):
         return time.perf_counter() - t
 
     rate = n0 / run(parts, threads)
-    n1 = int(max(n0, min(20000, rate * target_seconds)))
+    n1 = int(max(n0, min(40000, rate * target_seconds)))
     big = np.concatenate([parts] * ((n1 + n0 - 1) // n0))[:n1]
     runs = sorted(run(big, threads) for _ in range(1 if nx > 128 else 3))
     dt = runs[len(runs) // 2]
