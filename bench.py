@@ -346,7 +346,7 @@ def run_workload(args, rank, local, world, dev):
         step()
     al.engine.kernel_time(True)          # arm HIP-event timing of the hot kernels on the engine's stream
     rdist.barrier(); torch.cuda.synchronize()
-    solo = al.engine.search_path == 3
+    solo = al.engine.search_skips_offsets          # the kernels evaluate in-window offsets only: count the work that is asked for AND done
     live = torch.zeros((), device=dev)
     if solo:
         live_offsets(al.state, nx, ou, xr, xr, 1.0, reffree)      # first use of these torch operators (their one-off set-up) stays outside the timed region
@@ -369,8 +369,9 @@ def run_workload(args, rank, local, world, dev):
         polar_f, ccf_f, S, L, M = algorithmic_flops(nx, ou, xr, xr, 1.0, nref)
         live_frac = 1.0
         if solo:
-            # the solo kernel computes the in-window offsets only (a box that is tight around the rings -- ou = 60 in 128 pixels --
-            # leaves shifted particles a fraction of their 49 offsets): count the work that was asked for AND done
+            # the solo / duo / pair kernels and the size-generic kernels (live-offset lists) compute the in-window offsets only (a box
+            # that is tight around the rings -- ou = 60 in 128 pixels, ou = 120 in 256 -- leaves shifted particles a fraction of their
+            # offsets): count the work that was asked for AND done
             live_frac = float(live.item()) / args.steps / S
             polar_f *= live_frac; ccf_f *= live_frac
         per_launch = n * args.steps / max(n_a, 1)

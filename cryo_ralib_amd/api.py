@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "ra_debug_spectra", "ra_transform_accumulate", "ra_update_references", "ra_normalize_particles", "ra_sync", "ra_kernel_time",
     "ra_fsc_len", "ra_class_fsc", "ra_last_class_fsc", "ra_fit_tanh", "ra_class_averages", "ra_filter_references",
     "ra_state_from_params_dev", "ra_class_fsc_fit", "ra_filter_references_dev", "ra_last_refine_count",
-    "ra_create_ex", "ra_set_normalize_ring", "ra_get_options",
+    "ra_create_ex", "ra_set_normalize_ring", "ra_get_options", "ra_search_skips_offsets",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load_library(path=None):
     L.ra_lcirc.argtypes = [vp]
     L.ra_search_path.argtypes = [vp]
     L.ra_search_tiled.argtypes = [vp]
+    L.ra_search_skips_offsets.argtypes = [vp]
     L.ra_search_offsets_per_pass.argtypes = [vp]
     L.ra_set_nomirror.argtypes = [vp, ctypes.c_int]
     L.ra_set_mask.argtypes = [vp, vp]
@@ -319,6 +320,11 @@ class Engine:
     @property
     def search_tiled(self):
         return bool(self.lib.ra_search_tiled(self.handle))
+
+    @property
+    def search_skips_offsets(self):
+        """True when the search evaluates the in-window offsets of a particle only (ra_search_skips_offsets)"""
+        return bool(self.lib.ra_search_skips_offsets(self.handle))
 
     @property
     def search_offsets_per_pass(self):

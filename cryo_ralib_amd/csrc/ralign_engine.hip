@@ -112,6 +112,7 @@ struct ra_engine {
     float2 *d_stats_part = nullptr;     // [chunk * nshift_pad + 8][nquad_total] Normalize_ring partial sums of every (entry, ring quad)
     size_t zone_cap_rows = 0, zone_cap_pix = 0, zone_cap_zones = 0, stats_part_cap = 0;
     int2 *d_zone_rows = nullptr; int *d_zone_pix = nullptr; ZoneDesc *d_zone_desc = nullptr;
+    int *d_ent_base = nullptr, *d_ent_total = nullptr;      // live-offset lists of a chunk (size-generic path): [chunk + 1] entry ranges, their total
     float2 *d_gstats = nullptr;         // [chunk * nshift_pad + 8] Normalize_ring {avg, 1/sigma} of every particle-offset (generic path)
     unsigned long long *d_timeline = nullptr;      // profiling builds only (RALIGN_TIMELINE)
     float *d_cls_refspec = nullptr, *d_cls_Bf = nullptr;      // class-resident mode: [cls_cap][lring], [cls_cap][b_floats]
@@ -972,10 +973,31 @@ static int setup_zones(ra_engine *e)
     return RA_OK;
 }
 
+// Live-offset lists (round 6): the size-generic kernels work on the IN-WINDOW search offsets of every particle only -- what
+// Util.multiref_polar_ali_2d / ormq loop over (search_range) -- instead of computing all of them and masking in finalize_kernel.  A tight
+// box (configs[4]: ou + xr = 125 of 127) leaves a particle that sits 5 pixels off centre 8 of its 11 offsets per axis: 19 % less work
+// in all three stages once the states have moved.  The entries of a chunk then depend on its states: live_scan_kernel lays the ranges
+// out on the device, the kernels read the total there, the host launches for the full lists (empty slices return at once).
+// RALIGN_LIVE_OFFSETS=0: every offset of the list, masked later (as the particle-resident 90 x 90 kernels do).
+static int update_live_mode(ra_engine *e)
+{
+    e->dg.ent_base = nullptr; e->dg.ent_total = nullptr;
+    if (!e->generic || e->fused || e->solo) return RA_OK;
+    if (getenv("RALIGN_LIVE_OFFSETS") && atoi(getenv("RALIGN_LIVE_OFFSETS")) == 0) return RA_OK;
+    int rc;
+    if (!e->d_ent_base && ((rc = dev_alloc(e, &e->d_ent_base, (size_t)e->chunk + 8, true)) || (rc = dev_alloc(e, &e->d_ent_total, 4, true)))) return rc;
+    e->dg.ent_base = e->d_ent_base; e->dg.ent_total = e->d_ent_total;
+    return RA_OK;
+}
+
 // Polar2Dm + Normalize_ring statistics + Frngs of `cn` particles into the A blocks / d_gstats of the size-generic path
 static int launch_generic_polar(ra_engine *e, const float *part, const float *st, int cn, float *Abuf)
 {
     const Geometry &g = e->geo;
+    if (e->dg.ent_base) {
+        hipLaunchKernelGGL(live_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->dg, st, cn, e->d_ent_base, e->d_ent_total);
+        RA_HIP(hipGetLastError());
+    }
     if (e->zones) {
         hipLaunchKernelGGL(polar_zone_kernel<RA_ZONE_NW>, dim3((unsigned)cn * e->zdev.nzone * e->zdev.nchunk), dim3(64 * RA_ZONE_NW), e->zplan.lds_bytes, e->stream,
                            e->dg, e->zdev, part, st, cn, Abuf, e->d_stats_part);
@@ -1265,6 +1287,7 @@ static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options
     if ((rc = setup_fused(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_solo(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_zones(e))) { ra_destroy(e); return rc; }
+    if ((rc = update_live_mode(e))) { ra_destroy(e); return rc; }
     if ((rc = setup_refine(e))) { ra_destroy(e); return rc; }
     e->atomic_sums = getenv("RALIGN_ATOMIC_SUMS") && atoi(getenv("RALIGN_ATOMIC_SUMS")) != 0;
     *out = e;
@@ -1348,6 +1371,7 @@ extern "C" int ra_last_refine_count(ra_engine *e)
 extern "C" int ra_search_tiled(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->fused && e->tiled) ? 1 : 0; }
 extern "C" int ra_search_path(const ra_engine *e) { return !e ? RA_ERR_ARG : e->solo ? 3 : e->fused ? 1 : e->generic ? 2 : 0; }
 extern "C" int ra_search_offsets_per_pass(const ra_engine *e) { return !e ? RA_ERR_ARG : !e->solo ? 0 : (e->duo || e->pair) ? 2 : 1; }
+extern "C" int ra_search_skips_offsets(const ra_engine *e) { return !e ? RA_ERR_ARG : (e->solo || e->dg.ent_base) ? 1 : 0; }
 extern "C" int ra_num_shifts(const ra_engine *e) { return e ? e->geo.nshift : RA_ERR_ARG; }
 extern "C" int ra_maxrin(const ra_engine *e) { return e ? e->geo.maxrin : RA_ERR_ARG; }
 extern "C" int ra_lcirc(const ra_engine *e) { return e ? e->geo.lcirc : RA_ERR_ARG; }
@@ -1393,6 +1417,7 @@ extern "C" int ra_reset_shifts(ra_engine *e, float xrng, float yrng, float step)
     // (also when the previous window made the plan fall back to the generic kernels: the new one may fit again)
     if (!rc && e->generic && !e->fused && (e->solo || solo_wanted(e) || pair_wanted(e))) rc = setup_solo(e);
     if (!rc) rc = setup_zones(e);          // the zones' annuli follow the search range
+    if (!rc) rc = update_live_mode(e);     // (the plan may have moved between the particle-resident and the size-generic kernels)
     return rc;
 }
 
@@ -1820,7 +1845,7 @@ extern "C" int ra_debug_spectra(ra_engine *e, const float *d_particles, int n, c
     const size_t cnt = (size_t)n * g.nshift * g.lcirc;
     RA_HIP(hipMalloc((void **)&d_out, cnt * sizeof(float)));
     hipLaunchKernelGGL(unpack_spectra_kernel, dim3(n * g.nshift), dim3(256), 0, e->stream, e->dg, e->d_A, n, e->d_numr, d_out,
-                       e->generic ? (const float2 *)e->d_gstats : (const float2 *)nullptr);
+                       e->generic ? (const float2 *)e->d_gstats : (const float2 *)nullptr, d_state);
     hipError_t he = hipStreamSynchronize(e->stream);
     if (he == hipSuccess) he = hipMemcpy(h_out, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d_out);

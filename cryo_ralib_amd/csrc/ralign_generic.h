@@ -328,10 +328,19 @@ __global__ __launch_bounds__(RA_GEN_THREADS, 3) void polar_generic_kernel(DevGeo
     // (ent_stride = nshift: dense, a block may hold offsets of two particles; an offset index beyond nshift -- padded stride, or the
     // tail of the chunk -- repeats the last offset)
     const long long ent = (long long)blockIdx.x * 4 + wave;
-    const int p = (int)min((long long)n - 1, ent / g.ent_stride), slot = wave;
-    const int si = min((int)(ent - (long long)p * g.ent_stride), g.nshift - 1);
+    int p = (int)min((long long)n - 1, ent / g.ent_stride);
+    const int slot = wave;
+    int si = min((int)(ent - (long long)p * g.ent_stride), g.nshift - 1);
+    if (g.ent_base) {          // live-offset lists: entry -> (particle, j-th offset of its window); entries past the end repeat the last one
+        const int el = (int)min(ent, (long long)*g.ent_total - 1);
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (g.ent_base[mid] <= el) lo = mid; else hi = mid; }
+        p = lo;
+        si = el - g.ent_base[p];          // position in the window: turned into the list index below
+    }
     const float *img = images + (size_t)p * npix;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
+    if (g.ent_base) si = live_shift(g, w, si);
     const float cx = ((float)g.cnx + w.sxi) + g.shift_x[si], cy = ((float)g.cnx + w.syi) + g.shift_y[si];
 
     // one sampling pass: ring FFTs and, in multi-reference mode, the Normalize_ring partial sums (added in ring order)
@@ -500,7 +509,10 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, TM >= 4 ? 2 : 4) void ccf_generic_
         __syncthreads();
     }
 
+    // live-offset lists: the number of entries of the chunk is known on the device only -- tiles and (SPLIT) the tasks of this slice follow it
+    if (g.ent_total) n_mtile = (*g.ent_total + 7) >> 3;
     const int n_mt2 = (n_mtile + TM - 1) / TM, n_rt2 = (nrtile + TR - 1) / TR;
+    if (g.ent_total && SPLIT) ntask = max(0, min(ntask, n_mt2 * n_rt2 - task0));
     // SPLIT: the workgroup takes blocks task0 + blockIdx.x, + gridDim.x, .. of the slice; block tl leaves its spectra in zscr[tl]
     // (N/2 + 1 bins of 16 bytes per pair)
     for (int tl = SPLIT ? (int)blockIdx.x : 0; tl < (SPLIT ? ntask : 1); tl += SPLIT ? (int)gridDim.x : 1) {
@@ -732,6 +744,10 @@ __global__ __launch_bounds__(RA_GCCF_THREADS, 4) void gccf_ifft_kernel(DevGeom g
     float2 *twa_s = xb + (size_t)NW * PS, *twb_s = twa_s + 16 * 16;
     ifft3_twiddles<16, 4>(g.tw, twa_s, twb_s, tid, RA_GCCF_THREADS);
     const int n_rt2 = (nrtile + TR - 1) / TR;
+    if (g.ent_total) {          // live-offset lists: the chunk's entry count lives on the device
+        n_mtile = (*g.ent_total + 7) >> 3;
+        ntask = max(0, min(ntask, ((n_mtile + TM - 1) / TM) * n_rt2 - task0));
+    }
     const int nbatch = ntask * TM * TR * 8;
     for (int bt_ = blockIdx.x; bt_ < nbatch; bt_ += gridDim.x) {
         const int tl = bt_ / (TM * TR * 8), rem = bt_ - tl * (TM * TR * 8), sub = rem >> 3, o = rem & 7;

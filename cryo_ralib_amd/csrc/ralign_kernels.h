@@ -79,6 +79,10 @@ struct DevGeom {
     const float2 *tw;             // e^{-2 pi i k / maxrin}, k < maxrin
     const int4 *itemA, *itemB, *itemC;
     const float *mask;            // model_circle(last_ring) [nx*nx]
+    // size-generic class, live-offset lists (round 6): entries of a chunk are the IN-WINDOW offsets of its particles only, in scan
+    // order -- particle p owns entries ent_base[p] .. ent_base[p + 1] - 1 (live_scan_kernel), *ent_total of them in the chunk; null:
+    // entry of (p, s) = p * ent_stride + s
+    const int *ent_base, *ent_total;
     // wave-job schedule of the polar kernel (4 search offsets per pass)
     int n_job, n_qtab, n_inst;
     int n_job_b;                  // search_duo_kernel: jobs [n_job, n_job + n_job_b) = the ring jobs of a pass's second offset (0: as the first)
@@ -243,6 +247,48 @@ __device__ __forceinline__ Window particle_window(const DevGeom &g, float dx, fl
     w.lkx = (int)(fminf(qlx, g.xrng) / g.step); w.rkx = (int)(fminf(qex, g.xrng) / g.step);
     w.lky = (int)(fminf(qly, g.yrng) / g.step); w.rky = (int)(fminf(qey, g.yrng) / g.step);
     return w;
+}
+// the search offsets inside a window, in the order of the offset list (y outer, x inner): how many, the list index of the j-th, and
+// the position of list index s among them (-1: outside the window)
+__device__ __forceinline__ int live_count(const Window &w) { return (w.lkx + w.rkx + 1) * (w.lky + w.rky + 1); }
+__device__ __forceinline__ int live_shift(const DevGeom &g, const Window &w, int j)
+{
+    const int wx = w.lkx + w.rkx + 1, jy = j / wx, jx = j - jy * wx;
+    return (jy - w.lky + g.nky) * (2 * g.nkx + 1) + (jx - w.lkx + g.nkx);
+}
+__device__ __forceinline__ int live_index(const DevGeom &g, const Window &w, int s)
+{
+    const int nx1 = 2 * g.nkx + 1, iy = s / nx1 - g.nky, ix = s - (s / nx1) * nx1 - g.nkx;
+    if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) return -1;
+    return (iy + w.lky) * (w.lkx + w.rkx + 1) + (ix + w.lkx);
+}
+// per-particle entry ranges of a chunk: ent_base[p] = number of in-window offsets of particles 0 .. p - 1 (one workgroup; n <= 32768)
+__global__ __launch_bounds__(1024) void live_scan_kernel(DevGeom g, const float *__restrict__ state, int n, int *__restrict__ ent_base,
+                                                        int *__restrict__ ent_total)
+{
+    __shared__ int sc[1024];
+    __shared__ int run;
+    const int tid = threadIdx.x;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        const int p = b0 + tid;
+        const int c = p < n ? live_count(particle_window(g, state[2 * p], state[2 * p + 1])) : 0;
+        sc[tid] = c;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = tid >= o ? sc[tid - o] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        const int base = run;
+        if (p < n) ent_base[p] = base + sc[tid] - c;
+        __syncthreads();
+        if (tid == 1023) run = base + sc[1023];
+        __syncthreads();
+    }
+    if (tid == 0) { ent_base[n] = run; *ent_total = run; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -984,14 +1030,22 @@ __global__ void unpack_refs_kernel(DevGeom g, const float *__restrict__ refspec,
 // `cimage` inside Util.multiref_polar_ali_2d), for bin-for-bin tests of the polar kernel
 // stats (generic path only): {avg, 1/sigma} per particle-offset; the generic polar kernel writes raw spectra
 __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, int n, const int *__restrict__ numr,
-                                      float *__restrict__ out, const float2 *__restrict__ stats)
+                                      float *__restrict__ out, const float2 *__restrict__ stats, const float *__restrict__ state = nullptr)
 {
     const int m = blockIdx.x;                  // particle * nshift + shift
     const int p = m / g.nshift, sft = m - p * g.nshift;
     if (p >= n) return;
-    const size_t ent = (size_t)p * g.ent_stride + sft;          // entry of this particle-offset: block ent >> 2, slot ent & 3
-    const float *blk = A + (ent >> 2) * g.a_blk;
+    size_t ent = (size_t)p * g.ent_stride + sft;          // entry of this particle-offset: block ent >> 2, slot ent & 3
     float *dst = out + (size_t)m * g.lcirc;
+    if (g.ent_base) {          // live-offset lists: an offset outside the particle's window has no entry (zeros)
+        const int j = live_index(g, particle_window(g, state[2 * p], state[2 * p + 1]), sft);
+        if (j < 0) {
+            for (int i = threadIdx.x; i < g.lcirc; i += blockDim.x) dst[i] = 0.f;
+            return;
+        }
+        ent = (size_t)g.ent_base[p] + j;
+    }
+    const float *blk = A + (ent >> 2) * g.a_blk;
     const int row0 = (int)(ent & 3) * 2;
     for (int i = 0; i < g.nring; i++) {
         const int nlen = numr[3 * i + 2], o = numr[3 * i + 1] - 1;
@@ -1002,7 +1056,7 @@ __global__ void unpack_spectra_kernel(DevGeom g, const float *__restrict__ A, in
             const int2 ap = g.ent_apos[e];
             float v = blk[ap.x + (row0 + comp) * ap.y];
             if (stats) {
-                const float2 st = stats[(size_t)p * g.ent_stride + sft];
+                const float2 st = stats[ent];
                 if (j == 0) v -= st.x * (float)nlen;
                 v *= st.y;
             }
@@ -1447,7 +1501,7 @@ struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirro
 __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__restrict__ cand, int nrtile, int p, const Window &w,
                                               CandT best, int bs, int brt, float second, int s2, int rt2, float *__restrict__ state,
                                               ra_result *__restrict__ res, RefineRec *__restrict__ rlist, int *__restrict__ rcount,
-                                              float rthr, int p_base = 0)
+                                              float rthr, int p_base = 0, const CandT *__restrict__ c2rec = nullptr)
 {
     const float peak = best.val;
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
@@ -1494,7 +1548,7 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__r
                 rec.bs2 = bs; rec.ref2 = runner - 1; rec.mirror2 = (jword >> 21) & 1; rec.jtot2 = (jword >> 22) & 0x3ff;
                 rec.rt2 = (brt << 16) | brt;
             } else if (tie_rec) {
-                const CandT *c = cand + ((size_t)p * g.ent_stride + s2) * nrtile + rt2;
+                const CandT *c = c2rec ? c2rec : cand + ((size_t)p * g.ent_stride + s2) * nrtile + rt2;
                 rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = cand_jtot(c->jtot);
                 rec.rt2 = (rt2 << 16) | brt;          // scan order of the two records: (offset, reference tile)
             }
@@ -1515,6 +1569,21 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
     int bs = 0, brt = 0, s2 = -1, rt2 = 0;          // (s2, rt2): the record with the second-largest peak
     const int nx1 = 2 * g.nkx + 1;
+    if (g.ent_base) {          // live-offset lists: the particle's records are those of its in-window offsets, in scan order
+        const int e0 = g.ent_base[p], L = g.ent_base[p + 1] - e0;
+        const CandT *c2 = nullptr, *cb = nullptr;
+        for (int j = 0; j < L; j++) {
+            const int s = live_shift(g, w, j);
+            for (int rt = 0; rt < nrtile; rt++) {
+                const CandT *c = cand + ((size_t)e0 + j) * nrtile + rt;
+                const float v = c->val;
+                if (v >= peak) { second = peak; s2 = bs; rt2 = brt; c2 = cb; peak = v; best = *c; bs = s; brt = rt; cb = c; }
+                else if (v >= second) { second = v; s2 = s; rt2 = rt; c2 = c; }
+            }
+        }
+        finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr, p_base, c2);
+        return;
+    }
     for (int s = 0; s < g.nshift; s++) {
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
         if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
@@ -1539,14 +1608,17 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
     const Window w = particle_window(g, state[2 * p], state[2 * p + 1]);
-    const int nx1 = 2 * g.nkx + 1, nrec = g.nshift * nrtile;
+    // live-offset lists: the particle's records are those of its L in-window offsets, record li = j * nrtile + rt at entry e0 + j
+    const bool live = g.ent_base != nullptr;
+    const int e0 = live ? g.ent_base[p] : p * g.ent_stride, L = live ? g.ent_base[p + 1] - e0 : g.nshift;
+    const int nx1 = 2 * g.nkx + 1, nrec = L * nrtile;
     float bv = -1.0e23f, sv = -1.0e23f;
     int bi = -1, si = -1;                              // linear record index s * nrtile + rt of the best / second record
     for (int li = lane; li < nrec; li += 64) {
         const int s = li / nrtile;
         const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
-        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
-        const float v = cand[(size_t)p * g.ent_stride * nrtile + li].val;
+        if (!live && (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky)) continue;
+        const float v = cand[(size_t)e0 * nrtile + li].val;
         if (v >= bv) { sv = bv; si = bi; bv = v; bi = li; }
         else if (v >= sv) { sv = v; si = li; }
     }
@@ -1565,9 +1637,15 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
     CandT best; best.val = -1.0e23f; best.jtot = 1; best.refmir = 0;
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
     int bs = 0, brt = 0;
-    if (bi >= 0) { best = cand[(size_t)p * g.ent_stride * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
-    const int s2 = si >= 0 ? si / nrtile : -1, rt2 = si >= 0 ? si - s2 * nrtile : 0;
-    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr, p_base);
+    if (bi >= 0) { best = cand[(size_t)e0 * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
+    int s2 = si >= 0 ? si / nrtile : -1;
+    const int rt2 = si >= 0 ? si - s2 * nrtile : 0;
+    const CandT *c2 = si >= 0 ? cand + (size_t)e0 * nrtile + si : nullptr;
+    if (live) {          // positions in the live list -> indices of the offset list
+        bs = bi >= 0 ? live_shift(g, w, bs) : 0;
+        if (s2 >= 0) s2 = live_shift(g, w, s2);
+    }
+    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr, p_base, c2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -353,15 +353,19 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
     }
     __syncthreads();
 
-    const int per = (g.nshift + zp.nchunk - 1) / zp.nchunk;
-    const int s_lo = ch * per, s_hi = min(g.nshift, s_lo + per);
+    // offsets of this workgroup: a quarter of the offset list -- or, with live-offset lists, of the particle's in-window offsets
+    const bool live = g.ent_base != nullptr;
+    const int e0 = live ? g.ent_base[p] : 0, nlive = live ? g.ent_base[p + 1] - e0 : g.nshift;
+    const int per = (nlive + zp.nchunk - 1) / zp.nchunk;
+    const int s_lo = ch * per, s_hi = min(nlive, s_lo + per);
     const int nitem = max(0, s_hi - s_lo) * zd.nquad;
     const int cyi_mH = cyi - zd.H;
     const bool no_taps = RA_DBG(g, 512);
     for (int it = wave; it < nitem; it += NW) {
         const int sl = it / zd.nquad, q = it - sl * zd.nquad;
-        const int s = s_lo + sl, c4 = zd.ring0 + 4 * q;
-        const size_t e = (size_t)p * g.ent_stride + s;
+        const int jl = s_lo + sl, c4 = zd.ring0 + 4 * q;
+        const int s = live ? live_shift(g, w, jl) : jl;
+        const size_t e = live ? (size_t)e0 + jl : (size_t)p * g.ent_stride + jl;
         float *blk = out + (e >> 2) * g.a_blk;
         const int slot = (int)(e & 3);
         const float cx = cxf + g.shift_x[s], cy = cyf + g.shift_y[s];
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(64 * NW) void polar_zone_kernel(DevGeom g, ZonePlan
 __global__ void polar_stats_kernel(DevGeom g, const float2 *__restrict__ part, int nent, int nquad, float2 *__restrict__ stats)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nent) return;
+    if (e >= (g.ent_total ? *g.ent_total : nent)) return;
     float av = 0.f, sq = 0.f;
     for (int k = 0; k < nquad; k++) {
         const float2 v = part[(size_t)e * nquad + k];

@@ -171,6 +171,10 @@ int  ra_lcirc(const ra_engine *e);
 int  ra_search_path(const ra_engine *e);
 /* with ra_search_path == 3: search offsets per pass, 2 (search_duo_kernel, the default) or 1 (search_solo_kernel); 0 otherwise */
 int  ra_search_offsets_per_pass(const ra_engine *e);
+/* 1 when the search kernels evaluate the IN-WINDOW offsets of a particle only (sp_alignment.search_range, as the CPU path does): the
+ * solo / duo / pair kernels and, since round 6, the size-generic kernels (live-offset lists); 0 when every offset of the list is
+ * computed and the out-of-window ones are masked afterwards (fused / tiled kernels, kernel pair) */
+int  ra_search_skips_offsets(const ra_engine *e);
 /* 1 when the particle-resident path is search_tiled_kernel (reference tiles: 15 and more references), 0 otherwise */
 int  ra_search_tiled(const ra_engine *e);
 /* change the search window without re-allocating (reset_shifts analogue); the number of

@@ -147,6 +147,48 @@ def test_reset_shifts_replans_the_ring_zones():
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [M, F], ids=["mref", "reffree"])
+def test_live_offset_lists_of_the_generic_class(mode, monkeypatch):
+    """the size-generic kernels work on the in-window offsets of every particle only (live_scan_kernel, DevGeom::ent_base): particles
+    whose state sits at the edge of the allowed shifts -- windows of 2 .. 7 offsets per axis instead of 7, one reset by the mashi rule --
+    against the oracle, and bitwise against the engine that computes every offset and masks afterwards (RALIGN_LIVE_OFFSETS=0)"""
+    from test_gpu_parity import compare_search, default_path_only
+    default_path_only("RALIGN_GENERIC", "RALIGN_SOLO", "RALIGN_LIVE_OFFSETS")
+    nx, ou, xr, n = 150, 66, 3, 9
+    nref = 3 if mode == M else 1
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 1, 1, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask if mode == M else None, rg)
+    d0 = np.array([[0, 0], [7, 0], [-7, 7], [8, -8], [0, -6], [5, 8], [-8, 3], [9, 0], [-3, -7]], np.float32)      # mashi = 8; (9, 0): reset / clamped
+    d = d0.copy()
+    if mode == M:
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    else:
+        # (ali2d_single_iter takes its starting shift from the previous parameters: inverse_transform2(0, -dx, -dy) = (dx, dy))
+        p0 = np.zeros((n, 6), np.float32)
+        p0[:, 1:3] = -d0
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, p0, nthreads=8)
+    out = {}
+    for live in ("1", "0"):
+        monkeypatch.setenv("RALIGN_LIVE_OFFSETS", live)
+        eng = api.Engine(nx, ou, xr, xr, 1.0, nref, mode)
+        assert eng.search_path == 2 and eng.search_skips_offsets == (live == "1")
+        eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+        st = torch.from_numpy(d0.copy()).to(eng.dev)
+        res = eng.new_result(n)
+        eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+        eng.sync()
+        out[live] = (api.Engine.result_to_numpy(res), st.cpu().numpy())
+        assert compare_search(out[live][0], out[live][1], params, infos, d) == 0
+        # the polar stage of the in-window offsets, bin for bin (out-of-window offsets: zeros with live lists)
+        eng.close()
+    for k in ("ref_id", "mirror", "angle_bin", "shift_idx", "peak", "alpha", "sx", "sy"):
+        np.testing.assert_array_equal(out["1"][0][k], out["0"][0][k])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
+
+
 if __name__ == "__main__":
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, ROOT)

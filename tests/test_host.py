@@ -79,7 +79,7 @@ def test_shipped_library_reads_only_the_documented_switches():
         blob = f.read()
     names = sorted(set(m.decode() for m in re.findall(rb"RALIGN_[A-Z0-9_]+", blob)))
     documented = ["RALIGN_ATOMIC_SUMS", "RALIGN_CROP", "RALIGN_DUO", "RALIGN_FUSED", "RALIGN_GCCF_SPLIT", "RALIGN_GCCF_TM",
-                  "RALIGN_GENERIC", "RALIGN_GRID", "RALIGN_INFO", "RALIGN_PACK", "RALIGN_PAIR", "RALIGN_REFINE", "RALIGN_SOLO",
+                  "RALIGN_GENERIC", "RALIGN_GRID", "RALIGN_INFO", "RALIGN_LIVE_OFFSETS", "RALIGN_PACK", "RALIGN_PAIR", "RALIGN_REFINE", "RALIGN_SOLO",
                   "RALIGN_SOLO_JOBS", "RALIGN_TCROP", "RALIGN_TIGHT_RINGS", "RALIGN_TILED", "RALIGN_XSUM", "RALIGN_XTILE", "RALIGN_ZONES"]
     assert names == documented, sorted(set(names) ^ set(documented))
     readme = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "README.md")).read()
