@@ -189,6 +189,41 @@ def test_live_offset_lists_of_the_generic_class(mode, monkeypatch):
     np.testing.assert_array_equal(out["1"][1], out["0"][1])
 
 
+def test_generic_class_in_the_iteration_loop():
+    """three iterations of the host driver (search, class sums, reference update, state round trip) at a geometry of the size-generic
+    class -- ring zones, live-offset lists whose windows move with the states from the second iteration on, one refine launch for the
+    whole call over several chunks -- against the same loop built from oracle calls (every particle refined: alpha to the ulp)"""
+    from test_gpu_parity import compare_search, default_path_only, assert_alpha_equal_to_the_ulp, _oracle_mref_loop_step, _log_flips
+    from cryo_ralib_amd.mref import MrefAligner
+    default_path_only("RALIGN_GENERIC", "RALIGN_SOLO", "RALIGN_LIVE_OFFSETS", "RALIGN_ZONES")
+    nx, ou, nref, xr, n = 150, 68, 3, 3, 40
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    al = MrefAligner(parts, refs, ou, xr, xr, 1.0, preprocess=True, state_roundtrip=True, refine=-1, chunk=16)       # 3 chunks per call
+    assert al.engine.search_path == 2 and al.engine.search_skips_offsets
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    cur = np.stack([orc.normalize_mask(r, mask, 1) for r in refs])
+    op = np.stack([orc.normalize_mask(p, mask, 0) for p in parts])
+    d = np.zeros((n, 2), np.float32)
+    prev = None
+    for it in range(3):
+        params, infos, sums, counts, d = _oracle_mref_loop_step(op, cur, rg, mask, xr, prev, d, True)
+        got_counts = al.iterate()
+        r = al.params()
+        flips = compare_search(r, al.state.cpu().numpy(), params, infos, d)
+        _log_flips("generic-class loop it=%d" % it, n, flips)
+        assert flips == 0
+        prev = params
+        np.testing.assert_array_equal(got_counts, counts)
+        assert_alpha_equal_to_the_ulp(r["alpha"], params[:, 0])
+        cur = np.stack([orc.normalize_mask((sums[j, 0] + sums[j, 1]) * np.float32(1.0 / float(counts[j])), mask, 1) for j in range(nref)])
+        np.testing.assert_allclose(al.refs.cpu().numpy(), cur, rtol=0, atol=3e-6 * np.abs(cur).max())
+    # the windows did move: some particle's state is off centre by now (mashi = 76 - 68 - 2 = 6 > xr: windows shrink from |d| = 4 on)
+    assert np.abs(al.state.cpu().numpy()).max() >= 1
+    al.close()
+
+
 if __name__ == "__main__":
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, ROOT)
