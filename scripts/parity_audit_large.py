@@ -64,7 +64,9 @@ def classify(r, params, jt, d_new, d_old, shifts, maxrin):
     return int((~same).sum()), out
 
 
-def run_case(name, n, sigma, dev, threads):
+def run_case(name, n, sigma, dev, threads, interp=0, normalize=None):
+    """interp / normalize: the engine options of include/ralign.h (ra_options) against the oracle's own switches -- 1 = Util::quadri in
+    alrl_ms, normalize = False / True = Normalize_ring off / on whatever the mode (None: the mode's default)"""
     from cryo_ralib_amd import geometry
     nx, ou, xr, nref, rf = CASES[name]
     refs_np = synth.make_references(max(nref, 1), nx, ou)
@@ -78,15 +80,18 @@ def run_case(name, n, sigma, dev, threads):
     t0 = time.time()
     if rf:
         tavg = parts.mean(0)[None].astype(np.float32) if rf == "blob" else refs_np[:1]
-        refs_n, cref = orc.prepare_refs(tavg, None, rg)
-        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=threads)
+        refs_n, cref = orc.prepare_refs(tavg, None, rg, interp=interp)
+        if normalize:          # ormq on normalised rings = the one-reference multi-reference search from a zero state (windows coincide)
+            params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=threads, interp=interp, normalize=True)
+        else:
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=threads, interp=interp)
         mode = api.RA_MODE_REFFREE
     else:
-        refs_n, cref = orc.prepare_refs(refs_np, mask, rg)
-        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=threads)
+        refs_n, cref = orc.prepare_refs(refs_np, mask, rg, interp=interp)
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=threads, interp=interp, normalize=True if normalize is None else bool(normalize))
         mode = api.RA_MODE_MREF
     t_or = time.time() - t0
-    eng = api.Engine(nx, ou, xr, xr, 1.0, refs_n.shape[0], mode, device=dev.index)
+    eng = api.Engine(nx, ou, xr, xr, 1.0, refs_n.shape[0], mode, device=dev.index, interp=interp, normalize_ring=normalize)
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(dev))
     st, res = eng.new_state(n), eng.new_result(n)
     eng.align(torch.from_numpy(parts).to(dev), st, res)
@@ -101,7 +106,7 @@ def run_case(name, n, sigma, dev, threads):
     rel = np.abs(r["peak"] - params[:, 5]) / np.abs(params[:, 5])
     ok = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & (r["angle_bin"] == jt)
     da = np.abs(((r["alpha"][ok] - params[ok, 0]) + 180.0) % 360.0 - 180.0)
-    rec = {"workload": name, "geometry": {"nx": nx, "ou": ou, "xr": xr, "nref": refs_n.shape[0]}, "particles": n, "sigma": sigma,
+    rec = {"workload": name + (" / quadri" if interp else "") + ("" if normalize is None else " / Normalize_ring %s" % ("on" if normalize else "off")), "geometry": {"nx": nx, "ou": ou, "xr": xr, "nref": refs_n.shape[0]}, "particles": n, "sigma": sigma,
            "search_path": bench.SEARCH_PATHS[path] + (" (tiled)" if tiled else ""), "tie_flips": flips, "flip_classes": kinds,
            "max_rel_peak": float(rel.max()), "alpha_outliers_gt_2e-3_deg": int((da > 2e-3).sum()),
            "max_alpha_diff_deg": float(da.max()) if da.size else 0.0, "refined_by_exact_kernel": refined,
@@ -116,6 +121,8 @@ def main():
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_audit_large.json"))
+    ap.add_argument("--interp", type=int, default=0, help="1: Util::quadri in alrl_ms (engine option RA_INTERP_QUADRI, oracle ORC_INTERP_QUADRI)")
+    ap.add_argument("--normalize-ring", type=int, default=-1, help="0 / 1: Normalize_ring off / on whatever the mode (engine option; oracle flag)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -123,7 +130,7 @@ def main():
     recs = []
     for w in a.workloads:
         n = min(a.n, CAPS.get(w, a.n))
-        recs.append(run_case(w, n, a.sigma, dev, threads))
+        recs.append(run_case(w, n, a.sigma, dev, threads, a.interp, None if a.normalize_ring < 0 else bool(a.normalize_ring)))
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         with open(a.out, "w") as f:
             json.dump({"_what": "engine against the oracle on large sigma = %g samples: disagreements of the integer assignment by class "
