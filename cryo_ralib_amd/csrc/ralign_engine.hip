@@ -32,6 +32,9 @@ static thread_local std::string g_last_error;
 // options only they implement (ra_create_ex: RA_INTERP_QUADRI).  The option is engine state; the flag below carries it into the
 // planning helpers that see a geometry but no engine (fits_specialised_kernels, resident_expected) while that engine is planned.
 static thread_local bool g_force_generic = false;
+// ... and: plan this engine in the size-generic CLASS (crop / pair / solo kernels allowed) although the LDS-resident kernels would hold its
+// image -- the second attempt of ra_create_ex for more than 16 references in boxes whose tiled plan does not fit next to the whole image
+static thread_local bool g_generic_class = false;
 static bool generic_forced() { return g_force_generic || (getenv("RALIGN_GENERIC") && atoi(getenv("RALIGN_GENERIC")) != 0); }
 struct ForceGenericScope {
     bool prev;
@@ -1156,6 +1159,18 @@ extern "C" int ra_create_ex(ra_engine **out, const ra_config *cfg, const ra_opti
     // the plan of the four-offset kernels over a crop of the image is promised by tcrop_wanted on an estimate of the tables; should
     // the real tables miss it, the engine is planned again without that path (pair or generic kernels) instead of failing
     if (rc == RA_ERR_STATE) rc = create_engine(out, cfg, opt, false);
+    // More than 16 references in a box whose image fits the LDS but leaves no room for the tiled kernel's plan beside it (100 - 128
+    // pixels at ou = 21 .. 32) used to fall to the round-1 kernel pair (3.7 MB of HBM per particle): planned in the size-generic
+    // class instead, the search runs search_tiled_kernel over a crop of the image.  Kept only when that plan exists.
+    if (rc == RA_OK && *out && !(*out)->generic && !(*out)->fused && cfg->nref > RF_MAXREF && (*out)->geo.maxrin == 256 && !generic_forced() &&
+        !(getenv("RALIGN_FUSED") && atoi(getenv("RALIGN_FUSED")) == 0)) {          // (RALIGN_FUSED=0 asks for the kernel pair)
+        ra_engine *alt = nullptr;
+        g_generic_class = true;
+        const int rc2 = create_engine(&alt, cfg, opt, true);
+        g_generic_class = false;
+        if (rc2 == RA_OK && alt && (alt->fused || alt->solo)) { ra_destroy(*out); *out = alt; }
+        else if (alt) ra_destroy(alt);
+    }
     return rc;
 }
 static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options *opt, bool allow_tcrop)
@@ -1189,7 +1204,7 @@ static int create_engine(ra_engine **out, const ra_config *cfg, const ra_options
     }
     e->force_generic = g_force_generic;
     e->no_tcrop = !allow_tcrop;
-    e->generic = !fits_specialised_kernels(e->geo, *cfg);
+    e->generic = !fits_specialised_kernels(e->geo, *cfg) || g_generic_class;
     e->tcrop = tcrop_wanted(e);
     if (!e->tcrop && allow_tcrop && e->generic && e->geo.maxrin == 256 && !(getenv("RALIGN_TIGHT_RINGS") && atoi(getenv("RALIGN_TIGHT_RINGS")) == 0)) {
         // ou = 37 ... 40: crop + four ring buffers miss the LDS by 4 - 8 KB, of which the 16 padding floats per ring are 10 KB.  With

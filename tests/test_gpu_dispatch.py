@@ -46,6 +46,8 @@ CASES = [
     ("R17-maxrin128",             48,  20, 1, 1, 2, 2, 1.0, 17, 16, M, PAIRK),       # ... the kernel pair beyond
     ("R16-crop",                  128, 36, 1, 1, 3, 3, 1.0, 16, 8, M, TILED),
     ("R17-crop",                  128, 36, 1, 1, 3, 3, 1.0, 17, 8, M, TILED),
+    ("box128-ou25-R50",           128, 25, 1, 1, 3, 3, 1.0, 50, 8, M, TILED),        # image fits the LDS, the tiled plan beside it does not: tiled kernel
+    ("box100-ou30-R17",           100, 30, 1, 1, 3, 3, 1.0, 17, 8, M, TILED),        # ... over a crop (planned in the size-generic class; was the kernel pair)
     ("half-pixel-steps",          90,  36, 1, 1, 1, 1, 0.5, 5, 16, M, FUSED),
     ("half-pixel-steps-crop",     112, 34, 1, 1, 1, 2, 0.5, 3, 12, M, FUSED),
     ("half-pixel-steps-duo",      120, 50, 1, 1, 1, 1, 0.5, 2, 6, M, SOLO2),
