@@ -281,6 +281,7 @@ static int build_device_geometry(ra_engine *e)
     d.nx = g.nx; d.cnx = g.nx / 2 + 1;
     d.nring = g.nring; d.maxrin = g.maxrin; d.lcirc = g.lcirc; d.lring = g.lring; d.nbins = g.nbins;
     d.LB = g.LB; d.LBP = g.LBP; d.last_ring = g.last_ring;
+    d.win_ring = e->cfg.mode == RA_MODE_MREF ? g.last_ring : g.numr[3 * (g.nring - 1)];
     d.nshift = g.nshift; d.nshift_pad = g.nshift_pad; d.nkx = g.nkx; d.nky = g.nky; d.ent_stride = e->generic ? g.nshift : g.nshift_pad;      // generic class: dense entries
     d.step = g.step; d.xrng = e->cfg.xrng; d.yrng = e->cfg.yrng;
     d.nn_weight = g.nn_weight; d.inv_nn_weight = g.nn_weight > 0.f ? (float)(1.0 / (double)g.nn_weight) : 0.f; d.lg_maxrin = ilog2_floor(g.maxrin); d.mode = e->cfg.mode; d.nomirror = 0; d.norm_ring = e->cfg.mode == RA_MODE_MREF ? 1 : 0; d.interp = RA_INTERP_BILINEAR; d.quad_aligned = g.quad_aligned ? 1 : 0;
@@ -2398,7 +2399,8 @@ void run_search(int start, int stop, int mode)
         fprintf(stderr, "libralign_hip: bad index range [%d,%d)\n", start, stop);
         exit(EXIT_FAILURE);
     }
-    L.eng->cfg.mode = mode; L.eng->dg.mode = mode; L.eng->dg.norm_ring = mode == RA_MODE_MREF ? 1 : 0;      // (Normalize_ring follows the entry point: multiref_polar_ali_2d | ormq)
+    L.eng->cfg.mode = mode; L.eng->dg.mode = mode; L.eng->dg.norm_ring = mode == RA_MODE_MREF ? 1 : 0;
+    L.eng->dg.win_ring = mode == RA_MODE_MREF ? L.eng->geo.last_ring : L.eng->geo.numr[3 * (L.eng->geo.nring - 1)];      // (Normalize_ring follows the entry point: multiref_polar_ali_2d | ormq)
     for (int i = 0; i < n; i++) { L.h_state[2 * i] = L.h_param[start + i].shift_x; L.h_state[2 * i + 1] = L.h_param[start + i].shift_y; }
     hip_or_die(hipMemcpy(L.d_state, L.h_state, sizeof(float) * 2 * n, hipMemcpyHostToDevice), "state upload");
     if (ra_align(L.eng, L.d_sbj, n, L.d_state, L.d_res, nullptr)) die("ra_align");

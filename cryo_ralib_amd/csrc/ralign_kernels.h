@@ -44,6 +44,9 @@ struct DevGeom {
     int nx, cnx;                  // cnx = nx/2+1 (1-based SPIDER centre)
     int nring, maxrin, lcirc, lring, nbins, LB, LBP;
     int last_ring;
+    int win_ring;                 // the radius of the window rule (particle_window): the caller's last_ring argument for RA_MODE_MREF
+                                  // (test_mref_gpu_align.py:740, 761-766), numr[-3] -- the outermost SAMPLED ring, below it when the ring
+                                  // step does not divide last_ring - first_ring -- for RA_MODE_REFFREE (ali2d_single_iter: ou = numr[-3])
     int nshift, nshift_pad, nkx, nky;
     int ent_stride;               // entries (particle-offsets) per particle in the A blocks, statistics and candidate records: nshift_pad; the
                                   // size-generic path packs them densely (nshift: 121 instead of 124 at configs[4], no padding offsets in the contraction)
@@ -233,7 +236,7 @@ struct Window { float sxi, syi; int lkx, rkx, lky, rky; };
 __device__ __forceinline__ Window particle_window(const DevGeom &g, float dx, float dy)
 {
     Window w;
-    const float mashi = (float)(g.cnx - g.last_ring - 2);
+    const float mashi = (float)(g.cnx - g.win_ring - 2);
     if (g.mode == RA_MODE_MREF) {
         if (fabsf(dx) > mashi || fabsf(dy) > mashi) { dx = 0.f; dy = 0.f; }
     } else {
@@ -242,8 +245,8 @@ __device__ __forceinline__ Window particle_window(const DevGeom &g, float dx, fl
     }
     w.sxi = dx; w.syi = dy;
     const int cn = g.nx / 2 + 1;
-    float qlx = fmaxf(cn + dx - g.last_ring - 2, 0.f), qex = fmaxf(g.nx - cn - dx - g.last_ring, 0.f);
-    float qly = fmaxf(cn + dy - g.last_ring - 2, 0.f), qey = fmaxf(g.nx - cn - dy - g.last_ring, 0.f);
+    float qlx = fmaxf(cn + dx - g.win_ring - 2, 0.f), qex = fmaxf(g.nx - cn - dx - g.win_ring, 0.f);
+    float qly = fmaxf(cn + dy - g.win_ring - 2, 0.f), qey = fmaxf(g.nx - cn - dy - g.win_ring, 0.f);
     w.lkx = (int)(fminf(qlx, g.xrng) / g.step); w.rkx = (int)(fminf(qex, g.xrng) / g.step);
     w.lky = (int)(fminf(qly, g.yrng) / g.step); w.rky = (int)(fminf(qey, g.yrng) / g.step);
     return w;

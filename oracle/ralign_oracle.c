@@ -669,7 +669,10 @@ void orc_mref_iteration(const float *particles, int n, int nx,
 {
     const int npix = nx * nx;
     const int cnx = nx / 2 + 1, cny = cnx;
-    const int last_ring = rg->numr[3 * (rg->nring - 1)];
+    /* the caller's last_ring PARAMETER (test_mref_gpu_align.py:740, 761-766: mashi and search_range take the argument of
+     * mref_ali2d, not numr[-3]); with a ring step > 1 the outermost sampled ring can lie below it.  ali2d_single_iter, in
+     * contrast, reads ou = numr[-3] (orc_reffree_iteration). */
+    const int last_ring = rg->last_ring;
     const float mashi = (float)(cnx - last_ring - 2);
     int *iref_of = (int *)malloc(sizeof(int) * n);
     float *aligned = NULL;

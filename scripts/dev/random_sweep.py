@@ -1,6 +1,8 @@
 """random geometries through the engine against the CPU checker (run on the GPU box: python scripts/dev/random_sweep.py [n] [seed]);
 prints one line per case and the search path the engine took; exits non-zero on the first mismatch.  A third argument "big" draws
-boxes of 64 .. 160 pixels with rings up to 512 samples and up to 60 references (search_pair / search_duo / the generic kernels)."""
+boxes of 64 .. 160 pixels with rings up to 512 samples and up to 60 references (search_pair / search_duo / the generic kernels);
+"huge" boxes of 140 .. 230 pixels.  A fourth argument "state" starts every particle from a random accumulated shift within
++-(mashi + 1) (multiples of the step): shrunken and reset search windows, the live-offset lists of the size-generic class."""
 import os
 import sys
 
@@ -18,6 +20,7 @@ ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 big = len(sys.argv) > 3 and sys.argv[3] in ("big", "huge")
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"      # boxes of 140 .. 230 pixels, ou 61 .. 100: the size-generic class (polar_zone_kernel)
+rand_state = len(sys.argv) > 4 and sys.argv[4] == "state"
 for case in range(ncase):
     xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
     nx = int(rng.integers(140, 231)) if huge else int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
@@ -34,19 +37,38 @@ for case in range(ncase):
     mask = orc.model_circle(ou, nx, nx)
     refs_n, cref = orc.prepare_refs(refs, mask, rg)
     d = np.zeros((n, 2), np.float32)
+    if rand_state:
+        mashi = nx // 2 + 1 - ou - 2
+        lim = int((mashi + 1) / ts)
+        d = (rng.integers(-lim, lim + 1, size=(n, 2)) * ts).astype(np.float32)
+    d0 = d.copy()
+    if rand_state:      # the particle sits where its state says (a search centred 20 pixels beside it would only find noise peaks near zero)
+        for i in range(n):
+            parts[i] = np.roll(parts[i], (int(np.floor(d0[i, 1])), int(np.floor(d0[i, 0]))), axis=(0, 1))
     if mode == api.RA_MODE_MREF:
         params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8)
     else:
         params = np.zeros((n, 6), np.float32)
+        params[:, 1:3] = -d0
         params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8)
     eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs)
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
     tp = torch.from_numpy(parts).to(eng.dev)
-    st, res = eng.new_state(n), eng.new_result(n)
+    st, res = torch.from_numpy(d0.copy()).to(eng.dev), eng.new_result(n)
     eng.align(tp, st, res)
     eng.sync()
     path = "%d (%d offsets per pass)" % (eng.search_path, eng.search_offsets_per_pass)
-    compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    try:
+        compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
+    except AssertionError:
+        r = api.Engine.result_to_numpy(res)
+        print("case %d FAILED: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path))
+        print(" start states", d0.tolist())
+        print(" peaks engine", r["peak"].tolist())
+        print(" peaks oracle", params[:, 5].tolist())
+        print(" assignment engine", list(zip(r["ref_id"].tolist(), r["mirror"].tolist(), r["angle_bin"].tolist())), st.cpu().numpy().tolist())
+        print(" assignment oracle", [(int(params[i, 4]), int(params[i, 3]), infos[i].jtot) for i in range(n)], d.tolist())
+        raise
     eng.close()
     print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path), flush=True)
 print("all %d cases agree with the checker" % ncase)

@@ -191,6 +191,45 @@ def test_live_offset_lists_of_the_generic_class(mode, monkeypatch):
     np.testing.assert_array_equal(out["1"][1], out["0"][1])
 
 
+@pytest.mark.parametrize("mode", [M, F])
+@pytest.mark.parametrize("nx,ou,ir,rs", [(73, 15, 2, 2), (90, 36, 1, 3), (150, 66, 2, 3)])
+def test_window_radius_with_a_ring_step(mode, nx, ou, ir, rs):
+    """a ring step that does not divide last_ring - first_ring leaves the outermost sampled ring below last_ring: mref_ali2d resets
+    and cuts its windows with the last_ring ARGUMENT (test_mref_gpu_align.py:740, 761-766), ali2d_single_iter clamps with
+    ou = numr[-3] (DevGeom::win_ring).  States at mashi, between the two mashis and beyond, against the oracle"""
+    from test_gpu_parity import compare_search
+    rg = orc.rings(ir, ou, rs)
+    act = rg.numr[3 * (rg.nring - 1)]
+    assert act < ou
+    xr, n = 2, 10
+    nref = 3 if mode == M else 1
+    refs = synth.make_references(nref, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 1, 1, 0.3, ou=ou)
+    cn = nx // 2 + 1
+    m_arg, m_act = cn - ou - 2, cn - act - 2
+    d0 = np.array([[m_arg, 0], [m_arg + 0.5, 0], [0, -(m_arg + 1)], [m_act, m_act], [-(m_act + 0.5), 0], [0, m_act + 1],
+                   [-m_arg, m_arg - 1], [m_arg - 1.5, -m_act], [0, 0], [m_act + 3, -1]], np.float32)
+    for i in range(n):      # the particle sits where its state says
+        parts[i] = np.roll(parts[i], (int(np.floor(d0[i, 1])), int(np.floor(d0[i, 0]))), axis=(0, 1))
+    mask = orc.model_circle(ou, nx, nx)
+    refs_n, cref = orc.prepare_refs(refs, mask if mode == M else None, rg)
+    d = d0.copy()
+    if mode == M:
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    else:
+        p0 = np.zeros((n, 6), np.float32)
+        p0[:, 1:3] = -d0
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, p0, nthreads=8)
+    eng = api.Engine(nx, ou, xr, xr, 1.0, nref, mode, first_ring=ir, ring_skip=rs)
+    eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    st = torch.from_numpy(d0.copy()).to(eng.dev)
+    res = eng.new_result(n)
+    eng.align(torch.from_numpy(parts).to(eng.dev), st, res)
+    eng.sync()
+    assert compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d) == 0
+    eng.close()
+
+
 def test_generic_class_in_the_iteration_loop():
     """three iterations of the host driver (search, class sums, reference update, state round trip) at a geometry of the size-generic
     class -- ring zones, live-offset lists whose windows move with the states from the second iteration on, one refine launch for the

@@ -211,6 +211,39 @@ def test_search_range_rule():
     assert geometry.search_range(90, 36, 7.0, 3.0) == [3.0, 1.0]
 
 
+def test_window_radius_with_a_ring_step():
+    """rings 2, 4 .. 14 of last_ring = 15 (Numrinit(2, 15, 2)): mref_ali2d takes mashi and search_range from its last_ring ARGUMENT
+    (test_mref_gpu_align.py:740, 761-766: mashi = 37 - 15 - 2 = 20), ali2d_single_iter from ou = numr[-3] = 14 (mashi = 21,
+    clamped not reset) -- a state of 20.5 is reset by the first and kept by the second"""
+    nx, ou, n = 73, 15, 3
+    refs = synth.make_references(2, nx, ou)
+    parts, _ = synth.make_particles(refs, n, 1, 1, 0.1, ou=ou)
+    rg = orc.rings(2, ou, 2)
+    assert rg.numr[3 * (rg.nring - 1)] == 14 and rg.last_ring == 15
+    mask = orc.model_circle(ou, nx, nx)
+    _, cref = orc.prepare_refs(refs, mask, rg)
+    # mref: 20.5 > 20 is reset -> the result of a particle that starts from (0, 0); 20 is not
+    d_edge = np.array([[20.5, 0], [0, -20.5], [20, 0]], np.float32)
+    d_zero = np.array([[0, 0], [0, 0], [20, 0]], np.float32)
+    pe, _, _, _ = orc.mref_iteration(parts, cref, rg, 1, 1, 1.0, d_edge)
+    pz, _, _, _ = orc.mref_iteration(parts, cref, rg, 1, 1, 1.0, d_zero)
+    np.testing.assert_array_equal(pe, pz)
+    np.testing.assert_array_equal(d_edge, d_zero)
+    assert abs(d_edge[2, 0]) >= 19
+    # reference-free: 20.5 <= 21 is kept (the search runs around it), 21.5 is clamped to 21
+    def run(d0):
+        d = np.array(d0, np.float32)
+        p = np.zeros((n, 6), np.float32)
+        p[:, 1:3] = -d
+        out = orc.reffree_iteration(parts, cref[0], rg, 1, 1, 1.0, (0, 0), d, p)
+        return out[0], d
+    p_in, d_in = run([[20.5, 0], [0, 21.5], [0, 0]])
+    p_cl, d_cl = run([[20.5, 0], [0, 21.0], [0, 0]])
+    assert abs(d_in[0, 0] - 20.5) <= 1.0 and abs(d_in[1, 1] - 21.0) <= 1.0
+    np.testing.assert_array_equal(d_in, d_cl)
+    np.testing.assert_array_equal(p_in[:, [0, 3, 5]], p_cl[:, [0, 3, 5]])
+
+
 @pytest.mark.parametrize("nx,ou,nref,xr", [(90, 36, 4, 3), (32, 12, 3, 2)])
 def test_planted_truth_recovery(nx, ou, nref, xr):
     """particles = rot_shift2D(reference, planted); the search must return the inverse so that
