@@ -200,6 +200,13 @@ def _check(rc, what):
         raise EngineError("%s failed (%d): %s" % (what, rc, load_library().ra_last_error().decode()))
 
 
+def _norm_flag(flag):
+    """None or the header's -1: by mode; otherwise on / off (a bare bool(-1) would switch the normalisation ON)"""
+    if flag is None or (not isinstance(flag, bool) and isinstance(flag, (int, float)) and flag < 0):
+        return -1
+    return int(bool(flag))
+
+
 class Engine:
     """Handle-based engine.  All tensor arguments are torch CUDA tensors on `device`."""
 
@@ -207,17 +214,17 @@ class Engine:
                  device=0, chunk=0, interp=RA_INTERP_BILINEAR, normalize_ring=None):
         """interp / normalize_ring: the two hedges of include/ralign.h (ra_options) for the choices of the EMAN2 CPU path that the
         reference tree does not pin -- Util::alrl_ms's interpolation (RA_INTERP_QUADRI: older EMAN2 releases; size-generic kernels)
-        and Normalize_ring on / off independent of the mode (None: by mode)."""
+        and Normalize_ring on / off independent of the mode (None, or the header's -1: by mode)."""
         import torch
         self.torch = torch
         self.lib = load_library()
         self.cfg = RaConfig(int(nx), int(first_ring), int(last_ring), int(ring_skip), float(xrng), float(yrng),
                             float(step), int(nref), int(mode), int(device), int(chunk))
         self.handle = ctypes.c_void_p()
-        if interp == RA_INTERP_BILINEAR and normalize_ring is None:
+        if interp == RA_INTERP_BILINEAR and _norm_flag(normalize_ring) < 0:
             _check(self.lib.ra_create(ctypes.byref(self.handle), ctypes.byref(self.cfg)), "ra_create")
         else:
-            opt = RaOptions(int(interp), -1 if normalize_ring is None else int(bool(normalize_ring)))
+            opt = RaOptions(int(interp), _norm_flag(normalize_ring))
             _check(self.lib.ra_create_ex(ctypes.byref(self.handle), ctypes.byref(self.cfg), ctypes.byref(opt)), "ra_create_ex")
         self.nx, self.nref, self.mode, self.device = int(nx), int(nref), int(mode), int(device)
         self.dev = torch.device("cuda", device)
@@ -283,8 +290,8 @@ class Engine:
         _check(self.lib.ra_set_mask(self.handle, self._ptr(mask, self.torch.float32)), "ra_set_mask")
 
     def set_normalize_ring(self, flag):
-        """Normalize_ring for subsequent searches: True / False, None = the mode's default (ra_set_normalize_ring)"""
-        _check(self.lib.ra_set_normalize_ring(self.handle, -1 if flag is None else int(bool(flag))), "ra_set_normalize_ring")
+        """Normalize_ring for subsequent searches: True / False, None (or -1) = the mode's default (ra_set_normalize_ring)"""
+        _check(self.lib.ra_set_normalize_ring(self.handle, _norm_flag(flag)), "ra_set_normalize_ring")
 
     @property
     def options(self):

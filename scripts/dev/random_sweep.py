@@ -20,7 +20,8 @@ ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 big = len(sys.argv) > 3 and sys.argv[3] in ("big", "huge")
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"      # boxes of 140 .. 230 pixels, ou 61 .. 100: the size-generic class (polar_zone_kernel)
-rand_state = len(sys.argv) > 4 and sys.argv[4] == "state"
+rand_state = len(sys.argv) > 4 and sys.argv[4] in ("state", "state+options")
+rand_opt = len(sys.argv) > 4 and sys.argv[4] in ("options", "state+options")      # Util::quadri sampling / Normalize_ring against the mode
 for case in range(ncase):
     xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
     nx = int(rng.integers(140, 231)) if huge else int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
@@ -31,11 +32,17 @@ for case in range(ncase):
     mode = api.RA_MODE_MREF if rng.random() < 0.7 else api.RA_MODE_REFFREE
     nref = (int(rng.integers(1, 21)) if huge else int(rng.integers(1, 61)) if big else int(rng.integers(1, 17))) if mode == api.RA_MODE_MREF else 1
     n = int(rng.integers(2, 6)) if huge else int(rng.integers(3, 9)) if big else int(rng.integers(3, 20))
+    interp, norm = api.RA_INTERP_BILINEAR, -1
+    if rand_opt:
+        interp = api.RA_INTERP_QUADRI if rng.random() < 0.4 else api.RA_INTERP_BILINEAR
+        norm = int(rng.choice([-1, 0, 1])) if mode == api.RA_MODE_MREF else -1
+    o_interp = orc.INTERP_QUADRI if interp == api.RA_INTERP_QUADRI else orc.INTERP_BILINEAR
+    o_norm = (mode == api.RA_MODE_MREF) if norm < 0 else bool(norm)
     refs = synth.make_references(nref, nx, ou)
     parts, _ = synth.make_particles(refs, n, xr, yr, 0.25, ou=ou)
     rg = orc.rings(ir, ou, rs)
     mask = orc.model_circle(ou, nx, nx)
-    refs_n, cref = orc.prepare_refs(refs, mask, rg)
+    refs_n, cref = orc.prepare_refs(refs, mask, rg, interp=o_interp) if rand_opt else orc.prepare_refs(refs, mask, rg)
     d = np.zeros((n, 2), np.float32)
     if rand_state:
         mashi = nx // 2 + 1 - ou - 2
@@ -46,12 +53,12 @@ for case in range(ncase):
         for i in range(n):
             parts[i] = np.roll(parts[i], (int(np.floor(d0[i, 1])), int(np.floor(d0[i, 0]))), axis=(0, 1))
     if mode == api.RA_MODE_MREF:
-        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8)
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8, interp=o_interp, normalize=o_norm)
     else:
         params = np.zeros((n, 6), np.float32)
         params[:, 1:3] = -d0
-        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8)
-    eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs)
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8, interp=o_interp)
+    eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs, interp=interp, normalize_ring=None if norm < 0 else bool(norm))
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
     tp = torch.from_numpy(parts).to(eng.dev)
     st, res = torch.from_numpy(d0.copy()).to(eng.dev), eng.new_result(n)
@@ -70,5 +77,5 @@ for case in range(ncase):
         print(" assignment oracle", [(int(params[i, 4]), int(params[i, 3]), infos[i].jtot) for i in range(n)], d.tolist())
         raise
     eng.close()
-    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path), flush=True)
+    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d interp=%d norm=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, interp, norm, path), flush=True)
 print("all %d cases agree with the checker" % ncase)

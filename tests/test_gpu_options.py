@@ -189,3 +189,11 @@ def test_options_are_validated():
     o = api.RaOptions()
     assert lib.ra_get_options(h, ctypes.byref(o)) == 0 and (o.interp, o.normalize_ring) == (0, 1)
     lib.ra_destroy(h)
+    # the Python mirror takes None or the header's -1 for "by mode" (bool(-1) must not switch the normalisation on)
+    for flag, want in ((None, 0), (-1, 0), (True, 1), (1, 1), (False, 0), (0, 0)):
+        eng = api.Engine(90, 36, 3, 3, 1.0, 1, api.RA_MODE_REFFREE, normalize_ring=flag)
+        assert eng.options == (api.RA_INTERP_BILINEAR, want), (flag, eng.options)
+        eng.set_normalize_ring(True)
+        eng.set_normalize_ring(-1)
+        assert eng.options[1] == 0
+        eng.close()
