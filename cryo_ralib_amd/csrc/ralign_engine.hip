@@ -685,7 +685,7 @@ static WorkspacePlan plan_workspace(const Geometry &g, const ra_config &cfg, boo
     // sub-bin refinement (ralign_exact.h): exact reference spectra, the list of flagged particles, global ring buffers of large boxes
     const size_t lds_ref = (size_t)std::max(2 * g.lcirc, g.lcirc + 2 * g.maxrin) * sizeof(float) + RA_EXACT_TABLE_BYTES(g.maxrin);
     const size_t exact_ws = (size_t)cfg.nref * g.lcirc * sizeof(float) + (size_t)chunk * sizeof(RefineRec) +
-                            (lds_ref > 160 * 1024 - 256 ? (size_t)std::max(256, cfg.nref) * 2 * g.lcirc * sizeof(float) : 0);
+                            (lds_ref > 160 * 1024 - 1024 ? (size_t)std::max(256, cfg.nref) * 2 * g.lcirc * sizeof(float) : 0);
     w.bytes = (w.refspec_floats + w.b_floats + 2) * sizeof(float) + search_ws + sums_ws + exact_ws +
               (resident ? 0 : w.zscr_recs * sizeof(float2)) + refine + tables;
     // every hipMalloc is rounded up to the allocator's granule; ~40 small tables and buffers
@@ -1028,7 +1028,7 @@ static int setup_refine(ra_engine *e)
     if (g.lcirc & 1) return RA_OK;
     // large boxes: one offset's rings exceed the LDS (271 KB at 256 x 256 / ou = 120) -- the same kernels with the ring buffers
     // in global scratch
-    e->refine_gm = e->lds_refine > 160 * 1024 - 256;
+    e->refine_gm = e->lds_refine > 160 * 1024 - 1024;          // (the kernel's static LDS: reduction scratch and the tie candidates, ~0.7 KB)
     e->refine_grid = e->refine_gm ? 256 : 2048;
     if (e->refine_gm) e->lds_refine = RA_EXACT_TABLE_BYTES(g.maxrin);
     std::vector<float> tw;

@@ -10,9 +10,9 @@
 // refine_winner_kernel recomputes that neighbourhood for ONE (offset, reference, mirror) per particle with the CPU
 // path's own arithmetic:
 //   Polar2Dm   bilinear samples in Util::bilinear's operation order (bit-identical positions and values)
-//   Normalize_ring (multi-reference mode)  (v - avg) / sigma per sample in f32; avg and sigma from f64 sums -- a uniform
-//              shift / scale cancels in prb1d (both coefficient sets sum to zero, pos is a ratio), only the rounding of the
-//              individual samples matters
+//   Normalize_ring (multi-reference mode)  (v - avg) / sigma per sample in f32; avg and sigma from FLOAT sums taken sample after
+//              sample in ring order, as Util::Normalize_ring takes them (their rounding walk is ~1e-6 of sigma and differs from
+//              offset to offset: it cancels in one candidate's prb1d but orders two offsets whose maxima are closer than that)
 //   Frngs      the radix-2 real FFT of fftr_q in f32, table twiddles, no contraction: bit-identical spectra
 //   Crosrng_ms f32 products, f64 accumulation over the rings in ring order, against reference spectra prepared with the
 //              same three routines + Applyws (refspec_exact_kernel)
@@ -193,27 +193,43 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
 {
 #pragma clang fp contract(off)
     const float cx = ((float)g.cnx + sxi) + g.shift_x[bs], cy = ((float)g.cnx + syi) + g.shift_y[bs];
-    double av = 0.0, sq = 0.0;
     exact_lds_sync<GM>();
     constexpr int T = RA_EXACT_THREADS;
     for (int i0 = lane; i0 < g.lcirc; i0 += 4 * T) {        // four samples per trip: their 16 image taps are in flight together
-        float v[4], w[4];
+        float v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = min(i0 + T * u, g.lcirc - 1);
             v[u] = g.interp ? quadri_1b(img, g.nx, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy) : bilinear_1b(img, g.nx, g.samp_dx[i] + cx, g.samp_dy[i] + cy);
-            w[u] = g.samp_w[i];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (i0 + T * u < g.lcirc) {
-                circ[i0 + T * u] = v[u];
-                av += (double)(v[u] * w[u]); sq += (double)(v[u] * v[u] * w[u]);
-            }
+            if (i0 + T * u < g.lcirc) circ[i0 + T * u] = v[u];
     }
     if (g.norm_ring) {
-        av = block_sum_f64(av, red); sq = block_sum_f64(sq, red);
-        const float nn = g.nn_weight, avf = (float)av, sqf = (float)sq;
+        // Util::Normalize_ring sums av += v w and sq += v v w in FLOAT, sample after sample in ring order: a rounding random walk of
+        // ~1e-6 of sq over the 5816 samples of the headline geometry, different for every search offset -- and sigma scales the
+        // peak.  Two OFFSETS whose CCF maxima lie within 1e-6 of each other (half-pixel steps: a ridge in (shift, angle)) are thus
+        // ordered by that very walk, so the re-evaluation repeats it: wave 0 forms the products 64 at a time, and every lane adds
+        // them in sample order (v_readlane: one chain, uniform over the wave).  Until round 6 the sums were taken in double --
+        // the same sigma to 1e-6, which decides nothing about one candidate's sub-bin angle but does decide between two offsets.
+        exact_lds_sync<GM>();
+        if (lane < 64) {
+            float avf = 0.f, sqf = 0.f;
+            for (int i0 = 0; i0 < g.lcirc; i0 += 64) {
+                const int i = i0 + lane;
+                const float v = i < g.lcirc ? circ[i] : 0.f, w = i < g.lcirc ? g.samp_w[i] : 0.f;
+                const float p1 = v * w, p2 = v * v * w;          // (padding lanes add +0: no change)
+#pragma unroll
+                for (int k = 0; k < 64; k++) {
+                    avf += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p1), k));
+                    sqf += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p2), k));
+                }
+            }
+            if (lane == 0) { red[0] = (double)avf; red[1] = (double)sqf; }
+        }
+        exact_lds_sync<GM>();
+        const float nn = g.nn_weight, avf = (float)red[0], sqf = (float)red[1];
         const float avg = avf / nn;
         const float sgm = sqrtf((sqf - avf * avf / nn) / nn);
         exact_lds_sync<GM>();
@@ -303,6 +319,10 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     extern __shared__ __align__(16) float lds[];
     __shared__ double red[4];
     __shared__ int redi[4];
+    __shared__ long long cand_key[RA_TIE_ALTS + 1];          // the candidates of a float tie: scan-order key, (reference, mirror, bin,
+    __shared__ int cand_inf[RA_TIE_ALTS + 1][4];             // offset), the 7 CCF samples around the maximum (double)
+    __shared__ double cand_b[RA_TIE_ALTS + 1][7];
+    __shared__ int cand_win;
     const int lane = threadIdx.x;
     float *circ, *work;
     if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
@@ -327,23 +347,65 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     double b[7];
     exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
                         circ, work, lane, red, redi, twd, xs);
-    if (rec.bs2 >= 0) {
-        // a second record within RA_TIE_RTOL of the winner: both peaks in the CPU path's arithmetic, and its order of the scan --
-        // offsets, then references, ascending, a later candidate wins with ">="; straight beats mirrored on equality
-        int jt2 = rec.jtot2;
-        double b2[7];
-        exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)rec.ref2 * g.lcirc), rec.bs2, rec.sxi, rec.syi,
-                            rec.mirror2 != 0, jt2, b2, circ, work, lane, red, redi, twd, xs);
-        const long long o1 = ((long long)bs << 32) | ((long long)(rec.rt2 & 0xffff) << 16) | (unsigned)ref;
-        const long long o2 = ((long long)rec.bs2 << 32) | ((long long)(rec.rt2 >> 16) << 16) | (unsigned)rec.ref2;
-        bool second_wins;
-        if (o1 == o2) second_wins = rec.mirror2 ? b2[3] > b[3] : b2[3] >= b[3];      // same (offset, reference): qn >= qm keeps straight
-        else second_wins = o2 > o1 ? b2[3] >= b[3] : b2[3] > b[3];
-        if (second_wins) {
-            ref = rec.ref2; mirror = rec.mirror2; jtot = jt2; bs = rec.bs2;
-#pragma unroll
-            for (int t = 0; t < 7; t++) b[t] = b2[t];
+    if (rec.nalt > 0) {
+        // the other candidates within the tie tolerance of the winner: every peak in the CPU path's arithmetic, then the CPU path's
+        // own scan over them -- offsets, then references, ascending; per (offset, reference) "if (qn >= peak || qm >= peak)
+        // { if (qn >= qm) straight else mirrored; peak = that }" -- replayed literally, because it is NOT a total order in the
+        // multi-reference entry point: Util::multiref_polar_ali_2d keeps `peak` as a FLOAT (peak = static_cast<float>(qn)) and
+        // compares the next double against the rounded value, so of two offsets whose maxima round to the same float the earlier
+        // one stays when its value was rounded up (108 / 46 / ts 0.5: both 6459.770508).  ormq keeps a double.
+        // candidates that are not in the list lie below the tolerance and cannot win; the list is replayed in scan order.
+        const int ncand = 1 + rec.nalt;
+        if (lane == 0) {
+            cand_key[0] = ((long long)bs << 32) | ((long long)rec.brt << 16) | (unsigned)ref;
+            cand_inf[0][0] = ref; cand_inf[0][1] = mirror; cand_inf[0][2] = jtot; cand_inf[0][3] = bs;
+            for (int t = 0; t < 7; t++) cand_b[0][t] = b[t];
         }
+        for (int ai = 0; ai < rec.nalt; ai++) {
+            const RefineAlt alt = rec.alt[ai];
+            const int ref2 = alt.refmir & 0xffff, mirror2 = alt.refmir >> 16;
+            int jt2 = 1;
+            double b2[7];
+            exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref2 * g.lcirc), alt.bs, rec.sxi, rec.syi,
+                                mirror2 != 0, jt2, b2, circ, work, lane, red, redi, twd, xs);
+            if (lane == 0) {
+                cand_key[ai + 1] = ((long long)alt.bs << 32) | ((long long)alt.rt << 16) | (unsigned)ref2;
+                cand_inf[ai + 1][0] = ref2; cand_inf[ai + 1][1] = mirror2; cand_inf[ai + 1][2] = jt2; cand_inf[ai + 1][3] = alt.bs;
+                for (int t = 0; t < 7; t++) cand_b[ai + 1][t] = b2[t];
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const bool float_peak = g.mode == RA_MODE_MREF;
+            double peak = -1.0e23;
+            int cur = -1;
+            unsigned used = 0;
+            for (int step = 0; step < ncand; step++) {
+                int c = -1;          // the next (offset, reference) in scan order
+                for (int k = 0; k < ncand; k++)
+                    if (!((used >> k) & 1) && (c < 0 || cand_key[k] < cand_key[c])) c = k;
+                if (c < 0) break;
+                int cs = -1, cm = -1;          // its straight and mirrored candidates (the first of each, duplicates are dropped)
+                for (int k = 0; k < ncand; k++)
+                    if (!((used >> k) & 1) && cand_key[k] == cand_key[c]) {
+                        used |= 1u << k;
+                        if (cand_inf[k][1]) { if (cm < 0) cm = k; } else { if (cs < 0) cs = k; }
+                    }
+                const double qn = cs >= 0 ? cand_b[cs][3] : -1.0e300, qm = cm >= 0 ? cand_b[cm][3] : -1.0e300;
+                if (qn >= peak || qm >= peak) {
+                    cur = qn >= qm ? cs : cm;
+                    const double v = qn >= qm ? qn : qm;
+                    peak = float_peak ? (double)(float)v : v;
+                }
+            }
+            cand_win = cur < 0 ? 0 : cur;
+        }
+        __syncthreads();
+        const int wsel = cand_win;
+        ref = cand_inf[wsel][0]; mirror = cand_inf[wsel][1]; jtot = cand_inf[wsel][2]; bs = cand_inf[wsel][3];
+#pragma unroll
+        for (int t = 0; t < 7; t++) b[t] = cand_b[wsel][t];
+        __syncthreads();
     }
     if (lane == 0) {
         const double c2 = 49. * b[0] + 6. * b[1] - 21. * b[2] - 32. * b[3] - 27. * b[4] - 6. * b[5] + 31. * b[6];

@@ -1085,6 +1085,10 @@ struct CandT { float val; int jtot; int refmir; float t7[7]; };
 // comes within RA_TIE_RTOL of it, the record's jtot word carries that runner-up as well, so that finalize_kernel can hand
 // both to the exact re-evaluation: bits 0-12 jtot | 13-20 runner-up reference + 1 (0: none) | 21 its mirror flag | 22-31 its jtot
 #define RA_TIE_RTOL 3.0e-6f      // f32 peaks closer than this (relative) are re-evaluated in the CPU path's arithmetic
+// ... and records of DIFFERENT search offsets under Normalize_ring closer than this: the CPU path's sigma of an offset comes out of a
+// float sum over lcirc samples (a rounding walk of ~1.3e-6 of sigma at 5816 samples, one sigma), so two offsets whose exact maxima differ
+// by 3e-6 are still ordered either way by it (P ~ 5 %; 1e-5: ~1e-8).  exact_candidate repeats the walk bit for bit.
+#define RA_TIE_RTOL_OFFSETS 1.0e-5f
 __device__ __forceinline__ int cand_pack_runner(int jtot, const CandT &ru)
 {
     return (jtot & 0x1fff) | ((((ru.refmir & 0xffff) + 1) & 0xff) << 13) | (((ru.refmir >> 16) & 1) << 21) | ((ru.jtot & 0x3ff) << 22);
@@ -1492,19 +1496,26 @@ __global__ __launch_bounds__(RA_CCF_THREADS, RA_CCF_THREADS >= 1024 ? 4 : 2) voi
 // the ">=" rule of Util::multiref_polar_ali_2d, ang_n, the ormq tail and combine_params2
 // (test_mref_gpu_align.py:1043-1049).
 // record of a particle whose sub-bin angle is to be re-evaluated with the CPU path's arithmetic (ralign_exact.h)
-// (ref2, mirror2, jtot2, bs2): the runner-up of the offset / reference-tile scan when its peak is within RA_TIE_RTOL of the
-// winner's (bs2 = -1: none) -- the exact re-evaluation then decides between the two with the CPU path's ">=" order
-struct RefineRec { int p, ref, mirror, jtot, bs; float sxi, syi; int ref2, mirror2, jtot2, bs2, rt2; };
+// alt[0 .. nalt): every OTHER candidate whose f32 peak lies within RA_TIE_RTOL of the winner's -- a runner-up reference of the winning
+// offset (cand_pack_runner), the records of other offsets / reference tiles and their runner-ups -- (offset, reference tile,
+// reference | mirror << 16).  The exact re-evaluation decides among all of them with the CPU path's ">=" order.  A ridge of the CCF
+// in (shift, angle) -- half- or quarter-pixel steps -- puts three and more offsets within 1e-6 of each other: until round 6 the
+// record carried ONE runner-up, and a third candidate that the f64 CCF ranks first was lost (scripts/dev/random_legacy_sweep.py,
+// 77 / 29 / ts 0.5).  More than RA_TIE_ALTS near-ties: the first RA_TIE_ALTS in scan order.
+#define RA_TIE_ALTS 7
+struct RefineAlt { int bs, rt, refmir; };
+struct RefineRec { int p, ref, mirror, jtot, bs, brt; float sxi, syi; int nalt; RefineAlt alt[RA_TIE_ALTS]; };
 
 // rlist / rcount / rthr: particles whose prb1d is ill-conditioned (|c3| < rthr x max |b|; rthr < 0: every particle) are
 // appended to rlist for refine_winner_kernel; rlist = null: none
 // everything behind the scan over the records: prb1d / ang_n / ormq tail / combine_params2 of the winner (bs, brt), the result
-// record and the new state, and the hand-over to refine_winner_kernel (flat peaks and float ties; (s2, rt2) = the record with the
-// second-largest peak, s2 < 0: none)
-__device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__restrict__ cand, int nrtile, int p, const Window &w,
-                                              CandT best, int bs, int brt, float second, int s2, int rt2, float *__restrict__ state,
+// record and the new state, and the hand-over to refine_winner_kernel (flat peaks and float ties; second = the second-largest
+// record peak; scan(fn) calls fn(offset, reference tile, record) for every in-window record of the particle, in scan order)
+template <class Scan>
+__device__ __forceinline__ void finalize_tail(const DevGeom &g, int p, const Window &w,
+                                              CandT best, int bs, int brt, float second, float *__restrict__ state,
                                               ra_result *__restrict__ res, RefineRec *__restrict__ rlist, int *__restrict__ rcount,
-                                              float rthr, int p_base = 0, const CandT *__restrict__ c2rec = nullptr)
+                                              float rthr, int p_base, Scan scan)
 {
     const float peak = best.val;
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
@@ -1540,22 +1551,27 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, const CandT *__r
         // and the f64 CCF may order them differently); refine_winner_kernel decides them in the CPU path's arithmetic
         const float tol = RA_TIE_RTOL * fabsf(b[3]);
         const bool tie_bin = nb >= b[3] - tol;
-        const bool tie_rec = s2 >= 0 && second >= peak - RA_TIE_RTOL * fabsf(peak);
+        const float thr = peak - (g.norm_ring ? RA_TIE_RTOL_OFFSETS : RA_TIE_RTOL) * fabsf(peak);
+        const bool tie_rec = second >= thr;
         const int runner = (jword >> 13) & 0xff;          // another reference of the winning offset within the tolerance
         if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner) {
-            RefineRec rec;
+            RefineRec *rec = rlist + atomicAdd(rcount, 1);
             // (p_base: index of the chunk's first particle when the list spans a whole call)
-            rec.p = p_base + p; rec.ref = ref; rec.mirror = mirror; rec.jtot = best.jtot; rec.bs = bs; rec.sxi = w.sxi; rec.syi = w.syi;
-            rec.bs2 = -1; rec.ref2 = 0; rec.mirror2 = 0; rec.jtot2 = 1; rec.rt2 = brt;
-            if (runner) {
-                rec.bs2 = bs; rec.ref2 = runner - 1; rec.mirror2 = (jword >> 21) & 1; rec.jtot2 = (jword >> 22) & 0x3ff;
-                rec.rt2 = (brt << 16) | brt;
-            } else if (tie_rec) {
-                const CandT *c = c2rec ? c2rec : cand + ((size_t)p * g.ent_stride + s2) * nrtile + rt2;
-                rec.bs2 = s2; rec.ref2 = c->refmir & 0xffff; rec.mirror2 = c->refmir >> 16; rec.jtot2 = cand_jtot(c->jtot);
-                rec.rt2 = (rt2 << 16) | brt;          // scan order of the two records: (offset, reference tile)
-            }
-            rlist[atomicAdd(rcount, 1)] = rec;
+            rec->p = p_base + p; rec->ref = ref; rec->mirror = mirror; rec->jtot = best.jtot; rec->bs = bs; rec->brt = brt;
+            rec->sxi = w.sxi; rec->syi = w.syi;
+            int nalt = 0;
+            auto add = [&](int as, int art, int aref, int amir) {
+                if (nalt < RA_TIE_ALTS) { rec->alt[nalt].bs = as; rec->alt[nalt].rt = art; rec->alt[nalt].refmir = aref | (amir << 16); nalt++; }
+            };
+            if (runner) add(bs, brt, runner - 1, (jword >> 21) & 1);
+            if (tie_rec)
+                scan([&](int cs, int crt, const CandT &cr) {
+                    if ((cs == bs && crt == brt) || !(cr.val >= thr)) return;
+                    add(cs, crt, cr.refmir & 0xffff, cr.refmir >> 16);
+                    const int ru = (cr.jtot >> 13) & 0xff;
+                    if (ru) add(cs, crt, ru - 1, (cr.jtot >> 21) & 1);
+                });
+            rec->nalt = nalt;
         }
     }
 }
@@ -1570,34 +1586,37 @@ __global__ void finalize_kernel(DevGeom g, const CandT *__restrict__ cand, int n
     float peak = -1.0e23f, second = -1.0e23f;
     CandT best; best.val = peak; best.jtot = 1; best.refmir = 0;
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
-    int bs = 0, brt = 0, s2 = -1, rt2 = 0;          // (s2, rt2): the record with the second-largest peak
+    int bs = 0, brt = 0;
     const int nx1 = 2 * g.nkx + 1;
     if (g.ent_base) {          // live-offset lists: the particle's records are those of its in-window offsets, in scan order
         const int e0 = g.ent_base[p], L = g.ent_base[p + 1] - e0;
-        const CandT *c2 = nullptr, *cb = nullptr;
-        for (int j = 0; j < L; j++) {
-            const int s = live_shift(g, w, j);
-            for (int rt = 0; rt < nrtile; rt++) {
-                const CandT *c = cand + ((size_t)e0 + j) * nrtile + rt;
-                const float v = c->val;
-                if (v >= peak) { second = peak; s2 = bs; rt2 = brt; c2 = cb; peak = v; best = *c; bs = s; brt = rt; cb = c; }
-                else if (v >= second) { second = v; s2 = s; rt2 = rt; c2 = c; }
+        auto scan = [&](auto fn) {
+            for (int j = 0; j < L; j++) {
+                const int s = live_shift(g, w, j);
+                for (int rt = 0; rt < nrtile; rt++) fn(s, rt, cand[((size_t)e0 + j) * nrtile + rt]);
             }
-        }
-        finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr, p_base, c2);
+        };
+        scan([&](int s, int rt, const CandT &c) {
+            const float v = c.val;
+            if (v >= peak) { second = peak; peak = v; best = c; bs = s; brt = rt; }
+            else if (v >= second) second = v;
+        });
+        finalize_tail(g, p, w, best, bs, brt, second, state, res, rlist, rcount, rthr, p_base, scan);
         return;
     }
-    for (int s = 0; s < g.nshift; s++) {
-        const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
-        if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
-        for (int rt = 0; rt < nrtile; rt++) {
-            const CandT *c = cand + ((size_t)p * g.ent_stride + s) * nrtile + rt;
-            const float v = c->val;
-            if (v >= peak) { second = peak; s2 = bs; rt2 = brt; peak = v; best = *c; bs = s; brt = rt; }
-            else if (v >= second) { second = v; s2 = s; rt2 = rt; }
+    auto scan = [&](auto fn) {
+        for (int s = 0; s < g.nshift; s++) {
+            const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
+            if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
+            for (int rt = 0; rt < nrtile; rt++) fn(s, rt, cand[((size_t)p * g.ent_stride + s) * nrtile + rt]);
         }
-    }
-    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, second, s2, rt2, state, res, rlist, rcount, rthr, p_base);
+    };
+    scan([&](int s, int rt, const CandT &c) {
+        const float v = c.val;
+        if (v >= peak) { second = peak; peak = v; best = c; bs = s; brt = rt; }
+        else if (v >= second) second = v;
+    });
+    finalize_tail(g, p, w, best, bs, brt, second, state, res, rlist, rcount, rthr, p_base, scan);
 }
 
 // the same with one WAVE per particle, for paths that leave many records per particle (the generic kernels: 121 offsets x 13
@@ -1641,14 +1660,20 @@ __global__ __launch_bounds__(64) void finalize_wave_kernel(DevGeom g, const Cand
     for (int k = 0; k < 7; k++) best.t7[k] = 0.f;
     int bs = 0, brt = 0;
     if (bi >= 0) { best = cand[(size_t)e0 * nrtile + bi]; bs = bi / nrtile; brt = bi - bs * nrtile; }
-    int s2 = si >= 0 ? si / nrtile : -1;
-    const int rt2 = si >= 0 ? si - s2 * nrtile : 0;
-    const CandT *c2 = si >= 0 ? cand + (size_t)e0 * nrtile + si : nullptr;
-    if (live) {          // positions in the live list -> indices of the offset list
-        bs = bi >= 0 ? live_shift(g, w, bs) : 0;
-        if (s2 >= 0) s2 = live_shift(g, w, s2);
-    }
-    finalize_tail(g, cand, nrtile, p, w, best, bs, brt, sv, s2, rt2, state, res, rlist, rcount, rthr, p_base, c2);
+    if (live) bs = bi >= 0 ? live_shift(g, w, bs) : 0;          // position in the live list -> index of the offset list
+    auto scan = [&](auto fn) {
+        for (int li = 0; li < nrec; li++) {
+            int s = li / nrtile;
+            const int rt = li - s * nrtile;
+            if (live) s = live_shift(g, w, s);
+            else {
+                const int iy = s / nx1 - g.nky, ix = s % nx1 - g.nkx;
+                if (ix < -w.lkx || ix > w.rkx || iy < -w.lky || iy > w.rky) continue;
+            }
+            fn(s, rt, cand[(size_t)e0 * nrtile + li]);
+        }
+    };
+    finalize_tail(g, p, w, best, bs, brt, sv, state, res, rlist, rcount, rthr, p_base, scan);
 }
 
 // ------------------------------------------------------------------------------------------

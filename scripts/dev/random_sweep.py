@@ -36,6 +36,7 @@ for case in range(ncase):
     if rand_opt:
         interp = api.RA_INTERP_QUADRI if rng.random() < 0.4 else api.RA_INTERP_BILINEAR
         norm = int(rng.choice([-1, 0, 1])) if mode == api.RA_MODE_MREF else -1
+    nomirror = bool(rand_opt and mode == api.RA_MODE_REFFREE and rng.random() < 0.4)      # --nomirror: ormq(nomirror) -> Crosrng_ns
     o_interp = orc.INTERP_QUADRI if interp == api.RA_INTERP_QUADRI else orc.INTERP_BILINEAR
     o_norm = (mode == api.RA_MODE_MREF) if norm < 0 else bool(norm)
     refs = synth.make_references(nref, nx, ou)
@@ -57,9 +58,15 @@ for case in range(ncase):
     else:
         params = np.zeros((n, 6), np.float32)
         params[:, 1:3] = -d0
-        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8, interp=o_interp)
+        orc.set_nomirror(nomirror)
+        try:
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, params, nthreads=8, interp=o_interp)
+        finally:
+            orc.set_nomirror(False)
     eng = api.Engine(nx, ou, xr, yr, ts, nref, mode, first_ring=ir, ring_skip=rs, interp=interp, normalize_ring=None if norm < 0 else bool(norm))
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(eng.dev))
+    if nomirror:
+        eng.set_nomirror(True)
     tp = torch.from_numpy(parts).to(eng.dev)
     st, res = torch.from_numpy(d0.copy()).to(eng.dev), eng.new_result(n)
     eng.align(tp, st, res)
@@ -77,5 +84,5 @@ for case in range(ncase):
         print(" assignment oracle", [(int(params[i, 4]), int(params[i, 3]), infos[i].jtot) for i in range(n)], d.tolist())
         raise
     eng.close()
-    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d interp=%d norm=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, interp, norm, path), flush=True)
+    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d interp=%d norm=%d nomirror=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, interp, norm, nomirror, path), flush=True)
 print("all %d cases agree with the checker" % ncase)

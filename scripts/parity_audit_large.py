@@ -38,6 +38,13 @@ CASES = {
     "box96": (96, 36, 3, 10, None),                     # search_pair_kernel with ring buffers grown to hold a tile's spectra
     "box128r38": (128, 38, 3, 10, None),                # search_fused_kernel on a crop with the rings 4 floats apart
     "box256": (256, 36, 3, 10, None),                   # search_pair_kernel on a crop of the image around the particle's centre
+    # half-pixel steps: a ridge of the CCF in (shift, angle) puts neighbouring offsets within 1e-6 of each other far more often than
+    # whole-pixel steps do (round 6: the float sums of Normalize_ring and the float `peak` of multiref_polar_ali_2d decide those)
+    "mref_half": (90, 36, 2, 10, None, 0.5),            # search_fused_kernel, 81 offsets
+    "mref_half_xr1": (90, 36, 1, 10, None, 0.5),        # 25 offsets
+    "reffree_half": (90, 36, 2, 1, "template", 0.5),
+    "box100_half": (100, 40, 1, 10, None, 0.5),         # search_pair_kernel
+    "nb00_half": (130, 52, 1, 20, None, 0.5),           # search_solo / duo kernels
     "largebox": (256, 120, 5, 100, None),               # BASELINE configs[4] geometry (generic kernels); at most 8192 particles: the oracle needs ~0.5 s of 16 threads each
 }
 CAPS = {"largebox": 8192, "box256": 16384}
@@ -68,7 +75,8 @@ def run_case(name, n, sigma, dev, threads, interp=0, normalize=None):
     """interp / normalize: the engine options of include/ralign.h (ra_options) against the oracle's own switches -- 1 = Util::quadri in
     alrl_ms, normalize = False / True = Normalize_ring off / on whatever the mode (None: the mode's default)"""
     from cryo_ralib_amd import geometry
-    nx, ou, xr, nref, rf = CASES[name]
+    nx, ou, xr, nref, rf = CASES[name][:5]
+    ts = CASES[name][5] if len(CASES[name]) > 5 else 1.0
     refs_np = synth.make_references(max(nref, 1), nx, ou)
     parts_t, _ = bench.generate_shard(dev, refs_np, n, xr, xr, sigma, 11, nx, ou)
     rg = orc.rings(1, ou, 1)
@@ -82,16 +90,16 @@ def run_case(name, n, sigma, dev, threads, interp=0, normalize=None):
         tavg = parts.mean(0)[None].astype(np.float32) if rf == "blob" else refs_np[:1]
         refs_n, cref = orc.prepare_refs(tavg, None, rg, interp=interp)
         if normalize:          # ormq on normalised rings = the one-reference multi-reference search from a zero state (windows coincide)
-            params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=threads, interp=interp, normalize=True)
+            params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, ts, d, nthreads=threads, interp=interp, normalize=True)
         else:
-            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=threads, interp=interp)
+            params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, ts, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=threads, interp=interp)
         mode = api.RA_MODE_REFFREE
     else:
         refs_n, cref = orc.prepare_refs(refs_np, mask, rg, interp=interp)
-        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=threads, interp=interp, normalize=True if normalize is None else bool(normalize))
+        params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, ts, d, nthreads=threads, interp=interp, normalize=True if normalize is None else bool(normalize))
         mode = api.RA_MODE_MREF
     t_or = time.time() - t0
-    eng = api.Engine(nx, ou, xr, xr, 1.0, refs_n.shape[0], mode, device=dev.index, interp=interp, normalize_ring=normalize)
+    eng = api.Engine(nx, ou, xr, xr, ts, refs_n.shape[0], mode, device=dev.index, interp=interp, normalize_ring=normalize)
     eng.set_references(torch.from_numpy(np.ascontiguousarray(refs_n)).to(dev))
     st, res = eng.new_state(n), eng.new_result(n)
     eng.align(torch.from_numpy(parts).to(dev), st, res)
@@ -101,12 +109,12 @@ def run_case(name, n, sigma, dev, threads, interp=0, normalize=None):
     path, tiled, maxrin = eng.search_path, eng.search_tiled, eng.maxrin
     eng.close()
     jt = np.array([infos[i].jtot for i in range(n)])
-    shifts = geometry.shift_list(xr, xr, 1.0).astype(np.float32)
+    shifts = geometry.shift_list(xr, xr, ts).astype(np.float32)
     flips, kinds = classify(r, params, jt, d, np.zeros_like(d), shifts, maxrin)
     rel = np.abs(r["peak"] - params[:, 5]) / np.abs(params[:, 5])
     ok = (r["ref_id"] == params[:, 4].astype(int)) & (r["mirror"] == params[:, 3].astype(int)) & (r["angle_bin"] == jt)
     da = np.abs(((r["alpha"][ok] - params[ok, 0]) + 180.0) % 360.0 - 180.0)
-    rec = {"workload": name + (" / quadri" if interp else "") + ("" if normalize is None else " / Normalize_ring %s" % ("on" if normalize else "off")), "geometry": {"nx": nx, "ou": ou, "xr": xr, "nref": refs_n.shape[0]}, "particles": n, "sigma": sigma,
+    rec = {"workload": name + (" / quadri" if interp else "") + ("" if normalize is None else " / Normalize_ring %s" % ("on" if normalize else "off")), "geometry": {"nx": nx, "ou": ou, "xr": xr, "ts": ts, "nref": refs_n.shape[0]}, "particles": n, "sigma": sigma,
            "search_path": bench.SEARCH_PATHS[path] + (" (tiled)" if tiled else ""), "tie_flips": flips, "flip_classes": kinds,
            "max_rel_peak": float(rel.max()), "alpha_outliers_gt_2e-3_deg": int((da > 2e-3).sum()),
            "max_alpha_diff_deg": float(da.max()) if da.size else 0.0, "refined_by_exact_kernel": refined,
