@@ -94,13 +94,14 @@ for case in range(ncase):
         al.close()
     else:
         al = RefFreeAligner(parts, ou, str(xr), str(yr), str(ts), ir=ir, rs=rs, chunk=chunk, refine=-1)
+        center = -1 if rng.random() < 0.5 else 0          # the average-centre rule: states off the step grid from the second iteration on
         for it in range(NIT):
             prev = params6(al.params())
             d = al.state.cpu().numpy().copy()
-            al.iterate(0, None)
+            al.iterate(center, None)
             al.engine.sync()
             _, cref = orc.prepare_refs(al.tavg.cpu().numpy(), None, rg)
-            params, infos, sums, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, (0, 0), d, prev.copy(), nthreads=16)
+            params, infos, sums, _ = orc.reffree_iteration(parts, cref[0], rg, xr, yr, ts, al.cs, d, prev.copy(), nthreads=16)
             r = al.params()
             assert compare_search(r, al.state.cpu().numpy(), params, infos, d) == 0
             alpha_to_the_ulp(r["alpha"], params[:, 0])
@@ -113,6 +114,6 @@ for case in range(ncase):
             df = np.abs(got - want)
             nbig = int((df > 1e-4 * sc).sum())
             assert nbig <= max(4, df.size // 200), (nbig, df.size, float(df.max()), sc)
-        print("   path %d (%d offsets per pass), %d iterations ok" % (al.engine.search_path, al.engine.search_offsets_per_pass, NIT), flush=True)
+        print("   path %d (%d offsets per pass), %d iterations ok (center %d, last cs %.3f %.3f)" % (al.engine.search_path, al.engine.search_offsets_per_pass, NIT, center, al.cs[0], al.cs[1]), flush=True)
         al.close()
 print("all %d cases agree with the checker" % ncase)

@@ -20,17 +20,22 @@ ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 big = len(sys.argv) > 3 and sys.argv[3] in ("big", "huge")
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"      # boxes of 140 .. 230 pixels, ou 61 .. 100: the size-generic class (polar_zone_kernel)
+wide = len(sys.argv) > 5 and sys.argv[5] == "wide"      # odd steps, fractional ranges, fractional states, up to 130 references
 rand_state = len(sys.argv) > 4 and sys.argv[4] in ("state", "state+options")
 rand_opt = len(sys.argv) > 4 and sys.argv[4] in ("options", "state+options")      # Util::quadri sampling / Normalize_ring against the mode
 for case in range(ncase):
     xr = int(rng.integers(0, 4)); yr = int(rng.integers(0, 4))
     nx = int(rng.integers(140, 231)) if huge else int(rng.integers(64, 161)) if big else int(rng.integers(36, 101))
-    oumax = (nx - 1) // 2 - max(xr, yr) - 1
+    oumax = (nx - 1) // 2 - max(xr, yr) - 2
     ou = int(rng.integers(61, min(100, oumax) + 1)) if huge else int(rng.integers(24, min(78, oumax) + 1)) if big else int(rng.integers(8, min(40, oumax) + 1))
     ir = int(rng.integers(1, 4)); rs = int(rng.integers(1, 3))
-    ts = float(rng.choice([1.0, 1.0, 0.5]))
+    ts = float(rng.choice([1.0, 1.0, 0.5])) if not wide else float(rng.choice([1.0, 0.5, 0.25, 0.75, 1.5, 2.0, 3.0]))
+    if wide and rng.random() < 0.4:          # fractional ranges: int(range / step) offsets, the range itself in search_range
+        xr = float(xr) + float(rng.choice([0.25, 0.5, 0.8])); yr = float(yr) + float(rng.choice([0.0, 0.5, 0.8]))
     mode = api.RA_MODE_MREF if rng.random() < 0.7 else api.RA_MODE_REFFREE
     nref = (int(rng.integers(1, 21)) if huge else int(rng.integers(1, 61)) if big else int(rng.integers(1, 17))) if mode == api.RA_MODE_MREF else 1
+    if wide and mode == api.RA_MODE_MREF and not huge and rng.random() < 0.25:
+        nref = int(rng.integers(60, 131))
     n = int(rng.integers(2, 6)) if huge else int(rng.integers(3, 9)) if big else int(rng.integers(3, 20))
     interp, norm = api.RA_INTERP_BILINEAR, -1
     if rand_opt:
@@ -49,6 +54,8 @@ for case in range(ncase):
         mashi = nx // 2 + 1 - ou - 2
         lim = int((mashi + 1) / ts)
         d = (rng.integers(-lim, lim + 1, size=(n, 2)) * ts).astype(np.float32)
+        if wide:          # states off the step grid (the centre correction of ali2d_single_iter leaves arbitrary fractions)
+            d = (d + (rng.random((n, 2)) < 0.5) * rng.uniform(-0.5, 0.5, size=(n, 2))).astype(np.float32)
     d0 = d.copy()
     if rand_state:      # the particle sits where its state says (a search centred 20 pixels beside it would only find noise peaks near zero)
         for i in range(n):
@@ -76,7 +83,7 @@ for case in range(ncase):
         compare_search(api.Engine.result_to_numpy(res), st.cpu().numpy(), params, infos, d)
     except AssertionError:
         r = api.Engine.result_to_numpy(res)
-        print("case %d FAILED: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path))
+        print("case %d FAILED: nx=%d ou=%d ir=%d rs=%d xr=%g yr=%g ts=%g nref=%d n=%d mode=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, path))
         print(" start states", d0.tolist())
         print(" peaks engine", r["peak"].tolist())
         print(" peaks oracle", params[:, 5].tolist())
@@ -84,5 +91,5 @@ for case in range(ncase):
         print(" assignment oracle", [(int(params[i, 4]), int(params[i, 3]), infos[i].jtot) for i in range(n)], d.tolist())
         raise
     eng.close()
-    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%d yr=%d ts=%g nref=%d n=%d mode=%d interp=%d norm=%d nomirror=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, interp, norm, nomirror, path), flush=True)
+    print("case %2d ok: nx=%d ou=%d ir=%d rs=%d xr=%g yr=%g ts=%g nref=%d n=%d mode=%d interp=%d norm=%d nomirror=%d path=%s" % (case, nx, ou, ir, rs, xr, yr, ts, nref, n, mode, interp, norm, nomirror, path), flush=True)
 print("all %d cases agree with the checker" % ncase)
