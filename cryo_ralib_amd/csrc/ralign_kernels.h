@@ -1686,7 +1686,9 @@ __device__ __forceinline__ float quadri_background_1b(const float *fdata, int nx
 {
 #pragma clang fp contract(off)
     float x = xx, y = yy;
-    if ((x < 1.0f) || (x >= (float)(nx + 1)) || (y < 1.0f) || (y >= (float)(ny + 1))) { x = (float)xnew; y = (float)ynew; }
+    // (written as the negation of "inside": a NaN position -- the parameters of a NaN particle -- takes the background branch too,
+    // instead of (int)NaN = 0 indexing one row in front of the image)
+    if (!((x >= 1.0f) && (x < (float)(nx + 1)) && (y >= 1.0f) && (y < (float)(ny + 1)))) { x = (float)xnew; y = (float)ynew; }
     int i = (int)x, j = (int)y;
     float dx0 = x - i, dy0 = y - j;
     int ip1 = i + 1, im1 = i - 1, jp1 = j + 1, jm1 = j - 1;
@@ -1864,7 +1866,7 @@ __device__ __forceinline__ float quadri_background_wrap(const float *P, int pst,
 {
 #pragma clang fp contract(off)
     float x = xx, y = yy;
-    if ((x < 1.0f) || (x >= (float)(nx + 1)) || (y < 1.0f) || (y >= (float)(nx + 1))) { x = (float)xnew; y = (float)ynew; }
+    if (!((x >= 1.0f) && (x < (float)(nx + 1)) && (y >= 1.0f) && (y < (float)(nx + 1)))) { x = (float)xnew; y = (float)ynew; }          // (NaN: background)
     const int i = (int)x, j = (int)y;
     const float dx0 = x - i, dy0 = y - j;
     const float *q = P + j * pst + i;
@@ -2074,7 +2076,7 @@ __global__ __launch_bounds__(RA_XT_THREADS) void transform_sum_tile_kernel(int n
                 const float yold = xsang + ycang;
                 const float X = xold + 1.0f, Y = yold + 1.0f;
                 float v;
-                if ((X < 1.0f) || (X >= (float)(nx + 1)) || (Y < 1.0f) || (Y >= (float)(nx + 1))) {
+                if (!((X >= 1.0f) && (X < (float)(nx + 1)) && (Y >= 1.0f) && (Y < (float)(nx + 1)))) {          // (NaN: background)
                     v = own[iy * nx];
                 } else if (cur.mirror && tx < mstart) {
                     v = quadri_background_1b(particles + (size_t)mem[j] * npix, nx, nx, X, Y, ix + 1, iy + 1);
