@@ -1086,8 +1086,8 @@ struct CandT { float val; int jtot; int refmir; float t7[7]; };
 // both to the exact re-evaluation: bits 0-12 jtot | 13-20 runner-up reference + 1 (0: none) | 21 its mirror flag | 22-31 its jtot
 #define RA_TIE_RTOL 3.0e-6f      // f32 peaks closer than this (relative) are re-evaluated in the CPU path's arithmetic
 // ... and records of DIFFERENT search offsets under Normalize_ring closer than this: the CPU path's sigma of an offset comes out of a
-// float sum over lcirc samples (a rounding walk of ~1.3e-6 of sigma at 5816 samples, one sigma), so two offsets whose exact maxima differ
-// by 3e-6 are still ordered either way by it (P ~ 5 %; 1e-5: ~1e-8).  exact_candidate repeats the walk bit for bit.
+// float sum over lcirc samples (a rounding walk of ~1e-6 of the peak at 5816 samples, one sigma), so two offsets whose exact maxima
+// differ by 3e-6 are still ordered either way by it now and then.  exact_candidate repeats the walk bit for bit.
 #define RA_TIE_RTOL_OFFSETS 1.0e-5f
 __device__ __forceinline__ int cand_pack_runner(int jtot, const CandT &ru)
 {
@@ -1551,7 +1551,9 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, int p, const Win
         // and the f64 CCF may order them differently); refine_winner_kernel decides them in the CPU path's arithmetic
         const float tol = RA_TIE_RTOL * fabsf(b[3]);
         const bool tie_bin = nb >= b[3] - tol;
-        const float thr = peak - (g.norm_ring ? RA_TIE_RTOL_OFFSETS : RA_TIE_RTOL) * fabsf(peak);
+        // (the walk grows with the sample count: 3.4e-8 sqrt(lcirc / 3) of sq, one sigma -- 1.1e-6 between two offsets at 5816 samples,
+        // 3.7e-6 at the 71 k samples of a 256-pixel box with ou = 120: 1e-5 up to 10 k samples, 1e-7 sqrt(lcirc) beyond)
+        const float thr = peak - (g.norm_ring ? fmaxf(RA_TIE_RTOL_OFFSETS, 1.0e-7f * sqrtf((float)g.lcirc)) : RA_TIE_RTOL) * fabsf(peak);
         const bool tie_rec = second >= thr;
         const int runner = (jword >> 13) & 0xff;          // another reference of the winning offset within the tolerance
         if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner) {

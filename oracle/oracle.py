@@ -188,6 +188,11 @@ def set_nomirror(flag):
     lib().orc_set_nomirror(int(bool(flag)))
 
 
+def set_ormq_normalize(flag):
+    """ormq with Normalize_ring between Polar2Dm and Frngs (checker of the engine option normalize_ring = 1 in RA_MODE_REFFREE)"""
+    lib().orc_set_ormq_normalize(int(bool(flag)))
+
+
 def model_circle(r, nx, ny, edge_le=True):
     m = np.zeros((ny, nx), np.float32)
     lib().orc_model_circle(r, nx, ny, _f(m), int(edge_le))

@@ -432,6 +432,10 @@ void orc_multiref_polar_ali_2d(const float *img, int nx, int ny,
  * (test_reffree_gpu_align.py:846 passes nomirror down to ali2d_single_iter -> ormq).  Process-wide switch of the checker. */
 static int g_nomirror = 0;
 void orc_set_nomirror(int flag) { g_nomirror = flag; }
+/* hedge of include/ralign.h (ra_options.normalize_ring = 1 in RA_MODE_REFFREE): ormq with Util::Normalize_ring between Polar2Dm and
+ * Frngs -- ormq's own rules otherwise (double peak, clamped shifts).  Process-wide switch of the checker, off by default. */
+static int g_ormq_normalize = 0;
+void orc_set_ormq_normalize(int flag) { g_ormq_normalize = flag; }
 
 /* sp_alignment.ormq : single reference, python doubles, no Normalize_ring
  * (reference call: test_reffree_gpu_align.py:844-847 -> ali2d_single_iter -> ormq) */
@@ -450,6 +454,7 @@ void orc_ormq(const float *img, int nx, int ny, const float *crefim,
         for (int j = -lkx; j <= rkx; j++) {
             double ix = (double)j * step;
             orc_polar2dm(img, nx, ny, (float)(cnx + ix), (float)(cny + iy), rg, cimage, interp);
+            if (g_ormq_normalize) orc_normalize_ring(cimage, rg);
             orc_frngs(cimage, rg);
             double qn, qm; float tot, tmt; int jn, jm;
             orc_crosrng_ms(crefim, cimage, rg, &qn, &tot, &qm, &tmt, &jn, &jm);

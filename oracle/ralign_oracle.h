@@ -81,6 +81,7 @@ void orc_multiref_polar_ali_2d(const float *img, int nx, int ny,
 /* sp_alignment.ormq (single reference, no Normalize_ring; test_reffree_gpu_align.py:844-847).
  * out = {ang, sxs, sys, mirror, peak} */
 void orc_set_nomirror(int flag);
+void orc_set_ormq_normalize(int flag);   /* ormq on normalised rings (the engine option normalize_ring = 1 in reference-free mode) */
 void orc_ormq(const float *img, int nx, int ny, const float *crefim,
               const float xrng[2], const float yrng[2], float step,
               const orc_rings *rg, float cnx, float cny, int interp,

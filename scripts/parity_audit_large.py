@@ -45,9 +45,11 @@ CASES = {
     "reffree_half": (90, 36, 2, 1, "template", 0.5),
     "box100_half": (100, 40, 1, 10, None, 0.5),         # search_pair_kernel
     "nb00_half": (130, 52, 1, 20, None, 0.5),           # search_solo / duo kernels
+    "box150_half": (150, 66, 1, 10, None, 0.5),         # size-generic kernels (ring zones), lcirc = 24 k samples
+    "largebox_half": (256, 120, 1, 20, None, 0.5),      # configs[4] geometry at half-pixel steps, lcirc = 71 k samples
     "largebox": (256, 120, 5, 100, None),               # BASELINE configs[4] geometry (generic kernels); at most 8192 particles: the oracle needs ~0.5 s of 16 threads each
 }
-CAPS = {"largebox": 8192, "box256": 16384}
+CAPS = {"largebox": 8192, "box256": 16384, "largebox_half": 8192, "box150_half": 32768}
 
 
 def classify(r, params, jt, d_new, d_old, shifts, maxrin):
@@ -89,10 +91,13 @@ def run_case(name, n, sigma, dev, threads, interp=0, normalize=None):
     if rf:
         tavg = parts.mean(0)[None].astype(np.float32) if rf == "blob" else refs_np[:1]
         refs_n, cref = orc.prepare_refs(tavg, None, rg, interp=interp)
-        if normalize:          # ormq on normalised rings = the one-reference multi-reference search from a zero state (windows coincide)
-            params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, ts, d, nthreads=threads, interp=interp, normalize=True)
-        else:
+        # (normalize: ormq on normalised rings -- the checker's switch; the one-reference multi-reference search is NOT the same thing
+        # at float ties: Util::multiref_polar_ali_2d keeps its running peak as a float, ormq as a double)
+        orc.set_ormq_normalize(bool(normalize))
+        try:
             params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, ts, (0, 0), d, np.zeros((n, 6), np.float32), nthreads=threads, interp=interp)
+        finally:
+            orc.set_ormq_normalize(False)
         mode = api.RA_MODE_REFFREE
     else:
         refs_n, cref = orc.prepare_refs(refs_np, mask, rg, interp=interp)

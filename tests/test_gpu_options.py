@@ -82,9 +82,10 @@ def test_normalize_ring_off_in_multireference_mode(nx, ou, xr, nref, n, env, wan
                                                (90, 36, 3, {"RALIGN_GENERIC": "1"}, 2)],
                          ids=["fused-90-36", "fused-32-12", "pair-100-40", "generic"])
 def test_normalize_ring_on_in_reference_free_mode(nx, ou, xr, env, want, monkeypatch):
-    """RA_MODE_REFFREE with normalize_ring = 1: ormq's single-reference search on NORMALISED rings.  From a zero state the
-    windows of ormq (clamp) and of multiref_polar_ali_2d (reset) coincide, so the oracle's one-reference multi-reference
-    search is the statement to compare with; the peaks then differ from plain ormq's by the ring normalisation"""
+    """RA_MODE_REFFREE with normalize_ring = 1: ormq's single-reference search on NORMALISED rings -- the checker's ormq with
+    Normalize_ring between Polar2Dm and Frngs (orc.set_ormq_normalize).  From a zero state the windows of ormq (clamp) and of
+    multiref_polar_ali_2d (reset) coincide, so the one-reference multi-reference search finds the same peaks (it may order an
+    exact float tie of two offsets differently: its running peak is a float, ormq's a double)"""
     default_path_only("RALIGN_FUSED", "RALIGN_TILED", "RALIGN_GENERIC", "RALIGN_PAIR", "RALIGN_TCROP", "RALIGN_CROP")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -99,10 +100,17 @@ def test_normalize_ring_on_in_reference_free_mode(nx, ou, xr, env, want, monkeyp
     assert eng.search_path == want
     assert eng.options == (api.RA_INTERP_BILINEAR, 1)
     d1 = d.copy()
-    params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d1, nthreads=8, normalize=True)
+    orc.set_ormq_normalize(True)
+    try:
+        params, infos, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d1, np.zeros((n, 6), np.float32), nthreads=8)
+    finally:
+        orc.set_ormq_normalize(False)
     r, st = _search(eng, parts, refs_n)
     flips = compare_search(r, st, params, infos, d1)
     _log_flips("normalize_ring on / reffree / %d-%d %s" % (nx, ou, env or ""), n, flips)
+    dm = d.copy()
+    pm, _, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, dm, nthreads=8, normalize=True)
+    np.testing.assert_allclose(r["peak"], pm[:, 5], rtol=1e-4)
     # switched off at run time: plain ormq
     eng.set_normalize_ring(False)
     p0 = np.zeros((n, 6), np.float32)
