@@ -93,9 +93,17 @@ for case in range(ncase):
         print("   path %d (%d offsets per pass), %d iterations ok" % (al.engine.search_path, al.engine.search_offsets_per_pass, it + 1), flush=True)
         al.close()
     else:
-        al = RefFreeAligner(parts, ou, str(xr), str(yr), str(ts), ir=ir, rs=rs, chunk=chunk, refine=-1)
+        # a second stage on some cases (--xr "3 2" --ts "1 0.5": reset_shifts between the stages, test_reffree_gpu_align.py:355-357)
+        two = rng.random() < 0.4
+        xr2, yr2, ts2 = max(xr - 1, 0), max(yr - 1, 0), ts / 2
+        al = RefFreeAligner(parts, ou, "%d %d" % (xr, xr2) if two else str(xr), "%d %d" % (yr, yr2) if two else str(yr),
+                            "%g %g" % (ts, ts2) if two else str(ts), ir=ir, rs=rs, chunk=chunk, refine=-1)
         center = -1 if rng.random() < 0.5 else 0          # the average-centre rule: states off the step grid from the second iteration on
+        xr1, yr1, ts1 = xr, yr, ts
         for it in range(NIT):
+            if two and it >= 1:
+                al.set_stage(1)
+                xr, yr, ts = xr2, yr2, ts2
             prev = params6(al.params())
             d = al.state.cpu().numpy().copy()
             al.iterate(center, None)
@@ -114,6 +122,7 @@ for case in range(ncase):
             df = np.abs(got - want)
             nbig = int((df > 1e-4 * sc).sum())
             assert nbig <= max(4, df.size // 200), (nbig, df.size, float(df.max()), sc)
-        print("   path %d (%d offsets per pass), %d iterations ok (center %d, last cs %.3f %.3f)" % (al.engine.search_path, al.engine.search_offsets_per_pass, NIT, center, al.cs[0], al.cs[1]), flush=True)
+        print("   path %d (%d offsets per pass), %d iterations ok (center %d, last cs %.3f %.3f%s)" % (al.engine.search_path, al.engine.search_offsets_per_pass, NIT, center, al.cs[0], al.cs[1], ", second stage xr %d yr %d ts %g" % (xr2, yr2, ts2) if two else ""), flush=True)
+        xr, yr, ts = xr1, yr1, ts1
         al.close()
 print("all %d cases agree with the checker" % ncase)
