@@ -211,22 +211,22 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
         // ~1e-6 of sq over the 5816 samples of the headline geometry, different for every search offset -- and sigma scales the
         // peak.  Two OFFSETS whose CCF maxima lie within 1e-6 of each other (half-pixel steps: a ridge in (shift, angle)) are thus
         // ordered by that very walk, so the re-evaluation repeats it: wave 0 forms the products 64 at a time, and every lane adds
-        // them in sample order (v_readlane: one chain, uniform over the wave).  Until round 6 the sums were taken in double --
+        // them in sample order (v_readlane: one chain per wave, uniform over its lanes).  Until round 6 the sums were taken in double --
         // the same sigma to 1e-6, which decides nothing about one candidate's sub-bin angle but does decide between two offsets.
         exact_lds_sync<GM>();
-        if (lane < 64) {
-            float avf = 0.f, sqf = 0.f;
+        if (lane < 128) {          // wave 0 walks av, wave 1 walks sq: two independent chains, side by side on two SIMDs
+            const bool sq_wave = lane >= 64;
+            const int l = lane & 63;
+            float acc = 0.f;
             for (int i0 = 0; i0 < g.lcirc; i0 += 64) {
-                const int i = i0 + lane;
+                const int i = i0 + l;
                 const float v = i < g.lcirc ? circ[i] : 0.f, w = i < g.lcirc ? g.samp_w[i] : 0.f;
-                const float p1 = v * w, p2 = v * v * w;          // (padding lanes add +0: no change)
+                const float p = sq_wave ? v * v * w : v * w;          // (padding lanes add +0: no change)
 #pragma unroll
-                for (int k = 0; k < 64; k++) {
-                    avf += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p1), k));
-                    sqf += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p2), k));
-                }
+                for (int k = 0; k < 64; k++)
+                    acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), k));
             }
-            if (lane == 0) { red[0] = (double)avf; red[1] = (double)sqf; }
+            if (l == 0) red[sq_wave ? 1 : 0] = (double)acc;
         }
         exact_lds_sync<GM>();
         const float nn = g.nn_weight, avf = (float)red[0], sqf = (float)red[1];
