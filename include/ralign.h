@@ -140,7 +140,10 @@ typedef struct ra_result {
  *                   ra_set_refine follows the option.
  *   normalize_ring  Util::Normalize_ring between Polar2Dm and Frngs: -1 = by mode (RA_MODE_MREF on, as inside
  *                   Util.multiref_polar_ali_2d; RA_MODE_REFFREE off, as sp_alignment.ormq), 0 = off, 1 = on.  Every kernel family
- *                   honours it; the search window rule (reset vs clamp) stays the mode's. */
+ *                   honours it; everything else stays the mode's: the search window rule (mref_ali2d resets a shift beyond
+ *                   cnx - last_ring - 2 and cuts the windows with its last_ring argument; ali2d_single_iter clamps, with
+ *                   ou = numr[-3]) and the scan over offsets and references (Util::multiref_polar_ali_2d compares every candidate
+ *                   with its running peak ROUNDED TO FLOAT; ormq keeps a double) -- both reproduced literally, down to float ties. */
 #define RA_INTERP_BILINEAR 0
 #define RA_INTERP_QUADRI   1
 typedef struct ra_options {
