@@ -87,6 +87,8 @@ struct ra_engine {
     int refine_grid = 0;                // waves of a refine_winner_kernel launch
     size_t lds_refine = 0;
     float *d_twx = nullptr, *d_refx = nullptr, *d_cls_refx = nullptr;
+    unsigned long long *d_refhash = nullptr;        // [nref] hashes of the exact reference spectra (ref_hash_kernel)
+    int *d_refdup = nullptr;                        // [2 nref] copies of a reference inside the stack (DevGeom::ref_dup)
     int *d_twxoff = nullptr, *d_rcount = nullptr;
     RefineRec *d_rlist = nullptr;
     int *d_members = nullptr, *d_mcount = nullptr;      // [2 nref][chunk] member lists of a chunk, [2 nref] their lengths (class_members_kernel)
@@ -1047,7 +1049,8 @@ static int setup_refine(ra_engine *e)
     e->d_twx = (float *)dtw; e->d_twxoff = (int *)doff;
     if ((rc = dev_alloc(e, &e->d_refx, (size_t)e->cfg.nref * g.lcirc, true)) ||
         (rc = dev_alloc(e, &e->d_rlist, (size_t)e->chunk, false)) || (e->rlist_cap = e->chunk, 0) ||
-        (rc = dev_alloc(e, &e->d_rcount, 1, true))) return rc;
+        (rc = dev_alloc(e, &e->d_rcount, 1, true)) ||
+        (rc = dev_alloc(e, &e->d_refhash, (size_t)e->cfg.nref, true)) || (rc = dev_alloc(e, &e->d_refdup, (size_t)2 * e->cfg.nref, true))) return rc;
     if (e->refine_gm) {
         if ((rc = dev_alloc(e, &e->d_rscratch, (size_t)std::max(e->refine_grid, e->cfg.nref) * 2 * g.lcirc, false))) return rc;
         // the f64 twiddles and samples stay in LDS (24 maxrin bytes: 96 KB at maxrin 4096, beyond the 64 KB a kernel gets unasked)
@@ -1468,7 +1471,13 @@ extern "C" int ra_set_references(ra_engine *e, const float *d_refs)
             hipLaunchKernelGGL(refspec_exact_kernel<false>, dim3(e->cfg.nref), dim3(RA_EXACT_THREADS), e->lds_refine, e->stream, e->dg, (const int *)e->d_numr,
                                (const float *)e->d_wr, (const float *)e->d_twx, (const int *)e->d_twxoff, d_refs, e->cfg.nref, e->d_refx, (float *)nullptr);
         RA_HIP(hipGetLastError());
-    }
+        // copies of a reference inside the stack: their CCFs are equal to the bit and the CPU scan alone decides among them
+        hipLaunchKernelGGL(ref_hash_kernel, dim3(e->cfg.nref), dim3(256), 0, e->stream, (const float *)e->d_refx, g.lcirc, e->d_refhash);
+        hipLaunchKernelGGL(ref_groups_kernel, dim3(1), dim3(256), 0, e->stream, (const float *)e->d_refx, g.lcirc, e->cfg.nref,
+                           (const unsigned long long *)e->d_refhash, e->d_refdup);
+        RA_HIP(hipGetLastError());
+        e->dg.ref_dup = e->d_refdup;
+    } else e->dg.ref_dup = nullptr;
     if (e->generic || e->fused) {
         hipLaunchKernelGGL(ref_dc_weights_kernel, dim3((e->cfg.nref + 63) / 64), dim3(64), 0, e->stream, e->dg, e->d_refspec, e->cfg.nref, e->d_gcdc);
         RA_HIP(hipGetLastError());

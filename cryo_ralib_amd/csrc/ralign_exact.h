@@ -40,6 +40,7 @@ namespace ralign {
 // GM: the ring buffers live in global memory (boxes whose rings exceed the LDS: 271 KB per offset at 256 x 256 / ou = 120); the
 // workgroup's threads then hand data to each other through the CU's vector cache.
 #define RA_EXACT_THREADS 256
+#define RA_TIE_EXP 64            // entries of the replayed scan: candidates x copies of their references (more: the first 64)
 #define RA_EXACT_TABLE_BYTES(maxrin) ((size_t)24 * (maxrin))      // refine_winner_kernel: [maxrin] double2 twiddles + [maxrin] double samples
 template <bool GM = false> __device__ __forceinline__ void exact_lds_sync()
 {
@@ -305,6 +306,44 @@ __device__ __forceinline__ void exact_candidate(const DevGeom &g, const int *__r
     for (int t = 0; t < 7; t++) b[t] = xs[(jm - 1 + t - 3 + N) & (N - 1)];
 }
 
+// Copies of a reference inside the stack.  hash[r]: 64 bits over the words of reference r's exact spectrum; ref_groups_kernel then
+// compares the spectra of equal hashes word for word and writes DevGeom::ref_dup (first copy, next copy).  One launch each per
+// ra_set_references, nothing goes through the host.
+__global__ __launch_bounds__(256) void ref_hash_kernel(const float *__restrict__ refx, int lcirc, unsigned long long *__restrict__ hash)
+{
+    __shared__ unsigned long long part[4];
+    const unsigned *w = reinterpret_cast<const unsigned *>(refx + (size_t)blockIdx.x * lcirc);
+    unsigned long long h = 0;
+    for (int i = threadIdx.x; i < lcirc; i += 256) {
+        unsigned long long x = ((unsigned long long)w[i] << 32 | (unsigned)(i + 1)) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        h += x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) hash[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void ref_groups_kernel(const float *__restrict__ refx, int lcirc, int nref,
+                                                         const unsigned long long *__restrict__ hash, int *__restrict__ dup)
+{
+    for (int r = threadIdx.x; r < nref; r += 256) {
+        const unsigned *a = reinterpret_cast<const unsigned *>(refx + (size_t)r * lcirc);
+        int first = r, next = -1;
+        for (int r2 = 0; r2 < nref; r2++) {
+            if (r2 == r || hash[r2] != hash[r] || (r2 > r && next >= 0)) continue;
+            if (r2 < r && first < r) continue;          // the first copy is already known
+            const unsigned *b = reinterpret_cast<const unsigned *>(refx + (size_t)r2 * lcirc);
+            bool eq = true;
+            for (int i = 0; i < lcirc && eq; i++) eq = a[i] == b[i];
+            if (!eq) continue;
+            if (r2 < r) first = r2; else next = r2;
+        }
+        dup[2 * r] = first; dup[2 * r + 1] = next;
+    }
+}
+
 // refx: exact reference spectra [nref][lcirc] (refspec_exact_kernel); res, particles, cls, state: of the chunk (indexed by rec.p)
 // GM: the flagged particles are dealt to gridDim.x waves (each with 2 lcirc floats of global scratch in gscr)
 template <bool GM>
@@ -319,10 +358,13 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     extern __shared__ __align__(16) float lds[];
     __shared__ double red[4];
     __shared__ int redi[4];
-    __shared__ long long cand_key[RA_TIE_ALTS + 1];          // the candidates of a float tie: scan-order key, (reference, mirror, bin,
-    __shared__ int cand_inf[RA_TIE_ALTS + 1][4];             // offset), the 7 CCF samples around the maximum (double)
+    __shared__ int cand_inf[RA_TIE_ALTS + 1][4];             // the candidates of a float tie: (reference, mirror, bin, offset),
+                                                             // the 7 CCF samples around the maximum (double)
     __shared__ double cand_b[RA_TIE_ALTS + 1][7];
     __shared__ int cand_win;
+    __shared__ long long ex_key[RA_TIE_EXP];                 // the replay list: the candidates and the copies of their references
+    __shared__ unsigned char ex_ci[RA_TIE_EXP], ex_mir[RA_TIE_EXP];
+    __shared__ int ex_ref, ex_bs;
     const int lane = threadIdx.x;
     float *circ, *work;
     if constexpr (GM) { circ = gscr + (size_t)blockIdx.x * 2 * g.lcirc; work = circ + g.lcirc; }
@@ -347,17 +389,19 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
     double b[7];
     exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref * g.lcirc), bs, rec.sxi, rec.syi, mirror != 0, jtot, b,
                         circ, work, lane, red, redi, twd, xs);
-    if (rec.nalt > 0) {
+    const bool copies = g.ref_dup && !cls && (g.ref_dup[2 * ref] != ref || g.ref_dup[2 * ref + 1] >= 0);
+    if (rec.nalt > 0 || copies) {
         // the other candidates within the tie tolerance of the winner: every peak in the CPU path's arithmetic, then the CPU path's
         // own scan over them -- offsets, then references, ascending; per (offset, reference) "if (qn >= peak || qm >= peak)
         // { if (qn >= qm) straight else mirrored; peak = that }" -- replayed literally, because it is NOT a total order in the
         // multi-reference entry point: Util::multiref_polar_ali_2d keeps `peak` as a FLOAT (peak = static_cast<float>(qn)) and
         // compares the next double against the rounded value, so of two offsets whose maxima round to the same float the earlier
         // one stays when its value was rounded up (108 / 46 / ts 0.5: both 6459.770508).  ormq keeps a double.
-        // candidates that are not in the list lie below the tolerance and cannot win; the list is replayed in scan order.
+        // Candidates that are not in the list lie below the tolerance and cannot win.  COPIES of a candidate's reference
+        // (DevGeom::ref_dup) take part with the candidate's own values -- their spectra are equal to the bit --: of k copies the
+        // float rule keeps the first when its peak was rounded up and takes the last otherwise.
         const int ncand = 1 + rec.nalt;
         if (lane == 0) {
-            cand_key[0] = ((long long)bs << 32) | ((long long)rec.brt << 16) | (unsigned)ref;
             cand_inf[0][0] = ref; cand_inf[0][1] = mirror; cand_inf[0][2] = jtot; cand_inf[0][3] = bs;
             for (int t = 0; t < 7; t++) cand_b[0][t] = b[t];
         }
@@ -369,40 +413,53 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refine_winner_kernel(DevGeom
             exact_candidate<GM>(g, numr, tw, twoff, img, cbase + (cls ? (size_t)0 : (size_t)ref2 * g.lcirc), alt.bs, rec.sxi, rec.syi,
                                 mirror2 != 0, jt2, b2, circ, work, lane, red, redi, twd, xs);
             if (lane == 0) {
-                cand_key[ai + 1] = ((long long)alt.bs << 32) | ((long long)alt.rt << 16) | (unsigned)ref2;
                 cand_inf[ai + 1][0] = ref2; cand_inf[ai + 1][1] = mirror2; cand_inf[ai + 1][2] = jt2; cand_inf[ai + 1][3] = alt.bs;
                 for (int t = 0; t < 7; t++) cand_b[ai + 1][t] = b2[t];
             }
         }
         __syncthreads();
         if (lane == 0) {
+            int nex = 0;
+            for (int ci = 0; ci < ncand; ci++) {
+                const int r0 = cand_inf[ci][0];
+                const long long hi = (long long)cand_inf[ci][3] << 32;
+                if (g.ref_dup && !cls) {
+                    for (int r2 = g.ref_dup[2 * r0]; r2 >= 0 && nex < RA_TIE_EXP; r2 = g.ref_dup[2 * r2 + 1]) {
+                        ex_key[nex] = hi | (unsigned)r2; ex_ci[nex] = (unsigned char)ci; ex_mir[nex] = (unsigned char)cand_inf[ci][1]; nex++;
+                    }
+                } else if (nex < RA_TIE_EXP) {
+                    ex_key[nex] = hi | (unsigned)r0; ex_ci[nex] = (unsigned char)ci; ex_mir[nex] = (unsigned char)cand_inf[ci][1]; nex++;
+                }
+            }
             const bool float_peak = g.mode == RA_MODE_MREF;
             double peak = -1.0e23;
             int cur = -1;
-            unsigned used = 0;
-            for (int step = 0; step < ncand; step++) {
+            unsigned long long used = 0;
+            for (int step = 0; step < nex; step++) {
                 int c = -1;          // the next (offset, reference) in scan order
-                for (int k = 0; k < ncand; k++)
-                    if (!((used >> k) & 1) && (c < 0 || cand_key[k] < cand_key[c])) c = k;
+                for (int k = 0; k < nex; k++)
+                    if (!((used >> k) & 1) && (c < 0 || ex_key[k] < ex_key[c])) c = k;
                 if (c < 0) break;
-                int cs = -1, cm = -1;          // its straight and mirrored candidates (the first of each, duplicates are dropped)
-                for (int k = 0; k < ncand; k++)
-                    if (!((used >> k) & 1) && cand_key[k] == cand_key[c]) {
-                        used |= 1u << k;
-                        if (cand_inf[k][1]) { if (cm < 0) cm = k; } else { if (cs < 0) cs = k; }
+                int cs = -1, cm = -1;          // its straight and mirrored entries (the first of each, duplicates are dropped)
+                for (int k = 0; k < nex; k++)
+                    if (!((used >> k) & 1) && ex_key[k] == ex_key[c]) {
+                        used |= 1ull << k;
+                        if (ex_mir[k]) { if (cm < 0) cm = k; } else { if (cs < 0) cs = k; }
                     }
-                const double qn = cs >= 0 ? cand_b[cs][3] : -1.0e300, qm = cm >= 0 ? cand_b[cm][3] : -1.0e300;
+                const double qn = cs >= 0 ? cand_b[ex_ci[cs]][3] : -1.0e300, qm = cm >= 0 ? cand_b[ex_ci[cm]][3] : -1.0e300;
                 if (qn >= peak || qm >= peak) {
                     cur = qn >= qm ? cs : cm;
                     const double v = qn >= qm ? qn : qm;
                     peak = float_peak ? (double)(float)v : v;
                 }
             }
-            cand_win = cur < 0 ? 0 : cur;
+            if (cur < 0) cur = 0;
+            cand_win = ex_ci[cur];
+            ex_ref = (int)(ex_key[cur] & 0xffffffffll); ex_bs = (int)(ex_key[cur] >> 32);
         }
         __syncthreads();
         const int wsel = cand_win;
-        ref = cand_inf[wsel][0]; mirror = cand_inf[wsel][1]; jtot = cand_inf[wsel][2]; bs = cand_inf[wsel][3];
+        ref = ex_ref; mirror = cand_inf[wsel][1]; jtot = cand_inf[wsel][2]; bs = ex_bs;
 #pragma unroll
         for (int t = 0; t < 7; t++) b[t] = cand_b[wsel][t];
         __syncthreads();

@@ -86,6 +86,11 @@ struct DevGeom {
     // order -- particle p owns entries ent_base[p] .. ent_base[p + 1] - 1 (live_scan_kernel), *ent_total of them in the chunk; null:
     // entry of (p, s) = p * ent_stride + s
     const int *ent_base, *ent_total;
+    // copies of a reference inside the stack (ref_groups_kernel, ralign_exact.h): ref_dup[2 r] = the first reference whose exact
+    // spectrum equals reference r's bit for bit (r itself: none before it), ref_dup[2 r + 1] = the next one behind r (-1: none).
+    // Their CCFs are equal to the bit, so the CPU scan alone decides among them; a winner with copies goes to refine_winner_kernel,
+    // which replays the scan over all of them.  null: no exact re-evaluation (ra_set_refine(0)) / class-resident references
+    const int *ref_dup;
     // wave-job schedule of the polar kernel (4 search offsets per pass)
     int n_job, n_qtab, n_inst;
     int n_job_b;                  // search_duo_kernel: jobs [n_job, n_job + n_job_b) = the ring jobs of a pass's second offset (0: as the first)
@@ -1556,7 +1561,8 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, int p, const Win
         const float thr = peak - (g.norm_ring ? fmaxf(RA_TIE_RTOL_OFFSETS, 1.0e-7f * sqrtf((float)g.lcirc)) : RA_TIE_RTOL) * fabsf(peak);
         const bool tie_rec = second >= thr;
         const int runner = (jword >> 13) & 0xff;          // another reference of the winning offset within the tolerance
-        if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner) {
+        const bool copies = g.ref_dup && (g.ref_dup[2 * ref] != ref || g.ref_dup[2 * ref + 1] >= 0);      // the winner has copies in the stack
+        if (rthr < 0.f || fabsf(c3) < rthr * tmax || tie_bin || tie_rec || runner || copies) {
             RefineRec *rec = rlist + atomicAdd(rcount, 1);
             // (p_base: index of the chunk's first particle when the list spans a whole call)
             rec->p = p_base + p; rec->ref = ref; rec->mirror = mirror; rec->jtot = best.jtot; rec->bs = bs; rec->brt = brt;
