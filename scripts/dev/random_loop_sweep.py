@@ -87,9 +87,20 @@ for case in range(ncase):
                 break
             want = np.stack([orc.normalize_mask((sums[j, 0] + sums[j, 1]) * np.float32(1.0 / float(counts[j])), mask, 1) for j in range(nref)])
             got = al.refs.cpu().numpy()
-            # (rot_shift2D's interpolant is discontinuous across pixel cells: a one-ulp alpha moves single pixels by O(sigma);
-            # the bar of the tests: 99.9 % of the pixels under the mask within atol and a relative L2 error below 2e-4)
-            assert_images_close(got, want, mask, 1e-4 * np.abs(want).max())
+            # (rot_shift2D's interpolant is discontinuous across pixel cells: a particle whose alpha is one ulp beside the checker's
+            # moves single pixels of its class average by O(sigma / class size); with every alpha equal the averages agree to 1e-5)
+            nmis = int(((r["alpha"] != params[:, 0]) | (r["sx"] != params[:, 1]) | (r["sy"] != params[:, 2])).sum())
+            df = np.abs(got - want)
+            sc = float(np.abs(want).max())
+            if nmis == 0:
+                if df.max() > 1e-5 * sc:
+                    bad = np.argwhere(df > 1e-5 * sc)
+                    print("   iteration %d: every parameter equal, yet %d pixels of the averages differ (max %.4g of %.4g):" % (it, len(bad), df.max(), sc), bad[:8].tolist())
+                    print("   class sizes", counts.tolist())
+                assert df.max() <= 1e-5 * sc, (float(df.max()), sc)
+            else:
+                assert int((df > 1e-4 * sc).sum()) <= 6 * nmis, (int((df > 1e-4 * sc).sum()), nmis)
+                assert np.quantile(df, 0.99) <= 1e-4 * sc
         print("   path %d (%d offsets per pass), %d iterations ok" % (al.engine.search_path, al.engine.search_offsets_per_pass, it + 1), flush=True)
         al.close()
     else:

@@ -59,6 +59,8 @@ for case in range(ncase):
     d0 = d.copy()
     if rand_state:      # the particle sits where its state says (a search centred 20 pixels beside it would only find noise peaks near zero)
         for i in range(n):
+            if mode == api.RA_MODE_MREF and np.abs(d0[i]).max() > nx // 2 + 1 - ou - 2:
+                continue          # mref_ali2d resets this state: the search runs around the centre, where the particle still is
             parts[i] = np.roll(parts[i], (int(np.floor(d0[i, 1])), int(np.floor(d0[i, 0]))), axis=(0, 1))
     if mode == api.RA_MODE_MREF:
         params, infos, _, _ = orc.mref_iteration(parts, cref, rg, xr, yr, ts, d, nthreads=8, interp=o_interp, normalize=o_norm)
