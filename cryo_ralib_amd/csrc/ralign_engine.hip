@@ -1540,6 +1540,7 @@ __device__ __forceinline__ void tf_build_d(double a_deg, double tx, double ty, i
 }
 __device__ __forceinline__ void tf_params_d(const double T[3][3], double out[4])
 {
+#pragma clang fp contract(off)
     const double det = T[0][0] * T[1][1] - T[0][1] * T[1][0];
     const int m = det < 0;
     const double sgn = m ? -1.0 : 1.0, c = sgn * T[0][0], s = sgn * T[0][1];
@@ -1552,6 +1553,7 @@ __device__ __forceinline__ void tf_params_d(const double T[3][3], double out[4])
 __global__ void state_from_params_kernel(int n, int mode, const float *__restrict__ cs, const ra_result *__restrict__ res,
                                          float *__restrict__ state)
 {
+#pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     double A[3][3], B[3][3], C[3][3], I[3][3], prm[4];

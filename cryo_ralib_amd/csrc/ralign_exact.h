@@ -166,15 +166,23 @@ __global__ __launch_bounds__(RA_EXACT_THREADS) void refspec_exact_kernel(DevGeom
 __device__ __forceinline__ void finish_params(const DevGeom &g, float sxi, float syi, int jtot, float pos, int bs,
                                               float *alpha_out, float *sx_out, float *sy_out)
 {
+#pragma clang fp contract(off)
     const float tot = (float)jtot + pos;
     const float ang = fmodf(((tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
     const float ixw = g.shift_x[bs], iyw = g.shift_y[bs];
     const float sx = -ixw, sy = -iyw;
-    const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
-    const float sxs = sx * co - sy * so, sys = sx * so + sy * co;
+    // (float tail in Util::multiref_polar_ali_2d, Python doubles in sp_alignment.ormq: finalize_tail)
     const double a = (double)ang * M_PI / 180.0, c = cos(a), s = sin(a);
-    const double tx = c * (double)(-sxi) + s * (double)(-syi) + (double)sxs;
-    const double ty = -s * (double)(-sxi) + c * (double)(-syi) + (double)sys;
+    double sxs, sys;
+    if (g.mode == RA_MODE_MREF) {
+        const float co = (float)c, so = (float)(-s);
+        sxs = (double)(sx * co - sy * so); sys = (double)(sx * so + sy * co);
+    } else {
+        const double co = c, so = -s;
+        sxs = (double)sx * co - (double)sy * so; sys = (double)sx * so + (double)sy * co;
+    }
+    const double tx = c * (double)(-sxi) + s * (double)(-syi) + sxs;
+    const double ty = -s * (double)(-sxi) + c * (double)(-syi) + sys;
     double alpha = atan2(s, c) * 180.0 / M_PI;
     alpha = fmod(alpha, 360.0);
     if (alpha < 0) alpha += 360.0;

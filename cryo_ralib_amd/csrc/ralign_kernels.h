@@ -1522,6 +1522,9 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, int p, const Win
                                               ra_result *__restrict__ res, RefineRec *__restrict__ rlist, int *__restrict__ rcount,
                                               float rthr, int p_base, Scan scan)
 {
+    // (no contraction: the ormq tail sxs = sx co - sy so, sys = sx so + sy co is float arithmetic of two rounded products in the CPU
+    // path; an fma moves sys by one float ulp on ~6 % of the particles -- scripts/dev/alpha_ulp.py)
+#pragma clang fp contract(off)
     const float peak = best.val;
     const int mirror = best.refmir >> 16, ref = best.refmir & 0xffff;
     // Util::prb1d on the winner's neighbourhood, then Util::ang_n, mode F
@@ -1531,12 +1534,20 @@ __device__ __forceinline__ void finalize_tail(const DevGeom &g, int p, const Win
     const float ang = fmodf(((tot - 1.0f) / g.maxrin + 1.0f) * 360.0f, 360.0f);
     const float ixw = g.shift_x[bs], iyw = g.shift_y[bs];
     const float sx = -ixw, sy = -iyw;
-    const float co = (float)cos((double)ang * M_PI / 180.0), so = (float)(-sin((double)ang * M_PI / 180.0));
-    const float sxs = sx * co - sy * so, sys = sx * so + sy * co;
-    // combine_params2(0,-sxi,-syi,0, ang,sxs,sys,mirror) in double: rotate the pre-shift, add
+    // the tail of the search: sxs = sx co - sy so, sys = sx so + sy co -- FLOAT arithmetic with float co, so in
+    // Util::multiref_polar_ali_2d, Python doubles in sp_alignment.ormq
     const double a = (double)ang * M_PI / 180.0, c = cos(a), s = sin(a);
-    const double tx = c * (double)(-w.sxi) + s * (double)(-w.syi) + (double)sxs;
-    const double ty = -s * (double)(-w.sxi) + c * (double)(-w.syi) + (double)sys;
+    double sxs, sys;
+    if (g.mode == RA_MODE_MREF) {
+        const float co = (float)c, so = (float)(-s);
+        sxs = (double)(sx * co - sy * so); sys = (double)(sx * so + sy * co);
+    } else {
+        const double co = c, so = -s;
+        sxs = (double)sx * co - (double)sy * so; sys = (double)sx * so + (double)sy * co;
+    }
+    // combine_params2(0,-sxi,-syi,0, ang,sxs,sys,mirror) in double: rotate the pre-shift, add
+    const double tx = c * (double)(-w.sxi) + s * (double)(-w.syi) + sxs;
+    const double ty = -s * (double)(-w.sxi) + c * (double)(-w.syi) + sys;
     double alpha = atan2(s, c) * 180.0 / M_PI;
     alpha = fmod(alpha, 360.0);
     if (alpha < 0) alpha += 360.0;
