@@ -244,6 +244,38 @@ def test_window_radius_with_a_ring_step():
     np.testing.assert_array_equal(p_in[:, [0, 3, 5]], p_cl[:, [0, 3, 5]])
 
 
+def test_float_running_peak_of_the_multireference_scan():
+    """Util::multiref_polar_ali_2d keeps its running `peak` as a float (peak = static_cast<float>(qn)) and compares the next
+    candidate's double with the rounded value.  With three copies of a reference in the stack (equal CCFs to the bit) the scan
+    therefore keeps the FIRST copy when its peak was rounded up and ends on the LAST one otherwise -- never on the middle one;
+    both outcomes occur.  ormq with Normalize_ring (orc_set_ormq_normalize) finds the same peaks as the one-reference
+    multi-reference search from a zero state."""
+    nx, ou, xr, nref, n = 64, 24, 2, 6, 96
+    refs = synth.make_references(nref, nx, ou)
+    refs[3] = refs[1]; refs[5] = refs[1]
+    parts, truth = synth.make_particles(refs, n, xr, xr, 0.5, ou=ou)
+    rg = orc.rings(1, ou, 1)
+    mask = orc.model_circle(ou, nx, nx)
+    _, cref = orc.prepare_refs(refs, mask, rg)
+    d = np.zeros((n, 2), np.float32)
+    params, _, _, _ = orc.mref_iteration(parts, cref, rg, xr, xr, 1.0, d, nthreads=8)
+    won = params[:, 4].astype(int)
+    copies = won[np.isin(won, (1, 3, 5))]
+    assert len(copies) >= 20
+    assert not (copies == 3).any()
+    assert (copies == 1).any() and (copies == 5).any()
+    # ormq on normalised rings against the one-reference multi-reference search
+    d1 = np.zeros((n, 2), np.float32); d2 = np.zeros((n, 2), np.float32)
+    pm, _, _, _ = orc.mref_iteration(parts, cref[:1], rg, xr, xr, 1.0, d1, nthreads=8)
+    orc.set_ormq_normalize(True)
+    try:
+        po, _, _, _ = orc.reffree_iteration(parts, cref[0], rg, xr, xr, 1.0, (0, 0), d2, np.zeros((n, 6), np.float32), nthreads=8)
+    finally:
+        orc.set_ormq_normalize(False)
+    np.testing.assert_allclose(po[:, 5], pm[:, 5], rtol=1e-6)
+    assert (np.abs(d1 - d2).max(1) < 1e-6).mean() >= 0.98
+
+
 @pytest.mark.parametrize("nx,ou,nref,xr", [(90, 36, 4, 3), (32, 12, 3, 2)])
 def test_planted_truth_recovery(nx, ou, nref, xr):
     """particles = rot_shift2D(reference, planted); the search must return the inverse so that
