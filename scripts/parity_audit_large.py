@@ -45,6 +45,9 @@ CASES = {
     "reffree_half": (90, 36, 2, 1, "template", 0.5),
     "box100_half": (100, 40, 1, 10, None, 0.5),         # search_pair_kernel
     "nb00_half": (130, 52, 1, 20, None, 0.5),           # search_solo / duo kernels
+    "mref_quarter": (90, 36, 1, 10, None, 0.25),        # quarter-pixel steps, 81 offsets: the ridge holds more near-ties per particle
+    "mref_eighth": (90, 36, 0.5, 10, None, 0.125),      # eighth-pixel steps, 81 offsets (stress of the candidate list: RA_TIE_ALTS)
+    "reffree_quarter": (90, 36, 1, 1, "template", 0.25),
     "box150_half": (150, 66, 1, 10, None, 0.5),         # size-generic kernels (ring zones), lcirc = 24 k samples
     "largebox_half": (256, 120, 1, 20, None, 0.5),      # configs[4] geometry at half-pixel steps, lcirc = 71 k samples
     "largebox": (256, 120, 5, 100, None),               # BASELINE configs[4] geometry (generic kernels); at most 8192 particles: the oracle needs ~0.5 s of 16 threads each
